@@ -1,0 +1,213 @@
+"""
+CPU tests: the numpy oracle (oracle/mf_oracle.py) against the golden vectors.
+
+Golden vectors come from (a) the reference's own known-answer tests and (b) the reference's
+``collie.loss`` functions / embedding layers + torch run in the build container
+(tests/golden/make_golden.py).  Tolerance: 1e-5 relative (fp32), the bar BASELINE.json states.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import mf_oracle as O
+
+RTOL = 1e-5
+
+
+def close(a, b, rtol=RTOL, atol_scale=None):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    scale = np.abs(b).max() if atol_scale is None else atol_scale
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=rtol * max(scale, 1e-30))
+
+
+@pytest.fixture(scope='module')
+def known(golden_dir):
+    with open(os.path.join(golden_dir, 'ref_known_answers.json')) as f:
+        return json.load(f)
+
+
+# ------------------------------------------------------------------ reference known answers
+def _loss_fixture(known):
+    L = known['loss']
+    S = np.array(L['scores'], np.float32)
+    pi = np.array(L['positive_items'])
+    ni = np.array(L['negative_items'])
+    mni = np.array(L['many_negative_items'])
+    meta = {'a': np.array(L['metadata_a']), 'b': np.array(L['metadata_b'])}
+    return L, S, pi, ni, mni, meta
+
+
+def test_ideal_difference_known_answers(known):
+    L, S, pi, ni, mni, meta = _loss_fixture(known)
+    d = O.ideal_difference(pi, ni, {'a': meta['a']}, {'a': .2})
+    np.testing.assert_array_equal(d, np.array(L['metadata_a_diff'], np.float32))
+    d2 = O.ideal_difference(np.tile(pi, (4, 1)), mni, meta, {'a': .2, 'b': .3})
+    np.testing.assert_array_equal(d2, np.array(L['metadata_a_and_2_diff'], np.float32))
+    with pytest.raises(ValueError, match='sum of metadata weights was 1.1, must be <=1'):
+        O.ideal_difference(pi, ni, meta, {'a': .2, 'b': .9})
+
+
+def test_losses_known_answers(known):
+    L, S, pi, ni, mni, meta = _loss_fixture(known)
+    ps, ns, mns = S[pi], S[ni], S[mni]
+    w2 = {'a': .2, 'b': .3}
+    got = {
+        'bpr': O.loss_and_score_grads('bpr', ps, ns)[0],
+        'hinge': O.loss_and_score_grads('hinge', ps, ns)[0],
+        'adaptive_bpr': O.loss_and_score_grads('adaptive_bpr', ps, mns)[0],
+        'adaptive_hinge': O.loss_and_score_grads('adaptive_hinge', ps, mns)[0],
+        'warp_num_items_4': O.loss_and_score_grads('warp', ps, mns, num_items=4)[0],
+        'bpr_meta_a_0.2': O.loss_and_score_grads('bpr', ps, ns, None, pi, ni, {'a': meta['a']}, {'a': .2})[0],
+        'hinge_meta_a_0.2': O.loss_and_score_grads('hinge', ps, ns, None, pi, ni, {'a': meta['a']}, {'a': .2})[0],
+        'adaptive_bpr_meta_a0.2_b0.3': O.loss_and_score_grads('adaptive_bpr', ps, mns, None, pi, mni, meta, w2)[0],
+        'adaptive_hinge_meta_a0.2_b0.3': O.loss_and_score_grads('adaptive_hinge', ps, mns, None, pi, mni, meta, w2)[0],
+        'warp_meta_a0.2_b0.3_num_items_4': O.loss_and_score_grads('warp', ps, mns, 4, pi, mni, meta, w2)[0],
+    }
+    for key, val in got.items():
+        # the reference's own tests: 3 decimals (tests/test_losses.py)
+        np.testing.assert_almost_equal(float(val), L['expected_3dp'][key], decimal=3)
+        # the reference's functions run in the build container: 1e-5 relative
+        close(val, L['reference_run'][key])
+    close(O.loss_and_score_grads('bpr', np.float32([3.0]), np.float32([1.5]))[0],
+          L['reference_run']['doc_bpr_3.0_1.5'])
+    np.testing.assert_almost_equal(L['reference_run']['doc_bpr_3.0_1.5'], 0.2157, decimal=4)
+    close(O.loss_and_score_grads('warp', np.float32([1.5]), np.float32([[2.0], [3.0], [2.5]]), 30)[0],
+          L['reference_run']['doc_warp_1.5_[2,3,2.5]_n30'])
+    np.testing.assert_almost_equal(L['reference_run']['doc_warp_1.5_[2,3,2.5]_n30'], 31.1301, decimal=3)
+
+
+def test_metrics_known_answers(known):
+    M = known['metrics']
+    tg = sp.coo_matrix((np.ones(8), (M['users'], M['items'])), shape=(3, 4))
+    csr = tg.tocsr()
+    P = np.array(M['predicted_scores'], np.float32)
+    # tests/test_metrics.py:78-98 labels of the given recs
+    np.testing.assert_array_equal(O._labels(csr, np.arange(3), np.array(M['recs'])), np.array(M['labels'], float))
+    np.testing.assert_array_equal(O.topk_ids(P, 4), np.array(M['recs']))
+    assert O.mapk(csr, np.array([1, 2]), P[[1, 2]], k=4) == M['mapk_k4_users_1_2']
+    np.testing.assert_almost_equal(O.mapk(csr, np.arange(3), P, k=1), M['mapk_k1_all'])
+    np.testing.assert_almost_equal(O.mrr(csr, np.arange(3), P), M['mrr_all'])
+    np.testing.assert_almost_equal(O.auc_per_user(csr, np.arange(3), P), M['auc_sklearn_per_user'])
+    with pytest.raises(ValueError):
+        O.mapk(csr, np.arange(3), P, k=5)
+
+
+class _FixedScores(dict):
+    """tables stand-in whose forward returns a fixed score matrix (the reference mocks the model)."""
+
+
+@pytest.mark.parametrize('batch_size', [20, 2, 1])
+def test_evaluate_in_batches_known_answers(known, batch_size, monkeypatch):
+    M = known['metrics']
+    tg = sp.coo_matrix((np.ones(8), (M['users'], M['items'])), shape=(3, 4))
+    P = np.array(M['predicted_scores'], np.float32)
+    monkeypatch.setattr(O, 'get_preds', lambda tables, user_ids, n_items, y_range=None: P[np.asarray(user_ids)])
+    m, r, a = O.evaluate_in_batches([O.mapk, O.mrr, O.auc], tg, None, k=4, batch_size=batch_size)
+    exp = M['evaluate_in_batches_k4']
+    np.testing.assert_almost_equal(m, exp['mapk'])
+    np.testing.assert_almost_equal(r, exp['mrr'])
+    np.testing.assert_almost_equal(a, exp['auc'])
+
+
+# ------------------------------------------------------------------ reference-generated vectors
+def test_loss_and_score_grads_vs_reference(golden_dir):
+    z = np.load(os.path.join(golden_dir, 'loss_cases.npz'))
+    meta = {'a': z['meta_a'], 'b': z['meta_b']}
+    w = {'a': 0.2, 'b': 0.3}
+    N = int(z['num_items'])
+    for tag in z['cases']:
+        kind, use_meta, variant = tag.split('|')
+        sp_, sn_ = z[tag + '|s_pos'], z[tag + '|s_neg']
+        pos, neg = z[tag + '|pos'], z[tag + '|neg']
+        single = kind in ('bpr', 'hinge')
+        kw = dict(metadata=meta, metadata_weights=w) if use_meta == '1' else {}
+        loss, gp, gn, sel = O.loss_and_score_grads(
+            kind, sp_, sn_[0] if single else sn_, N, pos, neg[0] if single else neg, **kw)
+        close(loss, z[tag + '|loss'])
+        scale = max(np.abs(z[tag + '|g_pos']).max(), 1e-12)
+        close(gp, z[tag + '|g_pos'], atol_scale=scale)
+        close(gn.reshape(sn_.shape), z[tag + '|g_neg'], atol_scale=scale)
+
+
+def test_forward_vs_torch(golden_dir):
+    z = np.load(os.path.join(golden_dir, 'forward_cases.npz'))
+    for D in (1, 3, 8, 10, 30, 64, 100, 128, 256):
+        tables = {n: z[f'D{D}|t|{n}'] for n in ('user_embeddings', 'item_embeddings', 'user_biases', 'item_biases')}
+        for y, yr in ((0, None), (1, (1.0, 5.0))):
+            p = O.mf_forward(tables, z[f'D{D}|users'], z[f'D{D}|items'], yr)
+            ref = z[f'D{D}|y{y}|preds']
+            close(p, ref)
+
+
+def test_calculate_loss_and_sparse_grads_vs_reference(golden_dir):
+    z = np.load(os.path.join(golden_dir, 'train_cases.npz'))
+    meta = {'a': z['meta_a'], 'b': z['meta_b']}
+    w = {'a': 0.2, 'b': 0.3}
+    names = ('user_embeddings', 'item_embeddings', 'user_biases', 'item_biases')
+    for tag in z['cases']:
+        kind, D, K, m = tag.split('|')
+        tables = {n: z[f'{tag}|t|{n}'] for n in names}
+        kw = dict(metadata=meta, metadata_weights=w) if m == 'm1' else {}
+        out = O.calculate_loss(tables, z[f'{tag}|users'], z[f'{tag}|pos'], z[f'{tag}|neg'], kind, **kw)
+        close(out['loss'], z[f'{tag}|loss'])
+        close(out['s_pos'], z[f'{tag}|s_pos'])
+        close(out['s_neg'], z[f'{tag}|s_neg'])
+        for n in names:
+            rows, vals = out['grads'][n]
+            np.testing.assert_array_equal(rows, z[f'{tag}|g|{n}|rows'])      # touched set: exact
+            ref = z[f'{tag}|g|{n}|vals']
+            close(vals, ref, atol_scale=max(np.abs(z[f'{tag}|g|item_embeddings|vals']).max(), 1e-12))
+
+
+def test_optimizer_trajectories_vs_torch(golden_dir):
+    z = np.load(os.path.join(golden_dir, 'optimizer_cases.npz'))
+    combos = json.loads(str(z['combos']))
+    names = ('user_embeddings', 'item_embeddings', 'user_biases', 'item_biases')
+    for tag, sparse, opt, bopt, lr, blr, wd, kind, K in combos:
+        tables = {n: z[f'{tag}|t0|{n}'] for n in names}
+        st = O.TrainState(tables, optimizer=opt, bias_optimizer=bopt, lr=lr, bias_lr=blr,
+                          weight_decay=wd, sparse=sparse)
+        for s in range(4):
+            out = st.step(z[f'{tag}|s{s}|users'], z[f'{tag}|s{s}|pos'], z[f'{tag}|s{s}|neg'], kind)
+            close(out['loss'], z[f'{tag}|s{s}|loss'], rtol=2e-5)
+            for n in names:
+                ref = z[f'{tag}|s{s}|t|{n}']
+                if n == 'user_biases':
+                    # d(loss)/d(user bias) is analytically 0 for every pairwise loss (the bias
+                    # cancels in s+ - s-).  The reference's value is the fp32 residue of
+                    # (+g) + (-g) sums in coalesce order; Adam-type optimizers normalise that
+                    # residue into O(lr) random steps.  Not a parity target: only check that the
+                    # reference's drift (and the oracle's, which sums in the same way) is noise-sized.
+                    assert np.abs(ref).max() <= 4 * (blr or lr) * (s + 1)
+                    assert np.abs(st.t[n]).max() <= 4 * (blr or lr) * (s + 1)
+                    continue
+                close(st.t[n], ref, rtol=2e-5)
+                for key, mine in (('exp_avg', 'm'), ('exp_avg_sq', 'v'), ('sum', 'sum')):
+                    k2 = f'{tag}|s{s}|state|{n}|{key}'
+                    if k2 in z.files and n != 'user_biases':
+                        close(st.state[n][mine], z[k2], rtol=2e-5)
+
+
+def test_eval_case(golden_dir):
+    z = np.load(os.path.join(golden_dir, 'eval_case.npz'))
+    names = ('user_embeddings', 'item_embeddings', 'user_biases', 'item_biases')
+    tables = {n: z[f't|{n}'] for n in names}
+    N = tables['item_embeddings'].shape[0]
+    coo = sp.coo_matrix((np.ones(len(z['rows'])), (z['rows'], z['cols'])), shape=(9, N))
+    users = z['test_users']
+    preds = O.get_preds(tables, users, N)
+    close(preds, z['preds_torch'])
+    # AUC: pinned to sklearn on torch's sigmoid (the reference's own oracle for this metric)
+    au = O.auc_per_user(coo.tocsr(), users, z['preds_torch'])
+    np.testing.assert_allclose(au, z['auc_sklearn_on_torch_sigmoid'], rtol=1e-5)
+    # engineered exact ties: ids must come out in ascending order inside a tie group
+    ids = O.topk_ids(z['preds_torch'], N)
+    for i in range(len(users)):
+        s = z['preds_torch'][i][ids[i]]
+        assert np.all(np.diff(s) <= 0)
+        same = np.nonzero(np.diff(s) == 0)[0]
+        assert np.all(ids[i][same] < ids[i][same + 1])
