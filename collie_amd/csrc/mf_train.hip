@@ -1,0 +1,398 @@
+// K1: fused calculate_loss + backward coefficients for the implicit MF training step.
+//
+// Replaces, in one launch: users.long()/neg.T/repeat/flatten copies, 8 nn.Embedding lookups,
+// mul+sum+bias adds for B positive and K*B negative pairs (matrix_factorization.py:143-150,
+// base_pipeline.py:610-623), the loss (collie/loss/*.py) and the score-level part of autograd.
+//
+// Mapping (wave64): one wave per sample b.  LPR lanes cooperate on one embedding row (VEC floats
+// per lane, 16-byte loads when dim % 4 == 0), so 64/LPR item rows are gathered per wave-instruction;
+// the user row is read once per sample and stays in registers for all 1+K dot products.
+// After the dot products lane j (0 = positive, 1..K = negatives) owns score j, so the adaptive
+// arg-max (first max wins), the WARP first-violation search and the partial-credit factor are
+// single ballot/ffs steps.  All five losses give at most ONE negative a non-zero gradient, so the
+// backward stage writes just two rows per sample:
+//     stage_u[b] = g * I[pos] - g * I[neg_sel]      (gradient of U[user_b])
+//     stage_i[b] = g * U[user_b]                    (+ for I[pos], - for I[neg_sel])
+// plus g itself (bias gradients) and one 32-bit code per looked-up id that tells the
+// segment-reduce/optimizer kernels which staged row, with which sign, belongs to that id.
+#include "train_ws.h"
+
+namespace collie {
+namespace {
+
+template <int VEC>
+struct Vec;
+template <>
+struct Vec<1> {
+  float v[1];
+};
+template <>
+struct alignas(8) Vec<2> {
+  float v[2];
+};
+template <>
+struct alignas(16) Vec<4> {
+  float v[4];
+};
+
+template <int VEC>
+__device__ __forceinline__ Vec<VEC> vload(const float* p) {
+  return *reinterpret_cast<const Vec<VEC>*>(p);
+}
+template <int VEC>
+__device__ __forceinline__ void vstore(float* p, const Vec<VEC>& x) {
+  *reinterpret_cast<Vec<VEC>*>(p) = x;
+}
+template <int VEC>
+__device__ __forceinline__ Vec<VEC> vzero() {
+  Vec<VEC> z;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) z.v[i] = 0.0f;
+  return z;
+}
+template <int VEC>
+__device__ __forceinline__ float vdot(const Vec<VEC>& a, const Vec<VEC>& b) {
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) s = fmaf(a.v[i], b.v[i], s);
+  return s;
+}
+
+struct FwdParams {
+  collie_mf_tables t;
+  collie_mf_batch b;
+  collie_loss_cfg loss;
+  TrainWs ws;
+  float* s_pos_out;
+  float* s_neg_out;
+  int32_t* status;
+  int need_grad;
+  int nchunks;  // ceil(dim / VEC)
+  float inv_b;
+};
+
+constexpr int kBlock = 256;
+constexpr int kWavesPerBlock = kBlock / kWave;
+
+template <int VEC, int LPR>
+__global__ __launch_bounds__(kBlock) void mf_train_fwd_kernel(const FwdParams p) {
+  constexpr int RPW = kWave / LPR;  // item rows gathered per wave-instruction
+  const int lane = lane_id();
+  const int wave_in_block = threadIdx.x / kWave;
+  const int grp = lane / LPR;
+  const int lig = lane % LPR;
+  const int K = p.b.num_neg;
+  const int D = p.t.dim;
+  const int64_t B = p.b.batch;
+  const int npass = (K + 1 + RPW - 1) / RPW;
+  const bool single_chunk = p.nchunks <= LPR;
+  const bool my_chunk = lig < p.nchunks;
+  const int kind = p.loss.kind;
+
+  float loss1 = 0.0f, loss2 = 0.0f;
+
+  const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+  for (int64_t b = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave_in_block; b < B;
+       b += nwaves) {
+    // ---- ids: lane 0 = positive item, lanes 1..K = negatives -------------------------------
+    const int64_t u = load_idx(p.b.users, p.b.users_dtype, b);
+    int64_t item64 = 0;
+    if (lane == 0) {
+      item64 = load_idx(p.b.pos_items, p.b.pos_dtype, b);
+    } else if (lane <= K) {
+      item64 = load_idx(p.b.neg_items, p.b.neg_dtype,
+                        b * p.b.neg_stride_b + static_cast<int64_t>(lane - 1) * p.b.neg_stride_k);
+    }
+    const bool bad_item = lane <= K && (item64 < 0 || item64 >= p.t.num_items);
+    const bool bad = (u < 0 || u >= p.t.num_users) || (__ballot(bad_item) != 0ull);
+    if (bad) {  // wave-uniform: never touch memory through a bad id
+      if (lane == 0) {
+        if (p.status) atomicOr(p.status, 1);
+        if (p.need_grad) {
+          p.ws.gcoef[b] = 0.0f;
+          p.ws.side[COLLIE_SIDE_USER].codes[b] = kCodeNone;
+        }
+      }
+      if (p.need_grad && lane <= K) {
+        const int64_t slot = lane == 0 ? b : B + b * K + (lane - 1);
+        p.ws.side[COLLIE_SIDE_ITEM].codes[slot] = kCodeNone;
+      }
+      continue;
+    }
+    const int item = static_cast<int>(item64);
+
+    const float ub = p.t.user_bias[u];
+    const float ib = lane <= K ? p.t.item_bias[item] : 0.0f;
+    const float* urow = p.t.user_emb + u * D;
+
+    // ---- 1+K dot products; lane j ends up with dot_j ---------------------------------------
+    float mydot = 0.0f;
+    Vec<VEC> uvec = vzero<VEC>();
+    Vec<VEC> ipos = vzero<VEC>();
+    if (single_chunk && my_chunk) uvec = vload<VEC>(urow + lig * VEC);
+    for (int pass = 0; pass < npass; ++pass) {
+      const int j = pass * RPW + grp;
+      const int it = __shfl(item, j <= K ? j : K, kWave);
+      const float* irow = p.t.item_emb + static_cast<int64_t>(it) * D;
+      float part = 0.0f;
+      if (j <= K) {
+        if (single_chunk) {
+          if (my_chunk) {
+            const Vec<VEC> iv = vload<VEC>(irow + lig * VEC);
+            part = vdot<VEC>(uvec, iv);
+            if (pass == 0) ipos = iv;  // group 0 keeps the positive row for the backward stage
+          }
+        } else {
+          for (int c = lig; c < p.nchunks; c += LPR)
+            part += vdot<VEC>(vload<VEC>(urow + c * VEC), vload<VEC>(irow + c * VEC));
+        }
+      }
+      part = group_sum<LPR>(part);
+      const float got = __shfl(part, (lane % RPW) * LPR, kWave);
+      if (lane / RPW == pass) mydot = got;
+    }
+    const float s = (mydot + ub) + ib;  // matrix_factorization.py:146-150
+
+    // ---- partial credit: c_j = 1 - sum_m w_m [meta_m[pos] == meta_m[neg_j]] -----------------
+    float c = 1.0f;
+    if (p.loss.n_meta > 0) {
+      const int pos_item = __shfl(item, 0, kWave);
+      float frac = 0.0f;
+      if (lane >= 1 && lane <= K) {
+        for (int m = 0; m < p.loss.n_meta; ++m)
+          frac += (p.loss.meta[m][pos_item] == p.loss.meta[m][item]) ? p.loss.meta_weight[m] : 0.0f;
+      }
+      c = 1.0f - frac;
+    }
+
+    // ---- loss, selected negative, score gradient ---------------------------------------------
+    const float sp = __shfl(s, 0, kWave);
+    const bool isneg = lane >= 1 && lane <= K;
+    int sel = 1;
+    float ell = 0.0f, g = 0.0f;
+    if (kind == COLLIE_LOSS_WARP) {
+      const float h = (c - sp) + s;  // warp.py:99
+      const unsigned long long viol = __ballot(isneg && h > 0.0f);
+      if (viol) {
+        sel = __ffsll(static_cast<long long>(viol)) - 1;  // == number of tries (1-based)
+        const float ht = __shfl(h, sel, kWave);
+        const float w = logf(static_cast<float>(p.loss.num_items) / static_cast<float>(sel));
+        ell = w * ht;
+        g = -(w * (1.0f + 2.0f * ell)) * p.inv_b;
+      }
+    } else {
+      if (kind == COLLIE_LOSS_ADAPTIVE_BPR || kind == COLLIE_LOSS_ADAPTIVE_HINGE) {
+        const float top = wave_max(isneg ? s : -INFINITY);
+        const unsigned long long at = __ballot(isneg && s == top);
+        if (at) sel = __ffsll(static_cast<long long>(at)) - 1;  // first max, as torch.max
+      }
+      const float sn = __shfl(s, sel, kWave);
+      const float cs = __shfl(c, sel, kWave);
+      const float d = sp - sn;
+      if (kind == COLLIE_LOSS_BPR || kind == COLLIE_LOSS_ADAPTIVE_BPR) {
+        const float sig = sigmoidf_(d);
+        ell = cs - sig;
+        g = -(sig * (1.0f - sig)) * (1.0f + 2.0f * ell) * p.inv_b;
+      } else {
+        const float x = cs - d;
+        ell = fmaxf(x, 0.0f);
+        g = x >= 0.0f ? -(1.0f + 2.0f * ell) * p.inv_b : 0.0f;  // clamp passes grad at the kink
+      }
+    }
+    loss1 += ell;
+    loss2 += ell * ell;
+
+    if (p.s_pos_out && lane == 0) p.s_pos_out[b] = s;
+    if (p.s_neg_out && isneg) p.s_neg_out[static_cast<int64_t>(lane - 1) * B + b] = s;
+
+    if (!p.need_grad) continue;
+
+    // ---- backward staging ---------------------------------------------------------------------
+    const bool live = g != 0.0f;
+    if (lane == 0) {
+      p.ws.gcoef[b] = g;
+      p.ws.side[COLLIE_SIDE_USER].codes[b] = live ? static_cast<uint32_t>(b) : kCodeNone;
+      p.ws.side[COLLIE_SIDE_ITEM].codes[b] = live ? static_cast<uint32_t>(b) : kCodeNone;
+    } else if (isneg) {
+      p.ws.side[COLLIE_SIDE_ITEM].codes[B + b * K + (lane - 1)] =
+          (live && lane == sel) ? (static_cast<uint32_t>(b) | kCodeNeg) : kCodeNone;
+    }
+    // shuffles read only from active lanes: take the ids before the divergent region
+    const int sel_item = __shfl(item, sel, kWave);
+    const int pos_item_b = __shfl(item, 0, kWave);
+    if (live && grp == 0) {
+      const float* srow = p.t.item_emb + static_cast<int64_t>(sel_item) * D;
+      float* su = p.ws.stage_u + b * D;
+      float* si = p.ws.stage_i + b * D;
+      if (single_chunk) {
+        if (my_chunk) {
+          const Vec<VEC> isel = vload<VEC>(srow + lig * VEC);
+          Vec<VEC> gu, gi;
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) {
+            gu.v[i] = g * ipos.v[i] - g * isel.v[i];
+            gi.v[i] = g * uvec.v[i];
+          }
+          vstore<VEC>(su + lig * VEC, gu);
+          vstore<VEC>(si + lig * VEC, gi);
+        }
+      } else {
+        const float* prow = p.t.item_emb + static_cast<int64_t>(pos_item_b) * D;
+        for (int cidx = lig; cidx < p.nchunks; cidx += LPR) {
+          const Vec<VEC> a = vload<VEC>(prow + cidx * VEC);
+          const Vec<VEC> n = vload<VEC>(srow + cidx * VEC);
+          const Vec<VEC> uu = vload<VEC>(urow + cidx * VEC);
+          Vec<VEC> gu, gi;
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) {
+            gu.v[i] = g * a.v[i] - g * n.v[i];
+            gi.v[i] = g * uu.v[i];
+          }
+          vstore<VEC>(su + cidx * VEC, gu);
+          vstore<VEC>(si + cidx * VEC, gi);
+        }
+      }
+    }
+  }
+
+  // ---- per-block loss partials (fixed grid -> fixed summation order -> deterministic) ---------
+  __shared__ float red[2][kWavesPerBlock];
+  if (lane == 0) {
+    red[0][wave_in_block] = loss1;
+    red[1][wave_in_block] = loss2;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = 0.0f, c2 = 0.0f;
+    for (int w = 0; w < kWavesPerBlock; ++w) {
+      a += red[0][w];
+      c2 += red[1][w];
+    }
+    p.ws.loss_partials[2 * blockIdx.x] = a;
+    p.ws.loss_partials[2 * blockIdx.x + 1] = c2;
+  }
+}
+
+// loss = (sum l + sum l^2) / B   (bpr.py:89, hinge.py:85, warp.py:133)
+__global__ __launch_bounds__(kWave) void loss_finalize_kernel(const float* partials, int nblocks,
+                                                              float inv_b, float* loss_out) {
+  double a = 0.0, c = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += kWave) {
+    a += partials[2 * i];
+    c += partials[2 * i + 1];
+  }
+  for (int o = kWave / 2; o > 0; o >>= 1) {
+    a += __shfl_xor(a, o, kWave);
+    c += __shfl_xor(c, o, kWave);
+  }
+  if (threadIdx.x == 0) *loss_out = static_cast<float>((a + c) * static_cast<double>(inv_b));
+}
+
+template <int VEC>
+int launch_fwd(int lpr, dim3 grid, hipStream_t stream, const FwdParams& p) {
+  switch (lpr) {
+    case 1: hipLaunchKernelGGL((mf_train_fwd_kernel<VEC, 1>), grid, dim3(kBlock), 0, stream, p); break;
+    case 2: hipLaunchKernelGGL((mf_train_fwd_kernel<VEC, 2>), grid, dim3(kBlock), 0, stream, p); break;
+    case 4: hipLaunchKernelGGL((mf_train_fwd_kernel<VEC, 4>), grid, dim3(kBlock), 0, stream, p); break;
+    case 8: hipLaunchKernelGGL((mf_train_fwd_kernel<VEC, 8>), grid, dim3(kBlock), 0, stream, p); break;
+    case 16: hipLaunchKernelGGL((mf_train_fwd_kernel<VEC, 16>), grid, dim3(kBlock), 0, stream, p); break;
+    case 32: hipLaunchKernelGGL((mf_train_fwd_kernel<VEC, 32>), grid, dim3(kBlock), 0, stream, p); break;
+    default: hipLaunchKernelGGL((mf_train_fwd_kernel<VEC, 64>), grid, dim3(kBlock), 0, stream, p); break;
+  }
+  return check_launch("mf_train_fwd_kernel");
+}
+
+}  // namespace
+
+int validate_tables(const collie_mf_tables* t) {
+  COLLIE_REQUIRE(t != nullptr, "tables is NULL");
+  COLLIE_REQUIRE(t->user_emb && t->item_emb && t->user_bias && t->item_bias,
+                 "tables: NULL table pointer");
+  COLLIE_REQUIRE(t->dim >= 1, "tables: dim must be >= 1 (got %d)", t->dim);
+  COLLIE_REQUIRE(t->num_users >= 1 && t->num_items >= 1, "tables: empty table");
+  COLLIE_REQUIRE(t->num_users < (int64_t{1} << 31) && t->num_items < (int64_t{1} << 31),
+                 "tables: more than 2^31-1 rows per shard is not supported");
+  return 0;
+}
+
+int validate_batch(const collie_mf_batch* b) {
+  COLLIE_REQUIRE(b != nullptr, "batch is NULL");
+  COLLIE_REQUIRE(b->batch >= 1, "batch: batch size must be >= 1");
+  COLLIE_REQUIRE(b->users && b->pos_items && b->neg_items, "batch: NULL index pointer");
+  COLLIE_REQUIRE(b->num_neg >= 1 && b->num_neg <= COLLIE_MAX_NEG,
+                 "batch: num_negative_samples must be in [1, %d] (got %d)", COLLIE_MAX_NEG,
+                 b->num_neg);
+  COLLIE_REQUIRE(b->batch * (1 + static_cast<int64_t>(b->num_neg)) < (int64_t{1} << 30),
+                 "batch: (1 + K) * B must be < 2^30");
+  return 0;
+}
+
+// widest vector width every row start is aligned for
+int pick_vec(const collie_mf_tables* t) {
+  auto aligned = [](const void* p, size_t a) { return reinterpret_cast<uintptr_t>(p) % a == 0; };
+  if (t->dim % 4 == 0 && aligned(t->user_emb, 16) && aligned(t->item_emb, 16)) return 4;
+  if (t->dim % 2 == 0 && aligned(t->user_emb, 8) && aligned(t->item_emb, 8)) return 2;
+  return 1;
+}
+
+}  // namespace collie
+
+using namespace collie;
+
+extern "C" size_t collie_mf_train_workspace_bytes(int64_t batch, int32_t num_neg, int32_t dim) {
+  if (batch < 1 || num_neg < 1 || dim < 1) return 0;
+  return carve_train_ws(nullptr, batch, num_neg, dim).bytes;
+}
+
+extern "C" int collie_mf_train_forward(const collie_mf_tables* t, const collie_mf_batch* b,
+                                       const collie_loss_cfg* loss, void* workspace,
+                                       size_t workspace_bytes, int32_t need_grad, float* loss_out,
+                                       float* s_pos_out, float* s_neg_out, int32_t* status,
+                                       collie_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (validate_tables(t) || validate_batch(b)) return -1;
+  COLLIE_REQUIRE(loss != nullptr && loss_out != nullptr, "loss cfg / loss_out is NULL");
+  COLLIE_REQUIRE(loss->kind >= COLLIE_LOSS_BPR && loss->kind <= COLLIE_LOSS_WARP,
+                 "%d is not a valid loss function.", loss->kind);
+  COLLIE_REQUIRE(loss->n_meta >= 0 && loss->n_meta <= COLLIE_MAX_META,
+                 "at most %d metadata arrays are supported", COLLIE_MAX_META);
+  if (loss->kind == COLLIE_LOSS_BPR || loss->kind == COLLIE_LOSS_HINGE)
+    COLLIE_REQUIRE(b->num_neg == 1, "non-adaptive losses need exactly one negative per sample");
+  if (loss->kind == COLLIE_LOSS_WARP)
+    COLLIE_REQUIRE(b->num_neg > 1, "Cannot use WARP loss with a single negative sample!");
+  TrainWs ws = carve_train_ws(workspace, b->batch, b->num_neg, t->dim);
+  if (need_grad) {
+    COLLIE_REQUIRE(workspace != nullptr && workspace_bytes >= ws.bytes,
+                   "workspace too small: need %zu bytes, got %zu", ws.bytes, workspace_bytes);
+  } else if (workspace == nullptr || workspace_bytes < ws.bytes) {
+    COLLIE_REQUIRE(false, "workspace too small: need %zu bytes, got %zu", ws.bytes,
+                   workspace_bytes);
+  }
+
+  FwdParams p;
+  p.t = *t;
+  p.b = *b;
+  p.loss = *loss;
+  p.ws = ws;
+  p.s_pos_out = s_pos_out;
+  p.s_neg_out = s_neg_out;
+  p.status = status;
+  p.need_grad = need_grad;
+  p.inv_b = 1.0f / static_cast<float>(b->batch);
+  const int vec = pick_vec(t);
+  p.nchunks = (t->dim + vec - 1) / vec;
+  int lpr = 1;
+  while (lpr < p.nchunks && lpr < kWave) lpr *= 2;
+
+  int64_t nblocks = (b->batch + kWavesPerBlock - 1) / kWavesPerBlock;
+  if (nblocks > kMaxLossBlocks) nblocks = kMaxLossBlocks;
+  dim3 grid(static_cast<unsigned>(nblocks));
+  int rc;
+  if (vec == 4) rc = launch_fwd<4>(lpr, grid, stream, p);
+  else if (vec == 2) rc = launch_fwd<2>(lpr, grid, stream, p);
+  else rc = launch_fwd<1>(lpr, grid, stream, p);
+  if (rc) return rc;
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(kWave), 0, stream, ws.loss_partials,
+                     static_cast<int>(nblocks), p.inv_b, loss_out);
+  return check_launch("loss_finalize_kernel");
+}

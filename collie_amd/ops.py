@@ -1,0 +1,176 @@
+"""
+Thin tensor-level wrappers over the C ABI: they only marshal torch tensors (device pointers,
+current HIP stream) into ``libcollie_hip.so`` calls.  No arithmetic happens in this file.
+"""
+import ctypes
+from ctypes import byref, c_void_p
+
+import torch
+
+from collie_amd import _lib
+from collie_amd._lib import (Batch, LossCfg, OptimCfg, check, idx_dtype, load, make_tables, ptr,
+                             require_hip, stream_ptr)
+
+
+def make_batch(users, pos_items, neg_items):
+    """((users[B], pos[B]), neg[B, K]) exactly as the loaders emit it; no copies, no casts."""
+    for name, t in (('users', users), ('pos_items', pos_items), ('neg_items', neg_items)):
+        require_hip(t, name)
+    if users.dim() != 1 or pos_items.dim() != 1 or neg_items.dim() != 2:
+        raise ValueError('expected users[B], pos_items[B], neg_items[B, K]')
+    B = users.shape[0]
+    if pos_items.shape[0] != B or neg_items.shape[0] != B:
+        raise ValueError('users, pos_items and neg_items disagree on the batch size')
+    if users.stride(0) != 1:
+        users = users.contiguous()
+    if pos_items.stride(0) != 1:
+        pos_items = pos_items.contiguous()
+    batch = Batch(users.data_ptr(), pos_items.data_ptr(), neg_items.data_ptr(), idx_dtype(users),
+                  idx_dtype(pos_items), idx_dtype(neg_items), neg_items.shape[1], B,
+                  neg_items.stride(0), neg_items.stride(1))
+    batch._keepalive = (users, pos_items, neg_items)
+    return batch
+
+
+def make_loss_cfg(kind, num_items, metadata_codes=None, metadata_weights=None):
+    cfg = LossCfg()
+    cfg.kind = _lib.LOSS_KINDS[kind] if isinstance(kind, str) else int(kind)
+    cfg.num_items = int(num_items)
+    metadata_codes = metadata_codes or []
+    metadata_weights = metadata_weights or []
+    if len(metadata_codes) > _lib.MAX_META:
+        raise ValueError(f'at most {_lib.MAX_META} metadata arrays are supported')
+    cfg.n_meta = len(metadata_codes)
+    for i, (codes, w) in enumerate(zip(metadata_codes, metadata_weights)):
+        require_hip(codes, 'metadata')
+        assert codes.dtype == torch.int32 and codes.is_contiguous()
+        cfg.meta[i] = codes.data_ptr()
+        cfg.meta_weight[i] = float(w)
+    cfg._keepalive = list(metadata_codes)
+    return cfg
+
+
+def train_workspace_bytes(batch_size, num_neg, dim):
+    return int(load().collie_mf_train_workspace_bytes(batch_size, num_neg, dim))
+
+
+class TrainWorkspace:
+    """Device scratch of one model; grows on demand, reused every step."""
+
+    def __init__(self, device):
+        self.device = device
+        self.buf = None
+        self.key = None
+
+    def ensure(self, batch_size, num_neg, dim):
+        need = train_workspace_bytes(batch_size, num_neg, dim)
+        if need == 0:
+            raise ValueError('empty batch')
+        if self.buf is None or self.buf.numel() < need:
+            self.buf = torch.empty(need, dtype=torch.uint8, device=self.device)
+        self.key = (batch_size, num_neg, dim)
+        return self.buf
+
+
+def train_forward(tables, batch, loss_cfg, ws_buf, need_grad, loss_out, s_pos_out=None,
+                  s_neg_out=None, status=None):
+    check(load().collie_mf_train_forward(
+        byref(tables), byref(batch), byref(loss_cfg), ptr(ws_buf), ws_buf.numel(),
+        1 if need_grad else 0, ptr(loss_out), ptr(s_pos_out), ptr(s_neg_out), ptr(status),
+        stream_ptr()), 'collie_mf_train_forward')
+
+
+def train_build_segments(tables, batch, ws_buf, side):
+    check(load().collie_mf_train_build_segments(
+        byref(tables), byref(batch), ptr(ws_buf), ws_buf.numel(), side, stream_ptr()),
+        'collie_mf_train_build_segments')
+
+
+def train_update(tables, batch, ws_buf, side, is_bias, dense, cfg, state1=None, state2=None,
+                 row_stamp=None, grad_scale=None):
+    check(load().collie_mf_train_update(
+        byref(tables), byref(batch), ptr(ws_buf), ws_buf.numel(), side, 1 if is_bias else 0,
+        1 if dense else 0, byref(cfg), ptr(state1), ptr(state2), ptr(row_stamp), ptr(grad_scale),
+        stream_ptr()), 'collie_mf_train_update')
+
+
+def train_export_grad(tables, batch, ws_buf, side, is_bias):
+    """Coalesced gradient of one table: (rows int64 [n], values [n, D or 1]).  Synchronises."""
+    B, K = batch.batch, batch.num_neg
+    cap = B if side == _lib.SIDE_USER else B * (1 + K)
+    D = 1 if is_bias else tables.dim
+    dev = ws_buf.device
+    rows = torch.empty(cap, dtype=torch.int64, device=dev)
+    vals = torch.empty(cap, D, dtype=torch.float32, device=dev)
+    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    check(load().collie_mf_train_export_grad(
+        byref(tables), byref(batch), ptr(ws_buf), ws_buf.numel(), side, 1 if is_bias else 0,
+        ptr(rows), ptr(vals), ptr(count), stream_ptr()), 'collie_mf_train_export_grad')
+    n = int(count.item())
+    return rows[:n], vals[:n]
+
+
+def optim_cfg(algo, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, lr_decay=0.0):
+    return OptimCfg(_lib.OPT_ALGOS[algo] if isinstance(algo, str) else int(algo), int(step),
+                    float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
+                    float(lr_decay))
+
+
+def mf_score(tables, users, items, y_range=None, status=None):
+    require_hip(users, 'users')
+    require_hip(items, 'items')
+    users = users.contiguous()
+    items = items.contiguous()
+    if users.shape != items.shape or users.dim() != 1:
+        raise ValueError('users and items must be 1-d tensors of the same length')
+    out = torch.empty(users.shape[0], dtype=torch.float32, device=users.device)
+    has_y = y_range is not None
+    check(load().collie_mf_score(
+        byref(tables), ptr(users), idx_dtype(users), ptr(items), idx_dtype(items),
+        users.shape[0], int(has_y), float(y_range[0]) if has_y else 0.0,
+        float(y_range[1]) if has_y else 0.0, ptr(out), ptr(status), stream_ptr()),
+        'collie_mf_score')
+    return out
+
+
+def mf_score_backward(tables, users, items, grad_out, y_range=None, status=None):
+    users = users.contiguous()
+    items = items.contiguous()
+    grad_out = grad_out.contiguous().float()
+    M, D = users.shape[0], tables.dim
+    dev = users.device
+    gu = torch.empty(M, D, dtype=torch.float32, device=dev)
+    gi = torch.empty(M, D, dtype=torch.float32, device=dev)
+    gb = torch.empty(M, 1, dtype=torch.float32, device=dev)
+    has_y = y_range is not None
+    check(load().collie_mf_score_backward(
+        byref(tables), ptr(users), idx_dtype(users), ptr(items), idx_dtype(items), M, int(has_y),
+        float(y_range[0]) if has_y else 0.0, float(y_range[1]) if has_y else 0.0, ptr(grad_out),
+        ptr(gu), ptr(gi), ptr(gb), ptr(status), stream_ptr()), 'collie_mf_score_backward')
+    return gu, gi, gb
+
+
+def loss_forward_backward(loss_cfg, s_pos, s_neg_KB, pos_items=None, neg_items_KB=None,
+                          want_grad=True):
+    """Stand-alone loss on score tensors.  s_neg_KB is [K, B].  Returns (loss[1], g_pos, g_neg)."""
+    require_hip(s_pos, 'positive_scores')
+    require_hip(s_neg_KB, 'negative_scores')
+    s_pos = s_pos.contiguous().float()
+    s_neg_KB = s_neg_KB.contiguous().float()
+    K, B = s_neg_KB.shape
+    dev = s_pos.device
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    g_pos = torch.empty(B, dtype=torch.float32, device=dev) if want_grad else None
+    g_neg = torch.empty(K, B, dtype=torch.float32, device=dev) if want_grad else None
+    partials = torch.empty(2 * int(load().collie_loss_partials(B)), dtype=torch.float32, device=dev)
+    if pos_items is not None:
+        pos_items = pos_items.contiguous().long()
+        neg_items_KB = neg_items_KB.contiguous().long()
+    check(load().collie_loss_forward_backward(
+        byref(loss_cfg), ptr(s_pos), ptr(s_neg_KB), B, K, ptr(pos_items), ptr(neg_items_KB),
+        ptr(loss), ptr(g_pos), ptr(g_neg), ptr(partials), stream_ptr()),
+        'collie_loss_forward_backward')
+    return loss, g_pos, g_neg
+
+
+__all__ = [name for name in dir() if not name.startswith('_')]

@@ -1,0 +1,232 @@
+/*
+ * collie_hip.h — C ABI of libcollie_hip.so: the MI355X (gfx950) implementation of Collie's
+ * matrix-factorization train / eval hot path.
+ *
+ * The reference (ShopRunner/collie, /root/reference) is pure Python and has no FFI layer; the
+ * drop-in boundary is its Python object protocol.  Each entry point below
+ * therefore cites the reference *Python* interface whose inside it replaces.  The host-side
+ * mirror of those Python interfaces lives in collie_amd/ and binds these symbols with ctypes
+ * (collie_amd/_lib.py); INTEGRATION.md shows the binding a Collie maintainer would add.
+ *
+ * Conventions
+ *   - every pointer except `*_cfg`/struct arguments is a DEVICE pointer; the caller owns all
+ *     memory (outputs and workspaces are allocated by the caller, e.g. by torch);
+ *   - all work is enqueued on `stream` (a hipStream_t); nothing here synchronises the device
+ *     or allocates memory, so every entry point may be called under HIP graph capture;
+ *   - return value 0 = ok, negative = error; `collie_last_error()` gives the text
+ *     (thread-local);
+ *   - tables are row-major contiguous fp32: embeddings [rows, dim], biases [rows] ([rows,1]);
+ *   - index arrays are int32 or int64, selected by a `COLLIE_I32/I64` tag;
+ *   - out-of-range ids never fault: the sample is skipped and bit 0 of `*status` (device int32,
+ *     may be NULL) is set.
+ */
+#ifndef COLLIE_HIP_H
+#define COLLIE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* collie_stream_t; /* hipStream_t */
+
+enum { COLLIE_I32 = 0, COLLIE_I64 = 1 };
+
+/* collie/loss/{bpr,hinge,warp}.py of the reference; the adaptive variants are what base_pipeline.py:307-338 selects
+ * whenever num_negative_samples > 1 */
+enum {
+  COLLIE_LOSS_BPR = 0,            /* collie/loss/bpr.py:8-89      */
+  COLLIE_LOSS_HINGE = 1,          /* collie/loss/hinge.py:8-85    */
+  COLLIE_LOSS_ADAPTIVE_BPR = 2,   /* collie/loss/bpr.py:92-167    */
+  COLLIE_LOSS_ADAPTIVE_HINGE = 3, /* collie/loss/hinge.py:88-171  */
+  COLLIE_LOSS_WARP = 4            /* collie/loss/warp.py:8-154    */
+};
+
+/* torch.optim algorithms base_pipeline.py:418-433 can construct */
+enum {
+  COLLIE_OPT_SGD = 0,         /* torch.optim.SGD (momentum 0), sparse or dense grads  */
+  COLLIE_OPT_ADAGRAD = 1,     /* torch.optim.Adagrad, sparse or dense grads           */
+  COLLIE_OPT_SPARSE_ADAM = 2, /* torch.optim.SparseAdam (touched rows only)           */
+  COLLIE_OPT_ADAM = 3         /* torch.optim.Adam (dense: every row, every step)      */
+};
+
+enum { COLLIE_SIDE_USER = 0, COLLIE_SIDE_ITEM = 1 };
+
+#define COLLIE_MAX_META 4
+#define COLLIE_MAX_NEG 63 /* fused training path: one wave lane per (positive|negative) score */
+
+/* The four parameter tables of MatrixFactorizationModel._setup_model
+ * (collie/model/matrix_factorization.py:106-117). */
+typedef struct collie_mf_tables {
+  float* user_emb;  /* user_embeddings.weight [num_users, dim] */
+  float* item_emb;  /* item_embeddings.weight [num_items, dim] */
+  float* user_bias; /* user_biases.weight     [num_users, 1]   */
+  float* item_bias; /* item_biases.weight     [num_items, 1]   */
+  int64_t num_users;
+  int64_t num_items;
+  int32_t dim;
+} collie_mf_tables;
+
+/* One implicit batch ((users, pos_items), neg_items) as the loaders emit it
+ * (collie/interactions/datasets.py:382-388,439-443; base_pipeline.py:608-613).
+ * neg element (b, k) is read at neg[b * neg_stride_b + k * neg_stride_k] (element strides). */
+typedef struct collie_mf_batch {
+  const void* users;
+  const void* pos_items;
+  const void* neg_items;
+  int32_t users_dtype;
+  int32_t pos_dtype;
+  int32_t neg_dtype;
+  int32_t num_neg; /* K */
+  int64_t batch;   /* B */
+  int64_t neg_stride_b;
+  int64_t neg_stride_k;
+} collie_mf_batch;
+
+/* Loss selection + partial-credit metadata (collie/loss/metadata_utils.py:6-71): meta[m] is an
+ * int32 [num_items] array of category codes; weights must sum to <= 1 (checked by the host). */
+typedef struct collie_loss_cfg {
+  int32_t kind;
+  int32_t n_meta;
+  int64_t num_items; /* numerator of the WARP weight ln(num_items / tries), warp.py:120 */
+  const int32_t* meta[COLLIE_MAX_META];
+  float meta_weight[COLLIE_MAX_META];
+} collie_loss_cfg;
+
+/* Hyper-parameters of one torch.optim param group, read by the host from
+ * optimizer.param_groups at every step (LR schedulers mutate them between epochs). */
+typedef struct collie_optim_cfg {
+  int32_t algo;
+  int32_t step; /* 1-based step count of this parameter (bias correction / lr_decay) */
+  float lr;
+  float beta1;
+  float beta2;
+  float eps;
+  float weight_decay;
+  float lr_decay;
+} collie_optim_cfg;
+
+const char* collie_last_error(void);
+int collie_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * A2  MatrixFactorizationModel.forward(users, items)   matrix_factorization.py:120-159
+ * scores[j] = <U[users[j]], I[items[j]]> + bu[users[j]] + bi[items[j]], optional y_range sigmoid.
+ * ------------------------------------------------------------------------------------------- */
+int collie_mf_score(const collie_mf_tables* t, const void* users, int32_t users_dtype,
+                    const void* items, int32_t items_dtype, int64_t m, int32_t has_y_range,
+                    float y_lo, float y_hi, float* scores, int32_t* status,
+                    collie_stream_t stream);
+
+/* autograd of the above (nn.Embedding backward): per pair j
+ *   grad_user_rows[j,:] = g'_j * I[items[j],:],  grad_item_rows[j,:] = g'_j * U[users[j],:],
+ *   grad_bias[j] = g'_j, where g'_j = grad_out[j] (times the y_range sigmoid derivative).
+ * These are the *values* of the uncoalesced sparse COO gradients whose indices are users/items. */
+int collie_mf_score_backward(const collie_mf_tables* t, const void* users, int32_t users_dtype,
+                             const void* items, int32_t items_dtype, int64_t m,
+                             int32_t has_y_range, float y_lo, float y_hi, const float* grad_out,
+                             float* grad_user_rows, float* grad_item_rows, float* grad_bias,
+                             int32_t* status, collie_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * A4-A7  stand-alone loss callables  f(positive_scores, negative_scores, num_items=, ...)
+ * collie/loss/{bpr,hinge,warp,metadata_utils}.py.  s_neg is [K,B] row-major (K = 1 for the
+ * non-adaptive kinds).  Writes the scalar loss and (if non-NULL) d loss / d scores.
+ * pos_items / neg_items ([B] / [K,B], int64) are only read when cfg->n_meta > 0.
+ * ------------------------------------------------------------------------------------------- */
+int collie_loss_forward_backward(const collie_loss_cfg* cfg, const float* s_pos,
+                                 const float* s_neg, int64_t batch, int32_t num_neg,
+                                 const int64_t* pos_items, const int64_t* neg_items,
+                                 float* loss_out, float* grad_pos, float* grad_neg,
+                                 float* partials /* >= 2*collie_loss_partials(batch) floats */,
+                                 collie_stream_t stream);
+int64_t collie_loss_partials(int64_t batch);
+
+/* ---------------------------------------------------------------------------------------------
+ * A3+A4..A8  BasePipeline.calculate_loss(batch) + loss.backward()
+ * base_pipeline.py:603-634, trainer.py:462-463.  One fused kernel: gathers, K+1 dot products per
+ * sample, loss, and the per-sample gradient rows staged in `workspace` for the optimizers.
+ * need_grad = 0 (validation_step) skips the staging.
+ * s_pos_out [B] and s_neg_out [K,B] (reference layout) are optional (NULL to skip).
+ * ------------------------------------------------------------------------------------------- */
+size_t collie_mf_train_workspace_bytes(int64_t batch, int32_t num_neg, int32_t dim);
+int collie_mf_train_forward(const collie_mf_tables* t, const collie_mf_batch* b,
+                            const collie_loss_cfg* loss, void* workspace, size_t workspace_bytes,
+                            int32_t need_grad, float* loss_out, float* s_pos_out,
+                            float* s_neg_out, int32_t* status, collie_stream_t stream);
+
+/* A8 (grad.coalesce(), torch/optim/_functional.py:44): stable LSD radix sort of the looked-up row
+ * ids of one side (users: B ids; items: (1+K)*B ids) + segment heads.  Deterministic: no atomics
+ * on floating-point data anywhere.  Must follow collie_mf_train_forward on the same workspace. */
+int collie_mf_train_build_segments(const collie_mf_tables* t, const collie_mf_batch* b,
+                                   void* workspace, size_t workspace_bytes, int32_t side,
+                                   collie_stream_t stream);
+
+/* A10/A11  optimizer.step() for ONE table of one side:
+ *   is_bias = 0 -> the embedding table, 1 -> the bias table.
+ * Sparse algorithms (sparse=True models): SGD / ADAGRAD / SPARSE_ADAM touch exactly the looked-up
+ * rows, zero-gradient rows included.  Dense algorithms (sparse=False): ADAM / SGD / ADAGRAD with
+ * dense=1 additionally sweep every untouched row with a zero gradient (+ weight decay).
+ * state1 = exp_avg | state_sum, state2 = exp_avg_sq (NULL where the algorithm has none).
+ * row_stamp: int32 [rows] scratch owned by the optimizer, required when dense != 0 and the
+ * zero-gradient update is not the identity (Adam, or weight_decay != 0); NULL otherwise.
+ * grad_scale: optional device float the staged gradient is multiplied by (the grad_output that
+ * autograd hands to backward; NULL = 1). */
+int collie_mf_train_update(const collie_mf_tables* t, const collie_mf_batch* b, void* workspace,
+                           size_t workspace_bytes, int32_t side, int32_t is_bias, int32_t dense,
+                           const collie_optim_cfg* cfg, float* state1, float* state2,
+                           int32_t* row_stamp, const float* grad_scale, collie_stream_t stream);
+
+/* Materialise the coalesced gradient of one table (tests, and `.grad` for callers that ask):
+ * rows_out [cap] int64 (sorted unique looked-up rows), vals_out [cap, dim or 1], count_out [1]
+ * int32 (device).  cap must be >= number of ids on that side. */
+int collie_mf_train_export_grad(const collie_mf_tables* t, const collie_mf_batch* b,
+                                void* workspace, size_t workspace_bytes, int32_t side,
+                                int32_t is_bias, int64_t* rows_out, float* vals_out,
+                                int32_t* count_out, collie_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * A13-A16  get_preds + mapk / mrr / auc   collie/metrics.py:77-107,144-282
+ * Scores one batch of users against the item rows [item_begin, item_end) with exact-fp32 MFMA
+ * tiles and never writes the [Bu, N] score matrix: emits per user the top-k (score, id) of the
+ * shard (descending score, ascending id) and, for every (user, positive) pair listed in the CSR
+ * slice, the number of shard items ranked strictly above / tied with that positive
+ * (MRR and AUC are closed forms of those counts).
+ * ------------------------------------------------------------------------------------------- */
+size_t collie_mf_eval_workspace_bytes(int64_t n_users, int64_t n_items_shard, int32_t dim,
+                                      int32_t k);
+int collie_mf_eval_topk(const collie_mf_tables* t, const int64_t* user_ids, int64_t n_users,
+                        int64_t item_begin, int64_t item_end, int32_t k, int32_t has_y_range,
+                        float y_lo, float y_hi, float* topk_scores /* [n_users,k] */,
+                        int64_t* topk_ids /* [n_users,k] */, void* workspace,
+                        size_t workspace_bytes, collie_stream_t stream);
+
+/* positives' scores: pos_scores[e] for CSR entries e in [indptr[i], indptr[i+1]) of user i */
+int collie_mf_eval_pos_scores(const collie_mf_tables* t, const int64_t* user_ids, int64_t n_users,
+                              const int64_t* indptr, const int64_t* indices, int32_t has_y_range,
+                              float y_lo, float y_hi, float* pos_scores, collie_stream_t stream);
+
+/* rank counts of every positive against the shard:
+ *   above[e]  = #{ j in shard : s_ij >  s_ie  or (s_ij == s_ie and j < indices[e]) }   (MRR)
+ *   sig_lt[e] = #{ j in shard : sigmoid(s_ij) <  sigmoid(s_ie) }                        (AUC)
+ *   sig_eq[e] = #{ j in shard : sigmoid(s_ij) == sigmoid(s_ie) }   (includes j = e itself)
+ * counts are ADDED to the int32 outputs (zero them first; shards accumulate). */
+int collie_mf_eval_rank_counts(const collie_mf_tables* t, const int64_t* user_ids,
+                               int64_t n_users, const int64_t* indptr, const int64_t* indices,
+                               const float* pos_scores, int64_t item_begin, int64_t item_end,
+                               int32_t has_y_range, float y_lo, float y_hi, int32_t* above,
+                               int32_t* sig_lt, int32_t* sig_eq, collie_stream_t stream);
+
+/* MAP@k / MRR / AUC per user from the merged top-k ids and the rank counts
+ * (metrics.py:178-198, :224-240, :266-282).  ap/rr/auc are [n_users] (any may be NULL). */
+int collie_mf_eval_metrics(const int64_t* topk_ids, int32_t k, int64_t n_users, int64_t n_items,
+                           const int64_t* indptr, const int64_t* indices, const int32_t* above,
+                           const int32_t* sig_lt, const int32_t* sig_eq, double* ap, float* rr,
+                           double* auc, collie_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COLLIE_HIP_H */

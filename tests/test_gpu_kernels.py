@@ -1,0 +1,267 @@
+"""
+GPU parity tests (``-m gpu``): the HIP kernels, called through the C ABI, against the golden
+vectors captured from the reference's loss functions / torch (tests/golden) and against the numpy
+oracle on seeded inputs.  Bars: bit-exact for ids / touched-row sets, 1e-5 relative for fp32.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+NAMES = ('user_embeddings', 'item_embeddings', 'user_biases', 'item_biases')
+RTOL = 1e-5
+
+
+def close(a, b, rtol=RTOL, scale=None):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    s = np.abs(b).max() if scale is None else scale
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=rtol * max(float(s), 1e-30))
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    return torch.device('cuda:0')
+
+
+def to_dev(tables, dev):
+    return {n: torch.tensor(tables[n], device=dev).contiguous() for n in NAMES}
+
+
+def tables_struct(td):
+    from collie_amd import _lib
+    return _lib.make_tables(td['user_embeddings'], td['item_embeddings'], td['user_biases'],
+                            td['item_biases'])
+
+
+def meta_codes(z, dev):
+    return [torch.tensor(z['meta_a'], dtype=torch.int32, device=dev),
+            torch.tensor(z['meta_b'], dtype=torch.int32, device=dev)], [0.2, 0.3]
+
+
+def test_forward_pairs_vs_golden(golden_dir, dev):
+    from collie_amd import ops
+    z = np.load(os.path.join(golden_dir, 'forward_cases.npz'))
+    for D in (1, 3, 8, 10, 30, 64, 100, 128, 256):
+        td = to_dev({n: z[f'D{D}|t|{n}'] for n in NAMES}, dev)
+        t = tables_struct(td)
+        for dtype in (torch.int64, torch.int32):
+            users = torch.tensor(z[f'D{D}|users'], device=dev).to(dtype)
+            items = torch.tensor(z[f'D{D}|items'], device=dev).to(dtype)
+            for y, yr in ((0, None), (1, (1.0, 5.0))):
+                out = ops.mf_score(t, users, items, yr).cpu().numpy()
+                close(out, z[f'D{D}|y{y}|preds'])
+
+
+def test_forward_out_of_range_ids_do_not_fault(golden_dir, dev):
+    from collie_amd import ops
+    z = np.load(os.path.join(golden_dir, 'forward_cases.npz'))
+    td = to_dev({n: z[f'D64|t|{n}'] for n in NAMES}, dev)
+    t = tables_struct(td)
+    users = torch.tensor([0, 10 ** 9, 3, -1], device=dev)
+    items = torch.tensor([1, 2, 10 ** 9, 0], device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    out = ops.mf_score(t, users, items, None, status)
+    torch.cuda.synchronize()
+    assert int(status.item()) == 1
+    assert float(out[1]) == 0.0 and float(out[2]) == 0.0 and float(out[3]) == 0.0
+
+
+def test_standalone_losses_vs_reference(golden_dir, dev):
+    from collie_amd import ops
+    z = np.load(os.path.join(golden_dir, 'loss_cases.npz'))
+    codes, weights = meta_codes(z, dev)
+    N = int(z['num_items'])
+    for tag in z['cases']:
+        kind, use_meta, variant = tag.split('|')
+        sp = torch.tensor(z[tag + '|s_pos'], device=dev)
+        sn = torch.tensor(z[tag + '|s_neg'], device=dev)
+        cfg = ops.make_loss_cfg(kind, N, codes if use_meta == '1' else None,
+                                weights if use_meta == '1' else None)
+        pos = torch.tensor(z[tag + '|pos'], device=dev)
+        neg = torch.tensor(z[tag + '|neg'], device=dev)
+        loss, gp, gn = ops.loss_forward_backward(cfg, sp, sn, pos, neg)
+        close(loss.item(), z[tag + '|loss'])
+        scale = max(np.abs(z[tag + '|g_pos']).max(), 1e-12)
+        close(gp.cpu().numpy(), z[tag + '|g_pos'], scale=scale)
+        close(gn.cpu().numpy(), z[tag + '|g_neg'], scale=scale)
+
+
+def run_fused(td, users, pos, neg, kind, dev, codes=None, weights=None, need_grad=True):
+    from collie_amd import ops
+    t = tables_struct(td)
+    batch = ops.make_batch(users, pos, neg)
+    B, K = neg.shape
+    ws = ops.TrainWorkspace(dev)
+    buf = ws.ensure(B, K, t.dim)
+    cfg = ops.make_loss_cfg(kind, t.num_items, codes, weights)
+    loss = torch.empty(1, device=dev)
+    s_pos = torch.empty(B, device=dev)
+    s_neg = torch.empty(K, B, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    ops.train_forward(t, batch, cfg, buf, need_grad, loss, s_pos, s_neg, status)
+    return t, batch, buf, loss, s_pos, s_neg, status
+
+
+def test_fused_calculate_loss_and_grads_vs_reference(golden_dir, dev):
+    from collie_amd import _lib, ops
+    z = np.load(os.path.join(golden_dir, 'train_cases.npz'))
+    codes, weights = meta_codes(z, dev)
+    for tag in z['cases']:
+        kind, D, K, m = tag.split('|')
+        td = to_dev({n: z[f'{tag}|t|{n}'] for n in NAMES}, dev)
+        users = torch.tensor(z[f'{tag}|users'], device=dev)      # int32, as the loaders emit
+        pos = torch.tensor(z[f'{tag}|pos'], device=dev)          # int32
+        neg = torch.tensor(z[f'{tag}|neg'], device=dev)          # int64 [B, K]
+        kw = dict(codes=codes, weights=weights) if m == 'm1' else {}
+        t, batch, buf, loss, s_pos, s_neg, status = run_fused(td, users, pos, neg, kind, dev, **kw)
+        close(loss.item(), z[f'{tag}|loss'])
+        close(s_pos.cpu().numpy(), z[f'{tag}|s_pos'])
+        close(s_neg.cpu().numpy(), z[f'{tag}|s_neg'])
+        assert int(status.item()) == 0
+        gscale = max(np.abs(z[f'{tag}|g|item_embeddings|vals']).max(), 1e-12)
+        for side, names in ((_lib.SIDE_USER, ('user_embeddings', 'user_biases')),
+                            (_lib.SIDE_ITEM, ('item_embeddings', 'item_biases'))):
+            ops.train_build_segments(t, batch, buf, side)
+            for name in names:
+                rows, vals = ops.train_export_grad(t, batch, buf, side, 'bias' in name)
+                # touched-row set (zero-gradient rows included): exact
+                np.testing.assert_array_equal(rows.cpu().numpy(), z[f'{tag}|g|{name}|rows'])
+                ref = z[f'{tag}|g|{name}|vals']
+                if name == 'user_biases':
+                    # analytically zero; the reference holds only fp32 cancellation residue
+                    assert np.abs(ref).max() <= 1e-6 * max(gscale, 1.0)
+                    assert float(vals.abs().max()) == 0.0
+                else:
+                    close(vals.cpu().numpy(), ref, scale=gscale)
+
+
+ALGO_STATE = {'sparse_adam': ('exp_avg', 'exp_avg_sq'), 'adam': ('exp_avg', 'exp_avg_sq'),
+              'adagrad': ('sum', None), 'sgd': (None, None)}
+
+
+def test_optimizer_trajectories_vs_torch(golden_dir, dev):
+    """4 training steps per optimizer combination; tables and optimizer state after every step."""
+    from collie_amd import _lib, ops
+    z = np.load(os.path.join(golden_dir, 'optimizer_cases.npz'))
+    combos = json.loads(str(z['combos']))
+    for tag, sparse, opt, bopt, lr, blr, wd, kind, K in combos:
+        td = to_dev({n: z[f'{tag}|t0|{n}'] for n in NAMES}, dev)
+        state = {n: {'s1': torch.zeros_like(td[n]), 's2': torch.zeros_like(td[n]),
+                     'stamp': torch.zeros(td[n].shape[0], dtype=torch.int32, device=dev)}
+                 for n in NAMES}
+        for s in range(4):
+            users = torch.tensor(z[f'{tag}|s{s}|users'], device=dev)
+            pos = torch.tensor(z[f'{tag}|s{s}|pos'], device=dev)
+            neg = torch.tensor(z[f'{tag}|s{s}|neg'], device=dev)
+            t, batch, buf, loss, _, _, _ = run_fused(td, users, pos, neg, kind, dev)
+            close(loss.item(), z[f'{tag}|s{s}|loss'], rtol=2e-5)
+            for side in (_lib.SIDE_USER, _lib.SIDE_ITEM):
+                ops.train_build_segments(t, batch, buf, side)
+            for n in NAMES:
+                is_bias = 'bias' in n
+                algo, rate = (bopt, blr) if (is_bias and bopt is not None) else (opt, lr)
+                side = _lib.SIDE_USER if n.startswith('user') else _lib.SIDE_ITEM
+                eps = 1e-10 if algo == 'adagrad' else 1e-8
+                cfg = ops.optim_cfg(algo, s + 1, rate, eps=eps,
+                                    weight_decay=0.0 if algo == 'sparse_adam' else wd)
+                st = state[n]
+                ops.train_update(t, batch, buf, side, is_bias, not sparse, cfg,
+                                 st['s1'] if algo != 'sgd' else None,
+                                 st['s2'] if algo in ('adam', 'sparse_adam') else None,
+                                 st['stamp'] if not sparse else None)
+            for n in NAMES:
+                if n == 'user_biases':
+                    assert float(td[n].abs().max()) == 0.0   # exact zero gradient, see above
+                    continue
+                try:
+                    close(td[n].cpu().numpy(), z[f'{tag}|s{s}|t|{n}'], rtol=2e-5)
+                except AssertionError as e:
+                    bad = np.nonzero(np.abs(td[n].cpu().numpy() - z[f'{tag}|s{s}|t|{n}']).max(axis=1)
+                                     > 1e-4)[0]
+                    raise AssertionError(f'{tag} step {s} table {n} rows {bad}: {e}')
+                algo = bopt if ('bias' in n and bopt is not None) else opt
+                for key, mine in zip(ALGO_STATE[algo], ('s1', 's2')):
+                    if key is not None:
+                        close(state[n][mine].cpu().numpy(), z[f'{tag}|s{s}|state|{n}|{key}'],
+                              rtol=2e-5)
+
+
+@pytest.mark.parametrize('B,K,D,U,N', [(1, 1, 64, 5, 7), (4099, 10, 64, 3000, 500),
+                                        (70000, 10, 64, 138493, 26744), (513, 63, 32, 100, 4000),
+                                        (2500, 5, 520, 300, 200), (3000, 3, 30, 70000, 90000)])
+def test_fused_step_vs_oracle_seeded(dev, B, K, D, U, N):
+    """Whole step (forward, coalesce, SparseAdam + SGD-bias update) vs the numpy oracle."""
+    from oracle import mf_oracle as O
+    from collie_amd import _lib, ops
+    rng = np.random.default_rng(B + K)
+    tables = O.init_tables(U, N, D, rng)
+    tables['user_embeddings'] *= np.float32(4 * np.sqrt(D))
+    tables['item_embeddings'] *= np.float32(4 * np.sqrt(D))
+    tables['item_biases'] = rng.normal(0, 0.05, (N, 1)).astype(np.float32)
+    kind = 'adaptive_bpr' if K > 1 else 'bpr'
+    st = O.TrainState(tables, 'sparse_adam', 'sgd', lr=1e-2, bias_lr=1e-1, sparse=True)
+    td = to_dev(tables, dev)
+    m = {n: torch.zeros_like(td[n]) for n in NAMES}
+    v = {n: torch.zeros_like(td[n]) for n in NAMES}
+    for step in range(2):
+        # Zipf-ish popularity so that hot rows have long segments
+        users = (rng.zipf(1.3, B) % U).astype(np.int32)
+        pos = (rng.zipf(1.2, B) % N).astype(np.int32)
+        neg = rng.integers(0, N, (B, K)).astype(np.int64)
+        out = st.step(users, pos, neg, kind)
+        t, batch, buf, loss, s_pos, s_neg, status = run_fused(
+            td, torch.tensor(users, device=dev), torch.tensor(pos, device=dev),
+            torch.tensor(neg, device=dev), kind, dev)
+        close(loss.item(), out['loss'])
+        close(s_pos.cpu().numpy(), out['s_pos'])
+        close(s_neg.cpu().numpy(), out['s_neg'])
+        for side in (_lib.SIDE_USER, _lib.SIDE_ITEM):
+            ops.train_build_segments(t, batch, buf, side)
+        for n in ('user_embeddings', 'item_embeddings'):
+            side = _lib.SIDE_USER if n.startswith('user') else _lib.SIDE_ITEM
+            rows, vals = ops.train_export_grad(t, batch, buf, side, False)
+            np.testing.assert_array_equal(rows.cpu().numpy(), out['grads'][n][0])
+            close(vals.cpu().numpy(), out['grads'][n][1], rtol=5e-5)
+            ops.train_update(t, batch, buf, side, False, False,
+                             ops.optim_cfg('sparse_adam', step + 1, 1e-2), m[n], v[n])
+        for n in ('user_biases', 'item_biases'):
+            side = _lib.SIDE_USER if n.startswith('user') else _lib.SIDE_ITEM
+            ops.train_update(t, batch, buf, side, True, False, ops.optim_cfg('sgd', step + 1, 1e-1))
+        for n in ('user_embeddings', 'item_embeddings', 'item_biases'):
+            close(td[n].cpu().numpy(), st.t[n], rtol=5e-5)
+            if 'bias' not in n:
+                close(m[n].cpu().numpy(), st.state[n]['m'], rtol=5e-5)
+                close(v[n].cpu().numpy(), st.state[n]['v'], rtol=5e-5)
+
+
+def test_fused_step_is_deterministic(dev):
+    """Same inputs twice -> bit-identical tables and moments (no float atomics anywhere)."""
+    from oracle import mf_oracle as O
+    from collie_amd import _lib, ops
+    rng = np.random.default_rng(0)
+    U, N, D, B, K = 5000, 800, 64, 30000, 10
+    tables = O.init_tables(U, N, D, rng)
+    users = torch.tensor((rng.zipf(1.3, B) % U).astype(np.int32), device=dev)
+    pos = torch.tensor((rng.zipf(1.2, B) % N).astype(np.int32), device=dev)
+    neg = torch.tensor(rng.integers(0, N, (B, K)), device=dev)
+    results = []
+    for _ in range(2):
+        td = to_dev(tables, dev)
+        m = {n: torch.zeros_like(td[n]) for n in NAMES}
+        v = {n: torch.zeros_like(td[n]) for n in NAMES}
+        for step in range(3):
+            t, batch, buf, loss, _, _, _ = run_fused(td, users, pos, neg, 'adaptive_bpr', dev)
+            for side, n in ((_lib.SIDE_USER, 'user_embeddings'), (_lib.SIDE_ITEM, 'item_embeddings')):
+                ops.train_build_segments(t, batch, buf, side)
+                ops.train_update(t, batch, buf, side, False, False,
+                                 ops.optim_cfg('sparse_adam', step + 1, 1e-2), m[n], v[n])
+                ops.train_update(t, batch, buf, side, True, False, ops.optim_cfg('sgd', step + 1, 1e-1))
+        results.append([td[n].cpu().numpy().copy() for n in NAMES] + [loss.item()])
+    for a, b in zip(*results):
+        np.testing.assert_array_equal(a, b)
