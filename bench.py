@@ -1,0 +1,216 @@
+"""
+bench.py — headline benchmark of the MF training hot path (BASELINE.json: "train interactions/sec
+(pos+negs)") on BASELINE configs[1]: synthetic ML-20M shape (138,493 users x 26,744 items,
+20,000,263 interactions), MF dim=64, adaptive BPR + 10 negatives, SparseAdam (embeddings) + SGD
+(biases), on MI355X.
+
+A "step" is one pass of the hot path over one batch that is already resident in HBM:
+``model.calculate_loss(batch)`` (fused gather/dot/loss/backward-staging kernel) ->
+``loss.backward()`` -> ``optimizer.step()`` for both optimizers (radix coalesce + fused
+segment-reduce/row-update kernels), all through the product API.  Negative sampling is done on the
+device before the timed region.
+
+Contract: ``python bench.py --gpus N --steps K --warmup W`` prints ONE JSON line on rank 0.
+For N > 1 it is launched by torch.distributed.run, one rank per GPU.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+NUM_USERS, NUM_ITEMS, NUM_INTERACTIONS = 138_493, 26_744, 20_000_263
+DIM, NUM_NEG = 64, 10
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+class _Shape:
+    """What the model constructor reads from a train loader (sizes only: data is synthetic)."""
+    num_users, num_items, num_negative_samples = NUM_USERS, NUM_ITEMS, NUM_NEG
+    num_interactions = NUM_INTERACTIONS
+
+
+def build_model(device):
+    from collie_amd.model import MatrixFactorizationModel
+    torch.manual_seed(0)
+    model = MatrixFactorizationModel(train=_Shape(), embedding_dim=DIM, sparse=True, lr=1e-3,
+                                     bias_lr=1e-2, optimizer='sparse_adam', bias_optimizer='sgd',
+                                     loss='bpr', lr_scheduler_func=None)
+    model.to(device)
+    model.train()
+    return model
+
+
+def synthetic_batches(n, batch, device, dist, seed):
+    """n batches in the loaders' format: users/pos int32 [B], negatives int64 [B, K]."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    out = []
+    for _ in range(n):
+        if dist == 'zipf':
+            # Zipf(1.05) popularity over a random permutation of ids (inverse-CDF on a power law)
+            def zipf(rows):
+                u = torch.rand(batch, device=device, generator=g)
+                r = (torch.pow(u, -1.0 / 0.05) - 1.0).clamp_(0, rows - 1)
+                return r.to(torch.int32)
+            users, pos = zipf(NUM_USERS), zipf(NUM_ITEMS)
+        else:
+            users = torch.randint(0, NUM_USERS, (batch,), device=device, generator=g, dtype=torch.int32)
+            pos = torch.randint(0, NUM_ITEMS, (batch,), device=device, generator=g, dtype=torch.int32)
+        neg = torch.randint(0, NUM_ITEMS, (batch, NUM_NEG), device=device, generator=g)
+        out.append(((users, pos), neg))
+    return out
+
+
+def train_step(model, optimizers, batch):
+    for opt in optimizers:
+        opt.zero_grad()
+    loss = model.calculate_loss(batch)
+    loss.backward()
+    for opt in optimizers:
+        opt.step()
+    return loss
+
+
+def fwd_algorithmic_bytes(batch):
+    """SURVEY.md §8d, forward part: index reads + (1 user + 1+K item) rows of D+1 floats."""
+    idx = batch * (4 + 4) + batch * NUM_NEG * 8
+    rows = (batch + (1 + NUM_NEG) * batch) * (DIM + 1) * 4
+    return idx + rows
+
+
+def cpu_baseline(seconds=12.0, batch=1024):
+    """The reference's torch op sequence (oracle/torch_path.py) on the host cores: a 'port'."""
+    from oracle import torch_path
+    threads = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    model = torch_path.TorchMF(NUM_USERS, NUM_ITEMS, DIM, sparse=True)
+    opts = torch_path.make_optimizers(model, 'sparse_adam', 'sgd', 1e-3, 1e-2)
+    rng = np.random.default_rng(0)
+
+    def batch_():
+        return ((torch.from_numpy(rng.integers(0, NUM_USERS, batch).astype(np.int32)),
+                 torch.from_numpy(rng.integers(0, NUM_ITEMS, batch).astype(np.int32))),
+                torch.from_numpy(rng.integers(0, NUM_ITEMS, (batch, NUM_NEG))))
+    for _ in range(5):
+        torch_path.train_step(model, opts, batch_(), torch_path.t_adaptive_bpr)
+    steps, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        torch_path.train_step(model, opts, batch_(), torch_path.t_adaptive_bpr)
+        steps += 1
+    dt = time.perf_counter() - t0
+    return {'value': steps * batch * (1 + NUM_NEG) / dt, 'unit': 'interactions/s',
+            'cores': threads, 'kind': 'port',
+            'sample': f'{steps} steps of B={batch} (reference default batch size), same shape/'
+                      f'loss/optimizers, torch CPU op sequence of the reference, {dt:.1f} s'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--batch', type=int, default=65536, help='positives per step per GPU')
+    ap.add_argument('--dist', choices=['uniform', 'zipf'], default='uniform')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit('for --gpus N > 1 launch with: python -m torch.distributed.run '
+                         '--nnodes=1 --nproc-per-node N bench.py --gpus N ...')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    dist_on = world > 1
+    if dist_on:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=device)
+
+    model = build_model(device)
+    optimizers = model.configure_optimizers()
+    n_distinct = min(args.steps + args.warmup, 32)
+    batches = synthetic_batches(n_distinct, args.batch, device, args.dist, seed=1234 + rank)
+
+    for i in range(args.warmup):
+        train_step(model, optimizers, batches[i % n_distinct])
+
+    fwd_events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                  for _ in range(args.steps)]
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        batch = batches[(args.warmup + i) % n_distinct]
+        for opt in optimizers:
+            opt.zero_grad()
+        fwd_events[i][0].record()
+        loss = model.calculate_loss(batch)
+        fwd_events[i][1].record()
+        loss.backward()
+        for opt in optimizers:
+            opt.step()
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    model.check_status()
+    final_loss = float(loss.item())
+
+    if dist_on:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        fwd_ms = float(np.mean([a.elapsed_time(b) for a, b in fwd_events]))
+        per_step = args.batch * (1 + NUM_NEG)
+        value = world * per_step * args.steps / elapsed
+        alg = fwd_algorithmic_bytes(args.batch)
+        achieved = alg / (fwd_ms * 1e-3) / 1e9
+        result = {
+            'metric': 'train interactions/sec (pos+negs)',
+            'value': value,
+            'unit': 'interactions/s',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3,
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'f32',
+            'data': 'synthetic',
+            'config': {
+                'workload': 'BASELINE configs[1]: synthetic ML-20M shape 138493 users x 26744 '
+                            'items, MF dim=64, adaptive BPR + 10 negatives, SparseAdam + SGD bias',
+                'batch_per_gpu': args.batch, 'global_batch': args.batch * world,
+                'id_distribution': args.dist,
+                'parallelism': 'single GPU' if world == 1 else f'{world} independent replicas',
+                'final_loss': final_loss,
+            },
+            'roofline': {
+                'kernel': 'mf_train_fwd_kernel<4,16> (fused gather + dot + loss + backward staging)',
+                'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                'algorithmic_bytes_per_launch': alg, 'avg_launch_ms': fwd_ms,
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            result['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(result))
+    if dist_on:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,177 @@
+"""
+Host-side data objects that produce the batch format the hot path consumes.
+
+The reference's data layer (``collie/interactions/{datasets,samplers,dataloaders}.py``) is out of
+scope as a kernel; what *is* part of the drop-in boundary is the batch
+format, reproduced here exactly:
+
+    ((users int32 [B], pos_items int32 [B]), neg_items int64 [B, K])
+
+(``datasets.py:382-388,439-443``: scipy COO ``row``/``col`` are int32, ``np.random.randint`` gives
+int64).  Only what the MF path needs is provided: an ``Interactions`` wrapper over a COO matrix, a
+one-``__getitem__``-per-batch loader with approximate negative sampling
+(``ApproximateNegativeSamplingInteractionsDataLoader``, ``samplers.py:11-64``) and the default
+``InteractionsDataLoader`` whose exact negative sampling is vectorised here (rejection against a
+sorted (user, item) key array instead of the reference's per-sample Python loop,
+``datasets.py:399-426``).
+"""
+import math
+from typing import Iterable, Optional
+
+import numpy as np
+import torch
+from scipy.sparse import coo_matrix
+
+
+class Interactions:
+    """Implicit user-item interactions (``datasets.py:196-445``)."""
+
+    def __init__(self,
+                 mat=None,
+                 users: Optional[Iterable[int]] = None,
+                 items: Optional[Iterable[int]] = None,
+                 ratings: Optional[Iterable[int]] = None,
+                 num_negative_samples: int = 10,
+                 allow_missing_ids: bool = False,
+                 remove_duplicate_user_item_pairs: bool = True,
+                 num_users='infer',
+                 num_items='infer',
+                 check_num_negative_samples_is_valid: bool = True,
+                 max_number_of_samples_to_consider: int = 200,
+                 seed: Optional[int] = None):
+        if mat is None:
+            if users is None or items is None:
+                raise ValueError('Either ``mat`` or both ``users`` and ``items`` must be given')
+            users = np.asarray(users)
+            items = np.asarray(items)
+            if len(users) != len(items):
+                raise ValueError('Lengths of ``users`` and ``items`` must be equal')
+            if ratings is None:
+                ratings = np.ones(len(users))
+            ratings = np.asarray(ratings)
+            keep = ratings != 0      # 0 ratings are ignored for implicit data (datasets.py:293-302)
+            users, items, ratings = users[keep], items[keep], ratings[keep]
+            if num_users == 'infer':
+                num_users = int(users.max()) + 1
+            if num_items == 'infer':
+                num_items = int(items.max()) + 1
+            if not allow_missing_ids:
+                if len(np.unique(users)) != num_users or len(np.unique(items)) != num_items:
+                    raise ValueError('``users`` / ``items`` are missing ids; pass '
+                                     '``allow_missing_ids=True`` to allow this')
+            mat = coo_matrix((ratings, (users, items)), shape=(num_users, num_items))
+        else:
+            mat = coo_matrix(mat)
+        if remove_duplicate_user_item_pairs:
+            key = mat.row.astype(np.int64) * mat.shape[1] + mat.col
+            _, first = np.unique(key, return_index=True)
+            if len(first) != len(key):
+                first.sort()
+                mat = coo_matrix((mat.data[first], (mat.row[first], mat.col[first])), shape=mat.shape)
+        self.mat = coo_matrix((mat.data, (mat.row.astype(np.int32), mat.col.astype(np.int32))),
+                              shape=mat.shape)
+        self.num_users, self.num_items = self.mat.shape
+        self.num_interactions = self.mat.nnz
+        assert num_negative_samples >= 1
+        self.num_negative_samples = num_negative_samples
+        self.max_number_of_samples_to_consider = max_number_of_samples_to_consider
+        self.seed = seed if seed is not None else int(np.random.randint(0, 2 ** 31 - 1))
+        self._rng = np.random.default_rng(self.seed)
+        if check_num_negative_samples_is_valid:
+            most = int(np.bincount(self.mat.row).max()) if self.mat.nnz else 0
+            assert num_negative_samples < self.num_items - most, (
+                '``num_negative_samples`` must be less than {}!'.format(self.num_items - most))
+        self._pos_keys = None
+
+    def __len__(self):
+        return self.num_interactions
+
+    def _positive_keys(self):
+        if self._pos_keys is None:
+            self._pos_keys = np.sort(self.mat.row.astype(np.int64) * self.num_items + self.mat.col)
+        return self._pos_keys
+
+    def _negative_sample(self, user_id):
+        """[len(user_id), K] int64 negatives (``datasets.py:390-445``)."""
+        user_id = np.atleast_1d(user_id)
+        size = (len(user_id), self.num_negative_samples)
+        neg = self._rng.integers(0, self.num_items, size=size, dtype=np.int64)
+        if self.max_number_of_samples_to_consider > 0:
+            keys = self._positive_keys()
+            base = user_id.astype(np.int64)[:, None] * self.num_items
+            tries = max(1, self.max_number_of_samples_to_consider // self.num_negative_samples)
+            for _ in range(tries):
+                k = (base + neg).ravel()
+                pos = np.searchsorted(keys, k)
+                pos[pos >= len(keys)] = len(keys) - 1
+                clash = (keys[pos] == k).reshape(size)
+                if not clash.any():
+                    break
+                neg[clash] = self._rng.integers(0, self.num_items, size=int(clash.sum()))
+        return neg
+
+    def __getitem__(self, index):
+        user_id = self.mat.row[index]
+        item_id = self.mat.col[index]
+        neg = self._negative_sample(user_id)
+        if np.ndim(index) == 0:
+            neg = neg[0]
+        return (user_id, item_id), neg
+
+    def __repr__(self):
+        return (f'Interactions object with {self.num_interactions} interactions between '
+                f'{self.num_users} users and {self.num_items} items, returning '
+                f'{self.num_negative_samples} negative samples per interaction.')
+
+
+class _BaseLoader:
+    def __init__(self, interactions, batch_size, shuffle):
+        if not isinstance(interactions, Interactions):
+            raise ValueError('``interactions`` must be an ``Interactions`` object')
+        self.interactions = interactions
+        self.batch_size = batch_size
+        self.shuffle = shuffle
+        self._order = np.arange(len(interactions))
+        self._rng = np.random.default_rng(interactions.seed)
+
+    num_users = property(lambda self: self.interactions.num_users)
+    num_items = property(lambda self: self.interactions.num_items)
+    num_negative_samples = property(lambda self: self.interactions.num_negative_samples)
+    num_interactions = property(lambda self: self.interactions.num_interactions)
+    mat = property(lambda self: self.interactions.mat)
+
+    def __len__(self):
+        return math.ceil(len(self.interactions) / self.batch_size)
+
+    def __iter__(self):
+        if self.shuffle:
+            self._rng.shuffle(self._order)
+        for start in range(0, len(self.interactions), self.batch_size):
+            idxs = self._order[start:start + self.batch_size]
+            (users, items), neg = self.interactions[idxs]
+            yield ((torch.from_numpy(np.ascontiguousarray(users)),
+                    torch.from_numpy(np.ascontiguousarray(items))),
+                   torch.from_numpy(neg))
+
+
+class InteractionsDataLoader(_BaseLoader):
+    """Default loader (``dataloaders.py:70-173``): exact negative sampling unless disabled."""
+
+    def __init__(self, interactions=None, mat=None, users=None, items=None, ratings=None,
+                 batch_size: int = 1024, shuffle: bool = False, **kwargs):
+        if interactions is None:
+            interactions = Interactions(mat=mat, users=users, items=items, ratings=ratings, **kwargs)
+        super().__init__(interactions, batch_size, shuffle)
+
+
+class ApproximateNegativeSamplingInteractionsDataLoader(_BaseLoader):
+    """Batch-at-once approximate negative sampling (``dataloaders.py:176-294``)."""
+
+    def __init__(self, interactions=None, mat=None, users=None, items=None, ratings=None,
+                 batch_size: int = 1024, shuffle: bool = False, **kwargs):
+        if interactions is None:
+            interactions = Interactions(mat=mat, users=users, items=items, ratings=ratings,
+                                        max_number_of_samples_to_consider=0, **kwargs)
+        else:
+            interactions.max_number_of_samples_to_consider = 0
+        super().__init__(interactions, batch_size, shuffle)

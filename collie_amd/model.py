@@ -1,0 +1,508 @@
+"""
+``MatrixFactorizationModel`` — host-side mirror of the reference's
+``collie/model/matrix_factorization.py`` + the parts of ``collie/model/base/base_pipeline.py`` the
+matrix-factorization train/eval path uses.  Same constructor, hyper-parameter names, parameter
+names/shapes (``user_biases.weight [U,1]`` ... ``item_embeddings.weight [N,D]``), ``forward``,
+``calculate_loss``, ``configure_optimizers``, ``save_model`` / ``load_model_path``.
+
+What is different is underneath: there is no ``pytorch_lightning`` (the class is a plain
+``torch.nn.Module`` exposing the few LightningModule members the trainers and metrics touch) and all
+arithmetic runs in ``libcollie_hip.so``:
+
+  * ``calculate_loss`` on an implicit batch with one of the built-in losses launches ONE fused
+    kernel (gathers, 1+K dot products, loss, backward coefficients, staged gradient rows) and
+    returns a 0-d tensor whose ``backward()`` only arms the staged step; the fused optimizers
+    (``collie_amd/optim.py``) then run the sorted-segment reduce + row update kernels.
+  * ``forward(users, items)`` is an ``autograd.Function`` over the ``collie_mf_score`` kernels
+    (generic route: custom callable losses, ``get_item_predictions`` ...).
+
+There is no CPU fallback: tensors on a non-HIP device raise ``CollieHipError``.
+"""
+import textwrap
+import warnings
+from collections.abc import Iterable
+from functools import partial
+from typing import Callable, Dict, Optional, Tuple, Union
+
+import numpy as np
+import torch
+from torch import nn
+from torch.optim.lr_scheduler import ReduceLROnPlateau
+
+from collie_amd import _lib, loss as loss_mod, ops
+from collie_amd.interactions import (ApproximateNegativeSamplingInteractionsDataLoader,
+                                     Interactions, InteractionsDataLoader)
+from collie_amd.layers import ScaledEmbedding, ZeroEmbedding
+from collie_amd.optim import FUSED_OPTIMIZERS
+
+
+class HParams(dict):
+    """Attribute dict: ``hasattr`` is False for missing keys, ``.get`` works (``base_pipeline.py:230,604``)."""
+
+    def __getattr__(self, key):
+        try:
+            return self[key]
+        except KeyError:
+            raise AttributeError(key)
+
+    def __setattr__(self, key, value):
+        self[key] = value
+
+
+# ---- generic route: model(users, items) ---------------------------------------------------------
+class _MFScore(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, users, items, ue, ie, ub, ib, y_range, sparse, status):
+        tables = _lib.make_tables(ue, ie, ub, ib)
+        out = ops.mf_score(tables, users, items, y_range, status)
+        ctx.save_for_backward(users, items, ue, ie, ub, ib)
+        ctx.y_range, ctx.sparse, ctx.status = y_range, sparse, status
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        users, items, ue, ie, ub, ib = ctx.saved_tensors
+        tables = _lib.make_tables(ue, ie, ub, ib)
+        gu, gi, gb = ops.mf_score_backward(tables, users, items, grad_out, ctx.y_range, ctx.status)
+        u_idx = users.long().reshape(1, -1)
+        i_idx = items.long().reshape(1, -1)
+
+        def build(idx, vals, like):
+            if ctx.sparse:      # the uncoalesced COO gradient nn.Embedding(sparse=True) produces
+                return torch.sparse_coo_tensor(idx, vals, like.shape)
+            return torch.zeros_like(like).index_add_(0, idx[0], vals)
+
+        return (None, None, build(u_idx, gu, ue), build(i_idx, gi, ie), build(u_idx, gb, ub),
+                build(i_idx, gb, ib), None, None, None)
+
+
+# ---- fused route: calculate_loss ---------------------------------------------------------------
+class _FusedStep:
+    """One staged backward: batch, workspace and which sides already have their segments."""
+
+    def __init__(self, model, tables, batch, buf):
+        self.model, self.tables, self.batch, self.buf = model, tables, batch, buf
+        self.armed = False
+        self.grad_scale = None
+        self.segments = [False, False]
+        self.done = set()
+
+    def update(self, slot, dense, cfg, state1, state2, stamp):
+        side, is_bias = slot
+        if slot in self.done:
+            return                      # a table is updated at most once per staged backward
+        if not self.segments[side]:
+            ops.train_build_segments(self.tables, self.batch, self.buf, side)
+            self.segments[side] = True
+        ops.train_update(self.tables, self.batch, self.buf, side, is_bias, dense, cfg, state1,
+                         state2, stamp, self.grad_scale)
+        self.done.add(slot)
+
+
+class _FusedLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, staged, loss_value, *weights):
+        ctx.staged = staged
+        return loss_value.reshape(()).clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        staged = ctx.staged
+        staged.grad_scale = grad_out.detach().to(torch.float32).reshape(1).contiguous()
+        staged.armed = True
+        return (None, None, None) + (None,) * 4
+
+
+INTERACTIONS_LIKE_INPUT = Union[ApproximateNegativeSamplingInteractionsDataLoader, Interactions,
+                                InteractionsDataLoader]
+_TABLES = ('user_embeddings', 'item_embeddings', 'user_biases', 'item_biases')
+_SLOTS = {'user_embeddings': (_lib.SIDE_USER, False), 'item_embeddings': (_lib.SIDE_ITEM, False),
+          'user_biases': (_lib.SIDE_USER, True), 'item_biases': (_lib.SIDE_ITEM, True)}
+
+
+class MatrixFactorizationModel(nn.Module):
+    """
+    Training pipeline for the matrix factorization model (see the module docstring).
+
+    Parameters are those of the reference (``matrix_factorization.py:73-94``):
+    ``train, val, embedding_dim=30, dropout_p=0.0, sparse=False, lr=1e-3, bias_lr=1e-2,
+    lr_scheduler_func=partial(ReduceLROnPlateau, patience=1), weight_decay=0.0, optimizer='adam',
+    bias_optimizer='sgd', loss='hinge', metadata_for_loss=None, metadata_for_loss_weights=None,
+    y_range=None, load_model_path=None, map_location=None``.
+    """
+
+    def __init__(self,
+                 train: INTERACTIONS_LIKE_INPUT = None,
+                 val: INTERACTIONS_LIKE_INPUT = None,
+                 embedding_dim: int = 30,
+                 dropout_p: float = 0.0,
+                 sparse: bool = False,
+                 lr: float = 1e-3,
+                 bias_lr: Optional[Union[float, str]] = 1e-2,
+                 lr_scheduler_func: Optional[Callable] = partial(ReduceLROnPlateau, patience=1),
+                 weight_decay: float = 0.0,
+                 optimizer: Union[str, Callable] = 'adam',
+                 bias_optimizer: Optional[Union[str, Callable]] = 'sgd',
+                 loss: Union[str, Callable[..., torch.Tensor]] = 'hinge',
+                 metadata_for_loss: Optional[Dict[str, torch.Tensor]] = None,
+                 metadata_for_loss_weights: Optional[Dict[str, float]] = None,
+                 y_range: Optional[Tuple[float, float]] = None,
+                 load_model_path: Optional[str] = None,
+                 map_location: Optional[str] = None):
+        super().__init__()
+        if isinstance(train, Interactions):
+            train = InteractionsDataLoader(interactions=train, shuffle=True)
+        if isinstance(val, Interactions):
+            val = InteractionsDataLoader(interactions=val, shuffle=False)
+        self.train_loader = train
+        self.val_loader = val
+        self.lr_scheduler_func = lr_scheduler_func
+        self.loss = loss
+        self.optimizer = optimizer
+        self.bias_optimizer = bias_optimizer
+        self.hparams = HParams()
+        self._staged_step = None
+        self._workspace = None
+        self._status = None
+        self._meta_codes = None
+
+        if load_model_path is not None:
+            self._load_model_init_helper(load_model_path, map_location)
+            return
+
+        if self.train_loader is None:
+            raise TypeError('``train`` must be provided to all newly-instantiated models!')
+        if self.val_loader is not None:
+            assert self.train_loader.num_users == self.val_loader.num_users, (
+                'Both training and val ``num_users`` must equal: '
+                f'{self.train_loader.num_users} != {self.val_loader.num_users}.')
+            assert self.train_loader.num_items == self.val_loader.num_items, (
+                'Both training and val ``num_items`` must equal: '
+                f'{self.train_loader.num_items} != {self.val_loader.num_items}.')
+            err = ('Training and val ``num_negative_samples`` property must both equal ``1`` or '
+                   'both be greater than ``1``.')
+            if self.train_loader.num_negative_samples == 1:
+                assert self.val_loader.num_negative_samples == 1, err
+            elif self.train_loader.num_negative_samples > 1:
+                assert self.val_loader.num_negative_samples > 1, err
+            else:
+                raise ValueError('``self.train_loader.num_negative_samples`` must be greater than '
+                                 f'``0``, not {self.train_loader.num_negative_samples}.')
+
+        self.hparams.update(
+            embedding_dim=embedding_dim, dropout_p=dropout_p, sparse=sparse, lr=lr, bias_lr=bias_lr,
+            weight_decay=weight_decay, optimizer=optimizer if isinstance(optimizer, str) else None,
+            bias_optimizer=bias_optimizer if isinstance(bias_optimizer, str) else None,
+            loss=loss if isinstance(loss, str) else None, metadata_for_loss=metadata_for_loss,
+            metadata_for_loss_weights=metadata_for_loss_weights, y_range=y_range,
+            load_model_path=None, map_location=map_location)
+        self.hparams.num_users = self.train_loader.num_users
+        self.hparams.num_items = self.train_loader.num_items
+        self.hparams.num_epochs_completed = 0
+
+        self._configure_loss()
+
+        if self.hparams.sparse and self.hparams.weight_decay != 0:
+            warnings.warn(f'``weight_decay`` value must be 0 when ``sparse`` is flagged, not '
+                          f'{self.hparams.weight_decay}. Setting to 0.')
+            self.hparams.weight_decay = 0.0
+
+        self._setup_model()
+
+    # ---------------------------------------------------------------- construction / persistence
+    def _setup_model(self, **kwargs) -> None:
+        """``matrix_factorization.py:99-118``: same modules, names, shapes and init."""
+        hp = self.hparams
+        self.user_biases = ZeroEmbedding(hp.num_users, 1, sparse=hp.sparse)
+        self.item_biases = ZeroEmbedding(hp.num_items, 1, sparse=hp.sparse)
+        self.user_embeddings = ScaledEmbedding(hp.num_users, hp.embedding_dim, sparse=hp.sparse)
+        self.item_embeddings = ScaledEmbedding(hp.num_items, hp.embedding_dim, sparse=hp.sparse)
+        self.dropout = nn.Dropout(p=hp.dropout_p)
+
+    def _load_model_init_helper(self, load_model_path, map_location) -> None:
+        """``base_pipeline.py:245-257`` (loads files written by ``save_model``)."""
+        loaded = torch.load(str(load_model_path), map_location=map_location, weights_only=False)
+        for key, value in loaded['hparams'].items():
+            self.hparams[key] = value
+        self.hparams['load_model_path'] = load_model_path
+        self.hparams['map_location'] = map_location
+        self._setup_model()
+        self.load_state_dict(loaded['state_dict'])
+        self.eval()
+
+    def save_model(self, filename='model.pth') -> None:
+        """``base_pipeline.py:880-900``: ``{'state_dict', 'hparams'}``."""
+        torch.save({'state_dict': self.state_dict(), 'hparams': dict(self.hparams)}, str(filename))
+
+    # ----------------------------------------------------------------- LightningModule stand-ins
+    @property
+    def device(self):
+        return self.user_embeddings.weight.device
+
+    def log(self, *args, **kwargs):
+        pass
+
+    def freeze(self):
+        for p in self.parameters():
+            p.requires_grad = False
+        self.eval()
+
+    def train_dataloader(self):
+        return self.train_loader
+
+    def val_dataloader(self):
+        return self.val_loader
+
+    def on_fit_start(self):
+        self._move_any_external_data_to_device()
+
+    def optimizer_step(self, epoch=None, batch_idx=None, optimizer=None, optimizer_idx=None,
+                       optimizer_closure=None, **kwargs):
+        optimizer.step(closure=optimizer_closure)
+
+    def training_step(self, batch, batch_idx=None, optimizer_idx=None):
+        return self.calculate_loss(batch)
+
+    def validation_step(self, batch, batch_idx=None, optimizer_idx=None):
+        return self.calculate_loss(batch)
+
+    def _move_any_external_data_to_device(self):
+        """``base_pipeline.py:269-275`` (+ the int32 category codes the kernels read)."""
+        md = self.hparams.get('metadata_for_loss')
+        if md is not None:
+            self.hparams.metadata_for_loss = {k: torch.as_tensor(v).to(self.device)
+                                              for k, v in md.items()}
+        self._meta_codes = None
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._workspace = None
+        self._status = None
+        self._meta_codes = None
+        self._staged_step = None
+        return out
+
+    # ------------------------------------------------------------------------- loss / optimizers
+    def _configure_loss(self) -> None:
+        """``base_pipeline.py:277-340``: string -> loss, adaptive whenever K > 1."""
+        self.loss_function = None
+        self._loss_kind = None
+        if callable(self.loss):
+            self.loss_function = self.loss
+            return
+        self.hparams._is_implicit = False
+        if self.loss == 'mse':
+            self.loss_function = torch.nn.MSELoss(reduction='mean')
+            return
+        elif self.loss == 'mae':
+            self.loss_function = torch.nn.L1Loss(reduction='mean')
+            return
+        self.hparams._is_implicit = True
+        if not hasattr(self.train_loader, 'num_negative_samples'):
+            raise ValueError('``num_negative_samples`` attribute not found in ``train_loader`` - '
+                             'are you using explicit data with an implicit loss function?')
+        many = self.train_loader.num_negative_samples > 1
+        if self.loss == 'warp':
+            if not many:
+                raise ValueError('Cannot use WARP loss with a single negative sample!')
+            self._loss_kind = 'warp'
+        elif 'bpr' in self.loss:
+            if not many and 'adaptive' in self.loss:
+                warnings.warn('Adaptive BPR loss specified, but ``num_negative_samples`` == 1. '
+                              'Using standard BPR loss instead.')
+            self._loss_kind = 'adaptive_bpr' if many else 'bpr'
+        elif 'hinge' in self.loss or self.loss == 'adaptive':
+            if not many and 'adaptive' in self.loss:
+                warnings.warn('Adaptive hinge loss specified, but ``num_negative_samples`` == 1. '
+                              'Using standard hinge loss instead.')
+            self._loss_kind = 'adaptive_hinge' if many else 'hinge'
+        else:
+            raise ValueError('{} is not a valid loss function.'.format(self.loss))
+        self.loss_function = loss_mod.LOSS_FUNCTIONS[self._loss_kind]
+
+    def configure_optimizers(self):
+        """``base_pipeline.py:342-404``: same return shapes; string optimizers become fused ones."""
+        if self.bias_optimizer is not None:
+            if self.bias_optimizer == 'infer':
+                self.bias_optimizer = self.optimizer
+            if self.hparams.bias_lr == 'infer':
+                self.hparams.bias_lr = self.hparams.lr
+            bias_optimizer = self._get_optimizer(self.bias_optimizer, optimizer_type='bias')
+            optimizer = self._get_optimizer(self.optimizer, optimizer_type='all_but_bias')
+        else:
+            optimizer = self._get_optimizer(self.optimizer, optimizer_type='all')
+
+        if self.lr_scheduler_func is not None:
+            monitor = 'val_loss_epoch' if self.val_loader is not None else 'train_loss_epoch'
+            optimizer_list = [optimizer]
+            scheduler_list = [{'scheduler': self.lr_scheduler_func(optimizer), 'monitor': monitor}]
+            if self.bias_optimizer is not None:
+                optimizer_list.append(bias_optimizer)
+                scheduler_list.append({'scheduler': self.lr_scheduler_func(bias_optimizer),
+                                       'monitor': monitor})
+            return (optimizer_list, scheduler_list)
+        if self.bias_optimizer is not None:
+            return [optimizer, bias_optimizer]
+        return optimizer
+
+    def _get_optimizer(self, optimizer, **kwargs):
+        """``base_pipeline.py:406-437``."""
+        if callable(optimizer):
+            try:
+                return optimizer(self._get_optimizer_parameters(include_weight_decay=True, **kwargs))
+            except TypeError:
+                return optimizer(self._get_optimizer_parameters(include_weight_decay=False, **kwargs))
+        if optimizer not in FUSED_OPTIMIZERS:
+            raise ValueError('{} is not a valid optimizer!'.format(optimizer))
+        params = self._get_optimizer_parameters(
+            include_weight_decay=(optimizer != 'sparse_adam'), **kwargs)
+        return FUSED_OPTIMIZERS[optimizer](params).attach(self)
+
+    def _get_optimizer_parameters(self, include_weight_decay=True, optimizer_type='all', **kwargs):
+        """``base_pipeline.py:439-479``: the substring 'bias' in the parameter NAME routes it."""
+        assert optimizer_type in ['bias', 'all_but_bias', 'all'], f'{optimizer_type} not valid!'
+        if optimizer_type == 'bias':
+            groups = [{'params': [p for n, p in self.named_parameters() if 'bias' in n],
+                       'lr': self.hparams.bias_lr}]
+        elif optimizer_type == 'all_but_bias':
+            groups = [{'params': [p for n, p in self.named_parameters() if 'bias' not in n],
+                       'lr': self.hparams.lr}]
+        else:
+            groups = [{'params': list(self.parameters()), 'lr': self.hparams.lr}]
+        if include_weight_decay:
+            for g in groups:
+                g['weight_decay'] = self.hparams.weight_decay
+        return groups
+
+    # ------------------------------------------------------------------------------- arithmetic
+    def _tables(self):
+        return _lib.make_tables(self.user_embeddings.weight.data, self.item_embeddings.weight.data,
+                                self.user_biases.weight.data, self.item_biases.weight.data)
+
+    def _table_slot(self, param):
+        for name, slot in _SLOTS.items():
+            if getattr(self, name).weight is param:
+                return slot
+        return None
+
+    def _status_flag(self):
+        if self._status is None or self._status.device != self.device:
+            self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
+        return self._status
+
+    def check_status(self):
+        """Raise ``IndexError`` if any kernel saw an out-of-range id since the last check (syncs)."""
+        if self._status is not None and int(self._status.item()) != 0:
+            self._status.zero_()
+            raise IndexError('index out of range in self: a user or item id is outside the tables')
+
+    def _drop_staged_step(self):
+        self._staged_step = None
+
+    def forward(self, users: torch.Tensor, items: torch.Tensor) -> torch.Tensor:
+        """``matrix_factorization.py:120-159``."""
+        if self.training and self.hparams.dropout_p > 0:
+            raise NotImplementedError(
+                'dropout_p > 0 in training mode is not implemented in the HIP path '
+                '(SURVEY.md §7: torch-RNG parity is infeasible); use dropout_p=0.')
+        _lib.require_hip(self.user_embeddings.weight, 'MatrixFactorizationModel')
+        y = self.hparams.get('y_range')
+        return _MFScore.apply(users, items, self.user_embeddings.weight,
+                              self.item_embeddings.weight, self.user_biases.weight,
+                              self.item_biases.weight, tuple(y) if y is not None else None,
+                              bool(self.hparams.sparse), self._status_flag())
+
+    def _can_fuse(self):
+        if self._loss_kind is None or self.hparams.get('y_range') is not None:
+            return False
+        if self.training and self.hparams.dropout_p > 0:
+            return False
+        md = self.hparams.get('metadata_for_loss')
+        return md is None or len(md) <= _lib.MAX_META
+
+    def calculate_loss(self, batch) -> torch.Tensor:
+        """``base_pipeline.py:582-654``: same batch grammar, same errors."""
+        if len(batch) == 2 and isinstance(batch[0], Iterable) and len(batch[0]) == 2:
+            if self.hparams.get('_is_implicit') is False:
+                raise ValueError('Explicit loss with implicit data is invalid!')
+            ((users, pos_items), neg_items) = batch
+            if neg_items.dim() == 1:
+                neg_items = neg_items.reshape(-1, 1)
+            if self._can_fuse() and neg_items.shape[1] <= _lib.MAX_NEG:
+                return self._fused_calculate_loss(users, pos_items, neg_items)
+            # generic route: same op sequence as the reference, every op a HIP kernel
+            users = users.long()
+            pos_items = pos_items.long()
+            neg_items = torch.transpose(neg_items, 0, 1).long()
+            pos_preds = self(users, pos_items)
+            neg_preds = self(users.repeat(neg_items.shape[0]), neg_items.flatten()).view(
+                neg_items.shape[0], len(users))
+            return self.loss_function(
+                pos_preds, neg_preds, num_items=self.hparams.num_items, positive_items=pos_items,
+                negative_items=neg_items, metadata=self.hparams.get('metadata_for_loss'),
+                metadata_weights=self.hparams.get('metadata_for_loss_weights'))
+        elif len(batch) == 3:
+            if self.hparams.get('_is_implicit') is True:
+                raise ValueError('Implicit loss with explicit data is invalid!')
+            (users, items, ratings) = batch
+            preds = self(users.long(), items.long())
+            return self.loss_function(preds, ratings.float())
+        else:
+            raise ValueError(f'Unexpected format for batch: {batch}. See docs for expected format.')
+
+    def _fused_calculate_loss(self, users, pos_items, neg_items):
+        dev = self.device
+        _lib.require_hip(self.user_embeddings.weight, 'MatrixFactorizationModel')
+        for t in (users, pos_items, neg_items):
+            _lib.require_hip(t, 'batch')
+        need_grad = torch.is_grad_enabled() and any(
+            getattr(self, n).weight.requires_grad for n in _TABLES)
+        if self._workspace is None:
+            self._workspace = ops.TrainWorkspace(dev)
+        B, K = neg_items.shape
+        buf = self._workspace.ensure(B, K, self.hparams.embedding_dim)
+        if self._meta_codes is None:
+            self._meta_codes = loss_mod.metadata_to_codes(
+                self.hparams.get('metadata_for_loss'),
+                self.hparams.get('metadata_for_loss_weights'), dev)
+        codes, weights = self._meta_codes
+        tables = self._tables()
+        hbatch = ops.make_batch(users, pos_items, neg_items)
+        cfg = ops.make_loss_cfg(self._loss_kind, self.hparams.num_items, codes, weights)
+        loss_value = torch.empty(1, dtype=torch.float32, device=dev)
+        ops.train_forward(tables, hbatch, cfg, buf, need_grad, loss_value, None, None,
+                          self._status_flag())
+        if not need_grad:
+            return loss_value.reshape(())
+        staged = _FusedStep(self, tables, hbatch, buf)
+        self._staged_step = staged
+        weights_ = [getattr(self, n).weight for n in _TABLES]
+        return _FusedLoss.apply(self, staged, loss_value, *weights_)
+
+    # ------------------------------------------------------------------------------ conveniences
+    def _get_item_embeddings(self) -> torch.Tensor:
+        return self.item_embeddings.weight.data
+
+    def _get_user_embeddings(self) -> torch.Tensor:
+        return self.user_embeddings.weight.data
+
+    def get_item_predictions(self, user_id: int = 0, unseen_items_only: bool = False,
+                             sort_values: bool = True):
+        """``base_pipeline.py:656-718``."""
+        import pandas as pd
+        if user_id >= self.hparams.num_users:
+            raise ValueError(f'``user_id`` {user_id} is not in the model. Expected ID between '
+                             f'``0`` and ``self.hparams.num_users - 1`` '
+                             f'(``{self.hparams.num_users - 1}``), not ``{user_id}``')
+        user = torch.full((self.hparams.num_items,), user_id, dtype=torch.long, device=self.device)
+        item = torch.arange(self.hparams.num_items, dtype=torch.long, device=self.device)
+        with torch.no_grad():
+            preds = pd.Series(self(user, item).detach().cpu().numpy())
+        if sort_values:
+            preds = preds.sort_values(ascending=False)
+        if unseen_items_only:
+            drop = self.train_loader.mat.tocsr()[user_id, :].nonzero()[1]
+            if self.val_loader is not None:
+                drop = np.concatenate([drop, self.val_loader.mat.tocsr()[user_id, :].nonzero()[1]])
+            return preds.drop(drop)
+        return preds

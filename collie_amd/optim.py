@@ -1,0 +1,149 @@
+"""
+``torch.optim.Optimizer`` subclasses that ``MatrixFactorizationModel.configure_optimizers`` returns
+(reference: ``collie/model/base/base_pipeline.py:342-479``).
+
+Each class IS the torch optimizer the reference would have built (``SparseAdam``, ``Adam``,
+``Adagrad``, ``SGD``): same constructor, ``param_groups`` (so LR schedulers work), same
+``state_dict`` keys (``step``, ``exp_avg``, ``exp_avg_sq``, ``sum``).  ``step()`` differs: when the
+model holds a staged fused backward (see ``model._FusedStep``) the parameters it owns are updated
+by the ``collie_mf_train_update`` HIP kernel (sorted-segment reduce fused with the row update);
+hyper-parameters are re-read from ``param_groups`` at every call.  If no fused step is staged but
+ordinary ``.grad`` tensors exist (generic route: custom loss callables), the inherited torch
+``step()`` runs unchanged.
+"""
+import torch
+
+from collie_amd import _lib, ops
+
+
+class _FusedMixin:
+    _algo = None
+
+    def attach(self, model):
+        """Called by the model: lets ``step`` find the staged backward and the table slots."""
+        self._collie_model = model
+        return self
+
+    def zero_grad(self, set_to_none: bool = True):
+        model = getattr(self, '_collie_model', None)
+        if model is not None:
+            model._drop_staged_step()
+        return super().zero_grad(set_to_none=set_to_none)
+
+    def _staged(self):
+        model = getattr(self, '_collie_model', None)
+        if model is None:
+            return None
+        st = model._staged_step
+        return st if (st is not None and st.armed) else None
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        staged = self._staged()
+        if staged is None:
+            return super().step(closure)
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        model = self._collie_model
+        for group in self.param_groups:
+            for p in group['params']:
+                slot = model._table_slot(p)
+                if slot is None:
+                    if p.grad is not None:
+                        raise RuntimeError('fused optimizers only own the four MF tables')
+                    continue
+                if not p.requires_grad:
+                    continue
+                self._fused_update(staged, model, p, group, slot)
+        return loss
+
+
+def _step_count(state):
+    s = state.get('step', 0)
+    return int(s.item()) if torch.is_tensor(s) else int(s)
+
+
+class FusedSparseAdam(_FusedMixin, torch.optim.SparseAdam):
+    """``torch.optim.SparseAdam`` (``torch/optim/_functional.py:24-84``) on touched rows."""
+
+    def _fused_update(self, staged, model, p, group, slot):
+        if not model.hparams.sparse:
+            raise RuntimeError('SparseAdam does not support dense gradients, please consider '
+                               'Adam instead')
+        state = self.state[p]
+        if len(state) == 0:
+            state['step'] = 0
+            state['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            state['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        state['step'] += 1
+        beta1, beta2 = group['betas']
+        cfg = ops.optim_cfg(_lib.OPT_SPARSE_ADAM, state['step'], group['lr'], beta1, beta2,
+                            group['eps'])
+        staged.update(slot, False, cfg, state['exp_avg'], state['exp_avg_sq'], None)
+
+
+class FusedAdam(_FusedMixin, torch.optim.Adam):
+    """``torch.optim.Adam`` (dense, ``torch/optim/adam.py:396-547``): every row, every step."""
+
+    def _fused_update(self, staged, model, p, group, slot):
+        if model.hparams.sparse:
+            raise RuntimeError('Adam does not support sparse gradients, please consider '
+                               'SparseAdam instead')
+        if group.get('amsgrad') or group.get('maximize'):
+            raise RuntimeError('amsgrad / maximize are not supported by the fused Adam')
+        state = self.state[p]
+        if len(state) == 0:
+            state['step'] = torch.tensor(0.0, dtype=torch.float32)
+            state['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            state['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        if '_row_stamp' not in state:
+            state['_row_stamp'] = torch.zeros(p.shape[0], dtype=torch.int32, device=p.device)
+        state['step'] += 1
+        beta1, beta2 = group['betas']
+        cfg = ops.optim_cfg(_lib.OPT_ADAM, _step_count(state), group['lr'], beta1, beta2,
+                            group['eps'], group['weight_decay'])
+        staged.update(slot, True, cfg, state['exp_avg'], state['exp_avg_sq'], state['_row_stamp'])
+
+
+class FusedAdagrad(_FusedMixin, torch.optim.Adagrad):
+    """``torch.optim.Adagrad`` (``torch/optim/adagrad.py:346-388``), sparse or dense gradients."""
+
+    def _fused_update(self, staged, model, p, group, slot):
+        state = self.state[p]           # torch creates 'step' and 'sum' at construction
+        dense = not model.hparams.sparse
+        if state['sum'].device != p.device:
+            state['sum'] = state['sum'].to(p.device)
+        state['step'] += 1
+        stamp = None
+        if dense and group['weight_decay'] != 0:
+            if '_row_stamp' not in state:
+                state['_row_stamp'] = torch.zeros(p.shape[0], dtype=torch.int32, device=p.device)
+            stamp = state['_row_stamp']
+        cfg = ops.optim_cfg(_lib.OPT_ADAGRAD, _step_count(state), group['lr'], eps=group['eps'],
+                            weight_decay=group['weight_decay'], lr_decay=group['lr_decay'])
+        staged.update(slot, dense, cfg, state['sum'], None, stamp)
+
+
+class FusedSGD(_FusedMixin, torch.optim.SGD):
+    """``torch.optim.SGD`` with momentum 0 (the only form the reference constructs)."""
+
+    def _fused_update(self, staged, model, p, group, slot):
+        if group['momentum'] != 0 or group['nesterov'] or group.get('maximize'):
+            raise RuntimeError('the fused SGD supports momentum=0 only')
+        state = self.state[p]
+        dense = not model.hparams.sparse
+        state['_steps'] = state.get('_steps', 0) + 1
+        stamp = None
+        if dense and group['weight_decay'] != 0:
+            if '_row_stamp' not in state:
+                state['_row_stamp'] = torch.zeros(p.shape[0], dtype=torch.int32, device=p.device)
+            stamp = state['_row_stamp']
+        cfg = ops.optim_cfg(_lib.OPT_SGD, state['_steps'], group['lr'],
+                            weight_decay=group['weight_decay'])
+        staged.update(slot, dense, cfg, None, None, stamp)
+
+
+FUSED_OPTIMIZERS = {'sgd': FusedSGD, 'adagrad': FusedAdagrad, 'adam': FusedAdam,
+                    'sparse_adam': FusedSparseAdam}
