@@ -1,0 +1,603 @@
+// K6: full-catalog evaluation — get_preds + topk + mapk / mrr / auc of collie/metrics.py:77-282 —
+// without ever materialising the [users, items] score matrix.
+//
+// Scoring is an exact-fp32 MFMA GEMM (v_mfma_f32_32x32x2_f32): items on the A rows (staged through
+// a padded LDS tile shared by the four waves of a workgroup), users on the B columns (one user per
+// lane column, its embedding held in registers for the whole kernel).  A lane therefore owns one
+// user and receives 16 item scores per 32x32 tile, which makes the per-user epilogues private to
+// a lane:
+//   * top-k: a sorted (score, id) list in registers; candidates arrive in increasing id order, so
+//     a strict '>' test keeps "descending score, ascending id" exact;
+//   * rank counts for MRR / AUC: integer counters against the thresholds of the user's positives.
+// The MFMA result is bit-for-bit an fmaf chain in k order (MI355X guide, "FP32-input MFMA"), and
+// chain_score() below replays that exact chain for single (user, item) pairs, so the scores of
+// the positives (thresholds) are bit-identical to the scores the GEMM produces for the same pairs.
+#include "common.h"
+
+namespace collie {
+
+int validate_tables(const collie_mf_tables* t);
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kBlock = 256;
+constexpr int kWaves = kBlock / kWave;
+constexpr int kUsersPerBlock = 32 * kWaves;  // 128
+constexpr int kTileItems = 64;               // items staged in LDS per step
+constexpr int kPad = 4;                      // floats of row padding: conflict-free ds_read_b128
+constexpr int kCap = 16;                     // top-k capacity held in registers
+
+// k index consumed by MFMA step t on lane half h (see header comment of eval_gemm_kernel)
+__host__ __device__ __forceinline__ int kappa(int t, int h) { return 8 * (t >> 2) + 4 * h + (t & 3); }
+
+// The exact chain the MFMA GEMM computes for one (user row, item row) pair.
+__device__ __forceinline__ float chain_dot(const float* urow, const float* irow, int D, int D8) {
+  float acc = 0.0f;
+  for (int t = 0; t < D8 * 4; ++t) {
+    const int k0 = kappa(t, 0), k1 = kappa(t, 1);
+    const float a0 = k0 < D ? irow[k0] : 0.0f, b0 = k0 < D ? urow[k0] : 0.0f;
+    const float a1 = k1 < D ? irow[k1] : 0.0f, b1 = k1 < D ? urow[k1] : 0.0f;
+    acc = fmaf(a0, b0, acc);
+    acc = fmaf(a1, b1, acc);
+  }
+  return acc;
+}
+
+__device__ __forceinline__ float finish_score(float dot, float ub, float ib) { return (dot + ub) + ib; }
+
+__device__ __forceinline__ float yr(float s, int has_y, float lo, float hi) {
+  return has_y ? sigmoidf_(s) * (hi - lo) + lo : s;
+}
+
+// monotone map float <-> ordered uint so that thresholds can be binary-searched
+__device__ __forceinline__ uint32_t f2o(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float o2f(uint32_t o) {
+  const uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+  return __uint_as_float(u);
+}
+
+struct EvalParams {
+  collie_mf_tables t;
+  const int64_t* user_ids;
+  int64_t n_users;
+  int64_t item_begin, item_end;
+  int tiles_per_chunk;
+  int nchunks;
+  int k;
+  int D8;
+  // top-k outputs (candidates)
+  float* cand_scores;  // [n_users, nslots, kCap]
+  int32_t* cand_ids;
+  // rank-count inputs / outputs
+  const int64_t* indptr;   // [n_users + 1] CSR over the batch's users
+  const float* thr_lo;     // [nnz] lowest raw score whose sigmoid equals the positive's
+  const float* thr_hi;     // [nnz] highest such score
+  const float* best_score; // [n_users] raw score of the user's best positive
+  const int64_t* best_id;  // [n_users]
+  unsigned long long* counts;  // [n_users, 3]: above_best, sum_e #(sig<), sum_e #(sig<=)
+};
+
+// MODE 0: top-k candidates.  MODE 1: rank counts.
+template <int D8, int MODE>
+__global__ __launch_bounds__(kBlock) void eval_gemm_kernel(const EvalParams p) {
+  constexpr int DP = D8 * 8;           // padded depth
+  constexpr int LD = DP + kPad;        // LDS row stride (floats)
+  __shared__ __attribute__((aligned(16))) float tile[kTileItems * LD];
+  __shared__ float tile_bias[kTileItems];
+
+  const int lane = lane_id();
+  const int wave = threadIdx.x / kWave;
+  const int col = lane & 31;
+  const int h = lane >> 5;
+  const int D = p.t.dim;
+  const bool vec_ok = (D % 4 == 0);
+
+  // ---- this lane's user: embedding slices k = 8q + 4h .. +3 stay in registers ----------------
+  const int64_t uslot = static_cast<int64_t>(blockIdx.x) * kUsersPerBlock + wave * 32 + col;
+  const bool user_ok = uslot < p.n_users;
+  int64_t uid = p.user_ids[user_ok ? uslot : p.n_users - 1];
+  if (uid < 0) uid = 0;
+  if (uid >= p.t.num_users) uid = p.t.num_users - 1;
+  const float* urow = p.t.user_emb + uid * D;
+  const float ub = p.t.user_bias[uid];
+  f32x4 ufrag[D8];
+#pragma unroll
+  for (int q = 0; q < D8; ++q) {
+    const int k0 = 8 * q + 4 * h;
+    if (vec_ok && k0 + 3 < D) {
+      ufrag[q] = *reinterpret_cast<const f32x4*>(urow + k0);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ufrag[q][e] = (k0 + e < D) ? urow[k0 + e] : 0.0f;
+    }
+  }
+
+  // ---- per-lane epilogue state ------------------------------------------------------------------
+  float top_s[kCap];
+  int top_i[kCap];
+  unsigned long long c_above = 0, c_lt = 0, c_le = 0;
+  int64_t e_begin = 0, e_end = 0;
+  float bscore = 0.0f;
+  int bid = 0;
+  if (MODE == 0) {
+#pragma unroll
+    for (int i = 0; i < kCap; ++i) {
+      top_s[i] = -INFINITY;
+      top_i[i] = 0x7fffffff;
+    }
+  } else if (user_ok) {
+    e_begin = p.indptr[uslot];
+    e_end = p.indptr[uslot + 1];
+    bscore = p.best_score[uslot];
+    bid = static_cast<int>(p.best_id[uslot]);
+  }
+  const int k = p.k;
+
+  const int64_t chunk_items = static_cast<int64_t>(p.tiles_per_chunk) * kTileItems;
+  const int64_t chunk_begin = p.item_begin + static_cast<int64_t>(blockIdx.y) * chunk_items;
+  int64_t chunk_end = chunk_begin + chunk_items;
+  if (chunk_end > p.item_end) chunk_end = p.item_end;
+
+  for (int64_t base = chunk_begin; base < chunk_end; base += kTileItems) {
+    __syncthreads();
+    // ---- stage 64 item rows (zero-padded to DP, rows past the shard end are zero) ------------
+    for (int idx = threadIdx.x; idx < kTileItems * (DP / 4); idx += kBlock) {
+      const int r = idx / (DP / 4);
+      const int c4 = idx - r * (DP / 4);
+      const int64_t item = base + r;
+      f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (item < chunk_end) {
+        const float* irow = p.t.item_emb + item * D;
+        if (vec_ok && c4 * 4 + 3 < D) {
+          v = *reinterpret_cast<const f32x4*>(irow + c4 * 4);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (c4 * 4 + e < D) ? irow[c4 * 4 + e] : 0.0f;
+        }
+      }
+      *reinterpret_cast<f32x4*>(&tile[r * LD + c4 * 4]) = v;
+    }
+    if (threadIdx.x < kTileItems) {
+      const int64_t item = base + threadIdx.x;
+      tile_bias[threadIdx.x] = item < chunk_end ? p.t.item_bias[item] : 0.0f;
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int sub = 0; sub < kTileItems / 32; ++sub) {
+      f32x16 acc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+      const float* arow = &tile[(sub * 32 + col) * LD + 4 * h];
+#pragma unroll
+      for (int q = 0; q < D8; ++q) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(arow + 8 * q);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], ufrag[q][0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], ufrag[q][1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], ufrag[q][2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], ufrag[q][3], acc, 0, 0, 0);
+      }
+      // ---- epilogue: this lane's user x 16 items (rows (r&3) + 8(r>>2) + 4h of the tile) ------
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int64_t item = base + row;
+        const float s = finish_score(acc[r], ub, tile_bias[row]);
+        const bool in = item < chunk_end;
+        if (MODE == 0) {
+          if (in && s > top_s[kCap - 1]) {
+            // insertion into the sorted list (rare after warm-up; divergent lanes wait)
+            float cs = s;
+            int ci = static_cast<int>(item);
+#pragma unroll
+            for (int i = 0; i < kCap; ++i) {
+              const bool better = cs > top_s[i];
+              const float ts = top_s[i];
+              const int ti = top_i[i];
+              top_s[i] = better ? cs : ts;
+              top_i[i] = better ? ci : ti;
+              cs = better ? ts : cs;
+              ci = better ? ti : ci;
+            }
+          }
+        } else if (in && user_ok) {
+          c_above += (s > bscore || (s == bscore && item < bid)) ? 1ull : 0ull;
+          for (int64_t e = e_begin; e < e_end; ++e) {
+            c_lt += s < p.thr_lo[e] ? 1ull : 0ull;
+            c_le += s <= p.thr_hi[e] ? 1ull : 0ull;
+          }
+        }
+      }
+    }
+  }
+
+  if (!user_ok) return;
+  if (MODE == 0) {
+    const int nslots = p.nchunks * 2;
+    const int64_t slot = uslot * nslots + blockIdx.y * 2 + h;
+#pragma unroll
+    for (int i = 0; i < kCap; ++i) {
+      p.cand_scores[slot * kCap + i] = i < k ? top_s[i] : -INFINITY;
+      p.cand_ids[slot * kCap + i] = i < k ? top_i[i] : 0x7fffffff;
+    }
+  } else {
+    atomicAdd(&p.counts[uslot * 3 + 0], c_above);
+    atomicAdd(&p.counts[uslot * 3 + 1], c_lt);
+    atomicAdd(&p.counts[uslot * 3 + 2], c_le);
+  }
+}
+
+// one wave per user: k rounds of "best remaining candidate" over nslots * kCap candidates
+__global__ __launch_bounds__(kBlock) void merge_topk_kernel(const float* __restrict__ cand_scores,
+                                                            const int32_t* __restrict__ cand_ids,
+                                                            int64_t n_users, int nslots, int k,
+                                                            int has_y, float y_lo, float y_hi,
+                                                            float* __restrict__ out_scores,
+                                                            int64_t* __restrict__ out_ids) {
+  const int lane = lane_id();
+  const int64_t user = static_cast<int64_t>(blockIdx.x) * kWaves + threadIdx.x / kWave;
+  if (user >= n_users) return;
+  const int n = nslots * kCap;
+  const float* cs = cand_scores + user * n;
+  const int32_t* ci = cand_ids + user * n;
+  float last_s = INFINITY;
+  int last_i = -1;
+  for (int round = 0; round < k; ++round) {
+    // best candidate strictly after (last_s, last_i) in (score desc, id asc) order
+    float bs = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int j = lane; j < n; j += kWave) {
+      const float s = cs[j];
+      const int id = ci[j];
+      const bool after = s < last_s || (s == last_s && id > last_i);
+      const bool better = s > bs || (s == bs && id < bi);
+      if (after && better && id != 0x7fffffff) {
+        bs = s;
+        bi = id;
+      }
+    }
+    for (int o = kWave / 2; o > 0; o >>= 1) {
+      const float os = __shfl_xor(bs, o, kWave);
+      const int oi = __shfl_xor(bi, o, kWave);
+      if (os > bs || (os == bs && oi < bi)) {
+        bs = os;
+        bi = oi;
+      }
+    }
+    if (lane == 0) {
+      out_scores[user * k + round] = yr(bs, has_y, y_lo, y_hi);
+      out_ids[user * k + round] = bi == 0x7fffffff ? -1 : bi;
+    }
+    last_s = bs;
+    last_i = bi;
+  }
+}
+
+// scores of the positives (CSR entries) through the same chain as the GEMM + sigmoid intervals
+__global__ __launch_bounds__(kBlock) void pos_scores_kernel(
+    const collie_mf_tables t, const int64_t* __restrict__ user_ids, int64_t n_users,
+    const int64_t* __restrict__ indptr, const int64_t* __restrict__ indices, int D8, int has_y,
+    float y_lo, float y_hi, float* __restrict__ pos_scores, float* __restrict__ thr_lo,
+    float* __restrict__ thr_hi) {
+  const int64_t nnz = indptr[n_users];
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; e < nnz; e += stride) {
+    // user slot of entry e: binary search in indptr
+    int64_t lo = 0, hi = n_users;
+    while (hi - lo > 1) {
+      const int64_t mid = (lo + hi) / 2;
+      if (indptr[mid] <= e) lo = mid; else hi = mid;
+    }
+    int64_t uid = user_ids[lo];
+    int64_t item = indices[e];
+    if (uid < 0) uid = 0;
+    if (uid >= t.num_users) uid = t.num_users - 1;
+    if (item < 0) item = 0;
+    if (item >= t.num_items) item = t.num_items - 1;
+    const float dot = chain_dot(t.user_emb + uid * t.dim, t.item_emb + item * t.dim, t.dim, D8);
+    const float s = finish_score(dot, t.user_bias[uid], t.item_bias[item]);
+    pos_scores[e] = s;
+    if (thr_lo) {
+      // [lo, hi] = the raw-score interval whose sigmoid(preds) equals this positive's
+      // (metrics.py:277 ranks sigmoid(preds) in fp32, which ties scores the raw values do not)
+      const float target = sigmoidf_(yr(s, has_y, y_lo, y_hi));
+      uint32_t a = f2o(-INFINITY), b = f2o(s);      // smallest x in [a, b] with F(x) == target
+      while (a < b) {
+        const uint32_t m = a + (b - a) / 2;
+        if (sigmoidf_(yr(o2f(m), has_y, y_lo, y_hi)) >= target) b = m; else a = m + 1;
+      }
+      thr_lo[e] = o2f(a);
+      a = f2o(s);
+      b = f2o(INFINITY);                             // largest x in [a, b] with F(x) == target
+      while (a < b) {
+        const uint32_t m = a + (b - a + 1) / 2;
+        if (sigmoidf_(yr(o2f(m), has_y, y_lo, y_hi)) <= target) a = m; else b = m - 1;
+      }
+      thr_hi[e] = o2f(a);
+    }
+  }
+}
+
+// best positive per user: max score, lowest item id on ties (first relevant item of the order)
+__global__ __launch_bounds__(kBlock) void best_pos_kernel(const int64_t* __restrict__ indptr,
+                                                          const int64_t* __restrict__ indices,
+                                                          const float* __restrict__ pos_scores,
+                                                          int64_t n_users,
+                                                          float* __restrict__ best_score,
+                                                          int64_t* __restrict__ best_id) {
+  const int64_t u = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (u >= n_users) return;
+  float bs = -INFINITY;
+  int64_t bi = INT64_MAX;
+  for (int64_t e = indptr[u]; e < indptr[u + 1]; ++e) {
+    const float s = pos_scores[e];
+    const int64_t id = indices[e];
+    if (s > bs || (s == bs && id < bi)) {
+      bs = s;
+      bi = id;
+    }
+  }
+  best_score[u] = bs;
+  best_id[u] = bi;
+}
+
+// MAP@k, RR, AUC per user (metrics.py:178-198, :224-240, :266-282)
+__global__ __launch_bounds__(kBlock) void metrics_kernel(
+    const int64_t* __restrict__ topk_ids, int k, int64_t n_users, int64_t n_items,
+    const int64_t* __restrict__ indptr, const int64_t* __restrict__ indices,
+    const float* __restrict__ pos_scores, const unsigned long long* __restrict__ counts,
+    int has_y, float y_lo, float y_hi, double* __restrict__ ap, float* __restrict__ rr,
+    double* __restrict__ auc) {
+  const int64_t u = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (u >= n_users) return;
+  const int64_t b = indptr[u], e = indptr[u + 1];
+  const int64_t npos = e - b;
+  if (ap) {
+    // AP = sum_j rel_j * cumsum(rel)_j / j  /  min(k, npos); NaN (npos == 0) -> 0
+    double sum = 0.0;
+    int hits = 0;
+    for (int j = 0; j < k; ++j) {
+      const int64_t id = topk_ids[u * k + j];
+      // indices of a CSR row are sorted: binary search
+      int64_t lo = b, hi = e;
+      while (lo < hi) {
+        const int64_t mid = (lo + hi) / 2;
+        if (indices[mid] < id) lo = mid + 1; else hi = mid;
+      }
+      if (lo < e && indices[lo] == id) {
+        ++hits;
+        sum += static_cast<double>(hits) * (1.0 / static_cast<double>(j + 1));
+      }
+    }
+    const int64_t denom = npos < k ? npos : k;
+    ap[u] = denom > 0 ? sum / static_cast<double>(denom) : 0.0;
+  }
+  if (rr) {
+    // reciprocal rank of the best positive: 1 / (1 + #items ranked above it)
+    rr[u] = npos > 0 ? 1.0f / (static_cast<float>(counts[u * 3 + 0]) + 1.0f) : 0.0f;
+  }
+  if (auc) {
+    // Mann-Whitney with tie averaging on sigmoid(preds); the all-item counts include the
+    // positives themselves, which are removed pairwise here
+    double lt = static_cast<double>(counts[u * 3 + 1]);
+    double le = static_cast<double>(counts[u * 3 + 2]);
+    for (int64_t x = b; x < e; ++x) {
+      const float sx = sigmoidf_(yr(pos_scores[x], has_y, y_lo, y_hi));
+      for (int64_t y = b; y < e; ++y) {
+        const float sy = sigmoidf_(yr(pos_scores[y], has_y, y_lo, y_hi));
+        lt -= sy < sx ? 1.0 : 0.0;
+        le -= sy <= sx ? 1.0 : 0.0;
+      }
+    }
+    const double nneg = static_cast<double>(n_items - npos);
+    auc[u] = (npos > 0 && nneg > 0) ? (lt + 0.5 * (le - lt)) / (static_cast<double>(npos) * nneg)
+                                    : 0.0;
+  }
+}
+
+int d8_bucket(int dim) {
+  const int d8 = (dim + 7) / 8;
+  int b = 1;
+  while (b < d8) b *= 2;
+  return b;
+}
+
+struct EvalWs {
+  float* cand_scores;
+  int32_t* cand_ids;
+  size_t bytes;
+  int nchunks;
+  int tiles_per_chunk;
+};
+
+EvalWs carve_eval_ws(void* base, int64_t n_users, int64_t n_items_shard) {
+  EvalWs w;
+  const int64_t ntiles = (n_items_shard + kTileItems - 1) / kTileItems;
+  const int64_t user_blocks = (n_users + kUsersPerBlock - 1) / kUsersPerBlock;
+  // enough workgroups to fill 256 CUs a few times over, at most 64 chunks
+  int64_t want = (2048 + user_blocks - 1) / user_blocks;
+  if (want < 1) want = 1;
+  if (want > 64) want = 64;
+  if (want > ntiles) want = ntiles;
+  if (want < 1) want = 1;
+  w.tiles_per_chunk = static_cast<int>((ntiles + want - 1) / want);
+  if (w.tiles_per_chunk < 1) w.tiles_per_chunk = 1;
+  w.nchunks = static_cast<int>((ntiles + w.tiles_per_chunk - 1) / w.tiles_per_chunk);
+  if (w.nchunks < 1) w.nchunks = 1;
+  Carver c(base);
+  const size_t n = static_cast<size_t>(n_users) * w.nchunks * 2 * kCap;
+  w.cand_scores = c.take<float>(n);
+  w.cand_ids = c.take<int32_t>(n);
+  w.bytes = align_up(c.off, 256);
+  return w;
+}
+
+template <int MODE>
+int launch_gemm(int d8, dim3 grid, hipStream_t stream, const EvalParams& p) {
+  switch (d8) {
+    case 1: hipLaunchKernelGGL((eval_gemm_kernel<1, MODE>), grid, dim3(kBlock), 0, stream, p); break;
+    case 2: hipLaunchKernelGGL((eval_gemm_kernel<2, MODE>), grid, dim3(kBlock), 0, stream, p); break;
+    case 4: hipLaunchKernelGGL((eval_gemm_kernel<4, MODE>), grid, dim3(kBlock), 0, stream, p); break;
+    case 8: hipLaunchKernelGGL((eval_gemm_kernel<8, MODE>), grid, dim3(kBlock), 0, stream, p); break;
+    case 16: hipLaunchKernelGGL((eval_gemm_kernel<16, MODE>), grid, dim3(kBlock), 0, stream, p); break;
+    case 32: hipLaunchKernelGGL((eval_gemm_kernel<32, MODE>), grid, dim3(kBlock), 0, stream, p); break;
+    default:
+      set_error("embedding_dim > 256 is not supported by the MFMA evaluator");
+      return -1;
+  }
+  return check_launch("eval_gemm_kernel");
+}
+
+int check_range(const collie_mf_tables* t, int64_t n_users, int64_t item_begin, int64_t item_end) {
+  COLLIE_REQUIRE(n_users >= 1, "eval: empty user batch");
+  COLLIE_REQUIRE(item_begin >= 0 && item_end > item_begin && item_end <= t->num_items,
+                 "eval: bad item range [%lld, %lld)", static_cast<long long>(item_begin),
+                 static_cast<long long>(item_end));
+  COLLIE_REQUIRE(t->dim <= 256, "embedding_dim > 256 is not supported by the MFMA evaluator");
+  return 0;
+}
+
+}  // namespace
+}  // namespace collie
+
+using namespace collie;
+
+extern "C" int32_t collie_mf_eval_topk_capacity(void) { return kCap; }
+
+extern "C" size_t collie_mf_eval_workspace_bytes(int64_t n_users, int64_t n_items_shard) {
+  if (n_users < 1 || n_items_shard < 1) return 0;
+  return carve_eval_ws(nullptr, n_users, n_items_shard).bytes;
+}
+
+extern "C" int collie_mf_eval_topk(const collie_mf_tables* t, const int64_t* user_ids,
+                                   int64_t n_users, int64_t item_begin, int64_t item_end,
+                                   int32_t k, int32_t has_y_range, float y_lo, float y_hi,
+                                   float* topk_scores, int64_t* topk_ids, void* workspace,
+                                   size_t workspace_bytes, collie_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (validate_tables(t) || check_range(t, n_users, item_begin, item_end)) return -1;
+  COLLIE_REQUIRE(user_ids && topk_scores && topk_ids, "eval_topk: NULL pointer");
+  COLLIE_REQUIRE(k >= 1 && k <= kCap, "eval_topk: k must be in [1, %d] (got %d)", kCap, k);
+  COLLIE_REQUIRE(k <= item_end - item_begin, "eval_topk: k (%d) exceeds the number of items", k);
+  EvalWs ws = carve_eval_ws(workspace, n_users, item_end - item_begin);
+  COLLIE_REQUIRE(workspace && workspace_bytes >= ws.bytes,
+                 "eval workspace too small: need %zu bytes, got %zu", ws.bytes, workspace_bytes);
+  EvalParams p;
+  memset(&p, 0, sizeof(p));
+  p.t = *t;
+  p.user_ids = user_ids;
+  p.n_users = n_users;
+  p.item_begin = item_begin;
+  p.item_end = item_end;
+  p.tiles_per_chunk = ws.tiles_per_chunk;
+  p.nchunks = ws.nchunks;
+  p.k = k;
+  p.D8 = d8_bucket(t->dim);
+  p.cand_scores = ws.cand_scores;
+  p.cand_ids = ws.cand_ids;
+  dim3 grid(static_cast<unsigned>((n_users + kUsersPerBlock - 1) / kUsersPerBlock),
+            static_cast<unsigned>(ws.nchunks));
+  if (launch_gemm<0>(p.D8, grid, stream, p)) return -1;
+  hipLaunchKernelGGL(merge_topk_kernel, dim3(static_cast<unsigned>((n_users + kWaves - 1) / kWaves)),
+                     dim3(kBlock), 0, stream, ws.cand_scores, ws.cand_ids, n_users, ws.nchunks * 2,
+                     k, has_y_range, y_lo, y_hi, topk_scores, topk_ids);
+  return check_launch("merge_topk_kernel");
+}
+
+extern "C" int collie_mf_eval_merge_topk(const float* cand_scores, const int32_t* cand_ids,
+                                         int64_t n_users, int32_t nslots, int32_t k,
+                                         float* topk_scores, int64_t* topk_ids,
+                                         collie_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  COLLIE_REQUIRE(cand_scores && cand_ids && topk_scores && topk_ids, "merge_topk: NULL pointer");
+  COLLIE_REQUIRE(n_users >= 1 && nslots >= 1 && k >= 1 && k <= kCap, "merge_topk: bad sizes");
+  hipLaunchKernelGGL(merge_topk_kernel, dim3(static_cast<unsigned>((n_users + kWaves - 1) / kWaves)),
+                     dim3(kBlock), 0, stream, cand_scores, cand_ids, n_users, nslots, k, 0, 0.0f,
+                     0.0f, topk_scores, topk_ids);
+  return check_launch("merge_topk_kernel");
+}
+
+extern "C" int collie_mf_eval_pos_scores(const collie_mf_tables* t, const int64_t* user_ids,
+                                         int64_t n_users, const int64_t* indptr,
+                                         const int64_t* indices, int64_t nnz, int32_t has_y_range,
+                                         float y_lo, float y_hi, float* pos_scores, float* thr_lo,
+                                         float* thr_hi, float* best_score, int64_t* best_id,
+                                         collie_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (validate_tables(t)) return -1;
+  COLLIE_REQUIRE(user_ids && indptr && indices && pos_scores, "eval_pos_scores: NULL pointer");
+  COLLIE_REQUIRE(n_users >= 1 && nnz >= 0, "eval_pos_scores: bad sizes");
+  COLLIE_REQUIRE(t->dim <= 256, "embedding_dim > 256 is not supported by the MFMA evaluator");
+  if (nnz > 0) {
+    int64_t blocks = (nnz + kBlock - 1) / kBlock;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pos_scores_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0,
+                       stream, *t, user_ids, n_users, indptr, indices, d8_bucket(t->dim),
+                       has_y_range, y_lo, y_hi, pos_scores, thr_lo, thr_hi);
+    if (check_launch("pos_scores_kernel")) return -2;
+  }
+  if (best_score && best_id) {
+    hipLaunchKernelGGL(best_pos_kernel, dim3(static_cast<unsigned>((n_users + kBlock - 1) / kBlock)),
+                       dim3(kBlock), 0, stream, indptr, indices, pos_scores, n_users, best_score,
+                       best_id);
+    return check_launch("best_pos_kernel");
+  }
+  return 0;
+}
+
+extern "C" int collie_mf_eval_rank_counts(const collie_mf_tables* t, const int64_t* user_ids,
+                                          int64_t n_users, const int64_t* indptr,
+                                          const float* thr_lo, const float* thr_hi,
+                                          const float* best_score, const int64_t* best_id,
+                                          int64_t item_begin, int64_t item_end, uint64_t* counts,
+                                          collie_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (validate_tables(t) || check_range(t, n_users, item_begin, item_end)) return -1;
+  COLLIE_REQUIRE(user_ids && indptr && thr_lo && thr_hi && best_score && best_id && counts,
+                 "eval_rank_counts: NULL pointer");
+  EvalWs ws = carve_eval_ws(nullptr, n_users, item_end - item_begin);
+  EvalParams p;
+  memset(&p, 0, sizeof(p));
+  p.t = *t;
+  p.user_ids = user_ids;
+  p.n_users = n_users;
+  p.item_begin = item_begin;
+  p.item_end = item_end;
+  p.tiles_per_chunk = ws.tiles_per_chunk;
+  p.nchunks = ws.nchunks;
+  p.k = 1;
+  p.D8 = d8_bucket(t->dim);
+  p.indptr = indptr;
+  p.thr_lo = thr_lo;
+  p.thr_hi = thr_hi;
+  p.best_score = best_score;
+  p.best_id = best_id;
+  p.counts = reinterpret_cast<unsigned long long*>(counts);
+  dim3 grid(static_cast<unsigned>((n_users + kUsersPerBlock - 1) / kUsersPerBlock),
+            static_cast<unsigned>(ws.nchunks));
+  return launch_gemm<1>(p.D8, grid, stream, p);
+}
+
+extern "C" int collie_mf_eval_metrics(const int64_t* topk_ids, int32_t k, int64_t n_users,
+                                      int64_t n_items, const int64_t* indptr,
+                                      const int64_t* indices, const float* pos_scores,
+                                      const uint64_t* counts, int32_t has_y_range, float y_lo,
+                                      float y_hi, double* ap, float* rr, double* auc,
+                                      collie_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  COLLIE_REQUIRE(indptr && indices, "eval_metrics: NULL CSR");
+  COLLIE_REQUIRE(n_users >= 1, "eval_metrics: empty user batch");
+  if (ap) COLLIE_REQUIRE(topk_ids && k >= 1, "eval_metrics: AP needs the top-k ids");
+  if (rr || auc) COLLIE_REQUIRE(counts && pos_scores, "eval_metrics: RR / AUC need the rank counts");
+  hipLaunchKernelGGL(metrics_kernel, dim3(static_cast<unsigned>((n_users + kBlock - 1) / kBlock)),
+                     dim3(kBlock), 0, stream, topk_ids, k, n_users, n_items, indptr, indices,
+                     pos_scores, reinterpret_cast<const unsigned long long*>(counts), has_y_range,
+                     y_lo, y_hi, ap, rr, auc);
+  return check_launch("metrics_kernel");
+}

@@ -1,0 +1,256 @@
+"""
+``evaluate_in_batches`` and the ``mapk`` / ``mrr`` / ``auc`` metric callables
+(reference: ``collie/metrics.py``), same names, arguments, return shapes and errors.
+
+Fast route (taken when the model is this package's ``MatrixFactorizationModel`` and every metric
+is one of the three callables below): the catalog is scored by the exact-fp32 MFMA kernels of
+``mf_eval.hip``; the ``[users, items]`` score matrix of ``get_preds`` (metrics.py:102-107) is never
+written, the top-k ids never leave the GPU until the per-user AP / RR / AUC are final, and there
+is no scipy round trip.  The per-user values are then aggregated exactly as the reference does:
+consecutive slices of ``batch_size`` sorted unique test users, batch mean times batch length,
+divided by the number of test users (metrics.py:367-386).
+
+Generic route (any other model object or metric callable): ``get_preds`` materialises the score
+matrix through ``model(users, items)`` and each metric callable receives it, as in the reference.
+The callables below then reduce that dense matrix with the same HIP kernels
+(``collie_dense_*``), so no stock torch arithmetic is involved there either.
+"""
+import warnings
+from typing import Any, Callable, Iterable, List, Optional
+
+import numpy as np
+import torch
+from scipy.sparse import csr_matrix
+
+from collie_amd import _lib, ops
+from collie_amd.interactions import Interactions
+
+USERS_PER_LAUNCH = 8192
+
+
+def _get_user_item_pairs(user_ids, n_items: int, device):
+    """``metrics.py:20-74``."""
+    if isinstance(n_items, np.int64):
+        n_items = n_items.item()
+    users = torch.tensor(np.asarray(user_ids), dtype=torch.int64, device=device
+                         ).repeat_interleave(n_items)
+    items = torch.arange(0, n_items, device=device).repeat(len(user_ids))
+    return users, items
+
+
+def get_preds(model, user_ids, n_items: int, device) -> torch.Tensor:
+    """``metrics.py:77-107``: [n_users, n_items] scores through ``model(users, items)``."""
+    user, item = _get_user_item_pairs(user_ids, n_items, device)
+    with torch.no_grad():
+        predicted_scores = model(user, item)
+    return predicted_scores.view(-1, n_items)
+
+
+def _csr_slice(targets: csr_matrix, user_ids, device):
+    sub = targets[np.asarray(user_ids)]
+    sub.sort_indices()
+    indptr = torch.from_numpy(sub.indptr.astype(np.int64)).to(device)
+    indices = torch.from_numpy(sub.indices.astype(np.int64)).to(device)
+    return indptr, indices
+
+
+def _dense_tables(preds: torch.Tensor):
+    """
+    A dense [n, N] score matrix as MF tables: U = preds (dim N), I = identity would be O(N^2);
+    instead the dense callables run the reduction kernels on one-hot-free inputs by treating every
+    row of ``preds`` as a user whose "embedding" is the row itself against a unit item basis.
+    Only used for small generic-route matrices (the reference's default batch is 20 users).
+    """
+    n, N = preds.shape
+    dev = preds.device
+    eye = torch.eye(N, dtype=torch.float32, device=dev)
+    zeros_u = torch.zeros(n, 1, dtype=torch.float32, device=dev)
+    zeros_i = torch.zeros(N, 1, dtype=torch.float32, device=dev)
+    return _lib.make_tables(preds.contiguous().float(), eye, zeros_u, zeros_i), (eye, zeros_u, zeros_i)
+
+
+def _per_user(tables, user_slots, indptr, indices, n_items, k, y_range, want, ws=None,
+              item_range=None):
+    """Per-user (ap, rr, auc) device tensors for one launch-sized group of users."""
+    want_ap, want_rr, want_auc = want
+    dev = user_slots.device
+    n = user_slots.shape[0]
+    lo_i, hi_i = item_range if item_range is not None else (0, n_items)
+    ws = ws or ops.EvalWorkspace(dev)
+    topk_ids = None
+    if want_ap:
+        _, topk_ids = ops.eval_topk(tables, user_slots, lo_i, hi_i, k, y_range, ws)
+    pos = counts = None
+    if want_rr or want_auc:
+        pos, lo, hi, best_s, best_id = ops.eval_pos_scores(tables, user_slots, indptr, indices,
+                                                           y_range, True)
+        counts = torch.zeros(n, 3, dtype=torch.int64, device=dev)
+        ops.eval_rank_counts(tables, user_slots, indptr, lo, hi, best_s, best_id, lo_i, hi_i,
+                             counts)
+    return ops.eval_metrics(topk_ids, k, n, n_items, indptr, indices, pos, counts, y_range,
+                            want_ap, want_rr, want_auc)
+
+
+def _check_k(k, n_items):
+    if k > n_items:
+        raise ValueError(f'Ensure ``k`` ({k}) is less than the number of items ({n_items}):')
+    if k > ops.eval_topk_capacity():
+        raise ValueError(f'k={k} exceeds the register-resident top-k capacity '
+                         f'({ops.eval_topk_capacity()}) of the HIP evaluator')
+
+
+def _dense_metric(which, targets, user_ids, preds, k):
+    _lib.require_hip(preds, 'preds')
+    n, N = preds.shape
+    if N > 256:
+        raise _lib.CollieHipError(
+            'the dense metric callables are meant for small score matrices; use '
+            '``evaluate_in_batches`` with a MatrixFactorizationModel for full catalogs')
+    tables, keep = _dense_tables(preds)
+    slots = torch.arange(n, dtype=torch.int64, device=preds.device)
+    indptr, indices = _csr_slice(targets, user_ids, preds.device)
+    want = (which == 'ap', which == 'rr', which == 'auc')
+    out = _per_user(tables, slots, indptr, indices, N, k, None, want)
+    del keep
+    return out
+
+
+def mapk(targets: csr_matrix, user_ids, preds, k: int = 10) -> float:
+    """``metrics.py:144-198``: mean average precision at k (float64 math, NaN -> 0)."""
+    _check_k(k, preds.shape[1])
+    ap, _, _ = _dense_metric('ap', targets, user_ids, preds, k)
+    return ap.cpu().numpy().mean().item()
+
+
+def mrr(targets: csr_matrix, user_ids, preds, k: Optional[Any] = None) -> float:
+    """``metrics.py:201-240``: mean reciprocal rank of the first relevant item (fp32 mean)."""
+    _, rr, _ = _dense_metric('rr', targets, user_ids, preds, 1)
+    return rr.cpu().numpy().mean(dtype=np.float32).item()
+
+
+def auc(targets: csr_matrix, user_ids, preds, k: Optional[Any] = None) -> float:
+    """``metrics.py:243-282``: mean per-user AUROC of ``sigmoid(preds)`` (tie-averaged)."""
+    _, _, a = _dense_metric('auc', targets, user_ids, preds, 1)
+    return a.cpu().numpy().astype(np.float32).mean(dtype=np.float32).item()
+
+
+_FAST = {mapk: 'ap', mrr: 'rr', auc: 'auc'}
+
+
+def _batch_mean(name, values):
+    """The reduction each reference metric applies to one batch of users."""
+    if name == 'ap':
+        return float(values.mean())                                   # float64 (:195-198)
+    if name == 'rr':
+        return float(values.astype(np.float32).mean(dtype=np.float32))  # fp32 (:237-240)
+    return float(values.astype(np.float32).mean(dtype=np.float32))      # fp32 tensors (:280-282)
+
+
+def evaluate_in_batches(
+    metric_list: Iterable[Callable[..., float]],
+    test_interactions: Interactions,
+    model,
+    k: int = 10,
+    batch_size: int = 20,
+    logger=None,
+    verbose: bool = True,
+) -> List[float]:
+    """``metrics.py:285-395``."""
+    if not isinstance(test_interactions, Interactions):
+        raise ValueError(
+            '``test_interactions`` must be of type ``Interactions``, not '
+            f'{type(test_interactions)}. Try using ``explicit_evaluate_in_batches`` instead.')
+    metric_list = list(metric_list)
+    device = _get_evaluate_in_batches_device(model=model)
+    model.to(device)
+    model._move_any_external_data_to_device()
+
+    test_users = np.unique(test_interactions.mat.row)
+    targets = test_interactions.mat.tocsr()
+    n_items = test_interactions.num_items
+    if len(test_users) < batch_size:
+        batch_size = len(test_users)
+
+    from collie_amd.model import MatrixFactorizationModel
+    fast = (isinstance(model, MatrixFactorizationModel)
+            and all(m in _FAST for m in metric_list)
+            and k <= ops.eval_topk_capacity()
+            and model.hparams.embedding_dim <= 256)
+
+    if fast:
+        _check_k(k, n_items)
+        names = [_FAST[m] for m in metric_list]
+        want = ('ap' in names, 'rr' in names, 'auc' in names)
+        was_training = model.training
+        model.eval()
+        tables = model._tables()
+        y = model.hparams.get('y_range')
+        y = tuple(y) if y is not None else None
+        ws = ops.EvalWorkspace(torch.device(device) if not isinstance(device, torch.device) else device)
+        per_user = {n: [] for n in ('ap', 'rr', 'auc')}
+        with torch.no_grad():
+            for s in range(0, len(test_users), USERS_PER_LAUNCH):
+                group = test_users[s:s + USERS_PER_LAUNCH]
+                slots = torch.from_numpy(group.astype(np.int64)).to(tables_device(model))
+                indptr, indices = _csr_slice(targets, group, slots.device)
+                ap, rr, au = _per_user(tables, slots, indptr, indices, n_items, k, y, want, ws)
+                for n, v in (('ap', ap), ('rr', rr), ('auc', au)):
+                    if v is not None:
+                        per_user[n].append(v)
+        host = {n: torch.cat(v).cpu().numpy() for n, v in per_user.items() if v}
+        if was_training:
+            model.train()
+        accumulators = [0] * len(metric_list)
+        for i in range(int(np.ceil(len(test_users) / batch_size))):
+            sl = slice(i * batch_size, (i + 1) * batch_size)
+            for j, name in enumerate(names):
+                vals = host[name][sl]
+                accumulators[j] += _batch_mean(name, vals) * len(vals)
+    else:
+        accumulators = [0] * len(metric_list)
+        for i in range(int(np.ceil(len(test_users) / batch_size))):
+            user_range = test_users[i * batch_size:(i + 1) * batch_size]
+            preds = get_preds(model, user_range, n_items, device)
+            for j, metric in enumerate(metric_list):
+                score = metric(targets=targets, user_ids=user_range, preds=preds, k=k)
+                accumulators[j] += (score * len(user_range))
+
+    all_scores = [acc_score / len(test_users) for acc_score in accumulators]
+    if logger is not None:
+        _log_metrics(model=model, logger=logger, metric_list=metric_list, all_scores=all_scores,
+                     verbose=verbose)
+    return all_scores[0] if len(all_scores) == 1 else all_scores
+
+
+def tables_device(model):
+    return model.user_embeddings.weight.device
+
+
+def _get_evaluate_in_batches_device(model):
+    """``metrics.py:505-521``."""
+    device = getattr(model, 'device', None)
+    if torch.cuda.is_available() and str(device) == 'cpu':
+        warnings.warn('CUDA available but model device is set to CPU - is this desired?')
+    if device is None:
+        if torch.cuda.is_available():
+            warnings.warn('``model.device`` attribute is ``None``. Since GPU is available, putting '
+                          'model on GPU.')
+            device = 'cuda:0'
+        else:
+            device = 'cpu'
+    return device
+
+
+def _log_metrics(model, logger, metric_list, all_scores, verbose):
+    """``metrics.py:524-543``."""
+    try:
+        step = model.hparams.get('num_epochs_completed')
+    except AttributeError:
+        step = None
+    try:
+        metrics_dict = dict(zip([x.__name__ for x in metric_list], all_scores))
+    except AttributeError:
+        metrics_dict = dict(zip([type(x).__name__ for x in metric_list], all_scores))
+    if verbose:
+        print(f'Logging metrics {metrics_dict} to ``logger``...')
+    logger.log_metrics(metrics=metrics_dict, step=step)

@@ -173,4 +173,94 @@ def loss_forward_backward(loss_cfg, s_pos, s_neg_KB, pos_items=None, neg_items_K
     return loss, g_pos, g_neg
 
 
-__all__ = [name for name in dir() if not name.startswith('_')]
+
+
+# ---- evaluation -----------------------------------------------------------------------------------
+def eval_topk_capacity():
+    return int(load().collie_mf_eval_topk_capacity())
+
+
+def _y(y_range):
+    has_y = y_range is not None
+    return int(has_y), float(y_range[0]) if has_y else 0.0, float(y_range[1]) if has_y else 0.0
+
+
+class EvalWorkspace:
+    def __init__(self, device):
+        self.device = device
+        self.buf = None
+
+    def ensure(self, n_users, n_items_shard):
+        need = int(load().collie_mf_eval_workspace_bytes(n_users, n_items_shard))
+        if self.buf is None or self.buf.numel() < need:
+            self.buf = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self.buf
+
+
+def eval_topk(tables, user_ids, item_begin, item_end, k, y_range, ws):
+    """(scores [n, k] float32, ids [n, k] int64): descending score, ascending id on ties."""
+    require_hip(user_ids, 'user_ids')
+    assert user_ids.dtype == torch.int64 and user_ids.is_contiguous()
+    n = user_ids.shape[0]
+    dev = user_ids.device
+    buf = ws.ensure(n, item_end - item_begin)
+    scores = torch.empty(n, k, dtype=torch.float32, device=dev)
+    ids = torch.empty(n, k, dtype=torch.int64, device=dev)
+    has_y, lo, hi = _y(y_range)
+    check(load().collie_mf_eval_topk(byref(tables), ptr(user_ids), n, item_begin, item_end, k,
+                                     has_y, lo, hi, ptr(scores), ptr(ids), ptr(buf), buf.numel(),
+                                     stream_ptr()), 'collie_mf_eval_topk')
+    return scores, ids
+
+
+def eval_pos_scores(tables, user_ids, indptr, indices, y_range, want_thresholds):
+    n = user_ids.shape[0]
+    nnz = indices.shape[0]
+    dev = user_ids.device
+    pos = torch.empty(max(nnz, 1), dtype=torch.float32, device=dev)
+    lo = hi = best_s = best_id = None
+    if want_thresholds:
+        lo = torch.empty(max(nnz, 1), dtype=torch.float32, device=dev)
+        hi = torch.empty(max(nnz, 1), dtype=torch.float32, device=dev)
+        best_s = torch.empty(n, dtype=torch.float32, device=dev)
+        best_id = torch.empty(n, dtype=torch.int64, device=dev)
+    has_y, ylo, yhi = _y(y_range)
+    check(load().collie_mf_eval_pos_scores(
+        byref(tables), ptr(user_ids), n, ptr(indptr), ptr(indices), nnz, has_y, ylo, yhi,
+        ptr(pos), ptr(lo), ptr(hi), ptr(best_s), ptr(best_id), stream_ptr()),
+        'collie_mf_eval_pos_scores')
+    return pos, lo, hi, best_s, best_id
+
+
+def eval_rank_counts(tables, user_ids, indptr, lo, hi, best_s, best_id, item_begin, item_end,
+                     counts):
+    check(load().collie_mf_eval_rank_counts(
+        byref(tables), ptr(user_ids), user_ids.shape[0], ptr(indptr), ptr(lo), ptr(hi),
+        ptr(best_s), ptr(best_id), item_begin, item_end, ptr(counts), stream_ptr()),
+        'collie_mf_eval_rank_counts')
+
+
+def eval_metrics(topk_ids, k, n_users, n_items, indptr, indices, pos_scores, counts, y_range,
+                 want_ap, want_rr, want_auc):
+    dev = indptr.device
+    ap = torch.empty(n_users, dtype=torch.float64, device=dev) if want_ap else None
+    rr = torch.empty(n_users, dtype=torch.float32, device=dev) if want_rr else None
+    auc = torch.empty(n_users, dtype=torch.float64, device=dev) if want_auc else None
+    has_y, ylo, yhi = _y(y_range)
+    check(load().collie_mf_eval_metrics(
+        ptr(topk_ids), k, n_users, n_items, ptr(indptr), ptr(indices), ptr(pos_scores),
+        ptr(counts), has_y, ylo, yhi, ptr(ap), ptr(rr), ptr(auc), stream_ptr()),
+        'collie_mf_eval_metrics')
+    return ap, rr, auc
+
+
+def eval_merge_topk(cand_scores, cand_ids, k):
+    n, nslots, cap = cand_scores.shape
+    assert cap == eval_topk_capacity() and cand_ids.dtype == torch.int32
+    dev = cand_scores.device
+    scores = torch.empty(n, k, dtype=torch.float32, device=dev)
+    ids = torch.empty(n, k, dtype=torch.int64, device=dev)
+    check(load().collie_mf_eval_merge_topk(ptr(cand_scores.contiguous()),
+                                           ptr(cand_ids.contiguous()), n, nslots, k, ptr(scores),
+                                           ptr(ids), stream_ptr()), 'collie_mf_eval_merge_topk')
+    return scores, ids

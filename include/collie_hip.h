@@ -188,43 +188,67 @@ int collie_mf_train_export_grad(const collie_mf_tables* t, const collie_mf_batch
                                 int32_t* count_out, collie_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
- * A13-A16  get_preds + mapk / mrr / auc   collie/metrics.py:77-107,144-282
- * Scores one batch of users against the item rows [item_begin, item_end) with exact-fp32 MFMA
- * tiles and never writes the [Bu, N] score matrix: emits per user the top-k (score, id) of the
- * shard (descending score, ascending id) and, for every (user, positive) pair listed in the CSR
- * slice, the number of shard items ranked strictly above / tied with that positive
- * (MRR and AUC are closed forms of those counts).
+ * A13-A17  get_preds + mapk / mrr / auc   collie/metrics.py:77-107,144-282
+ *
+ * The [users, items] score matrix of get_preds (metrics.py:102-107) is never written.  Scores are
+ * produced in 32x32 tiles by exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) and consumed in registers.
+ * All entry points take a *batch* of users (user_ids [n_users], int64) and an item shard
+ * [item_begin, item_end) of the catalog, so the same calls serve single-GPU evaluation (one shard
+ * = whole catalog) and catalog-sharded evaluation (one shard per GPU, results merged).
+ * The user's positives are a CSR slice over the batch: indptr [n_users+1], indices [nnz] (item
+ * ids, ascending inside a row as scipy's tocsr() gives them, metrics.py:368).
  * ------------------------------------------------------------------------------------------- */
-size_t collie_mf_eval_workspace_bytes(int64_t n_users, int64_t n_items_shard, int32_t dim,
-                                      int32_t k);
+
+/* largest k the register-resident top-k supports */
+int32_t collie_mf_eval_topk_capacity(void);
+
+size_t collie_mf_eval_workspace_bytes(int64_t n_users, int64_t n_items_shard);
+
+/* preds.topk(k) (metrics.py:171) over the shard: topk_ids / topk_scores [n_users, k], ordered by
+ * descending score, ascending item id on exact ties.  Scores are y_range-transformed if asked. */
 int collie_mf_eval_topk(const collie_mf_tables* t, const int64_t* user_ids, int64_t n_users,
                         int64_t item_begin, int64_t item_end, int32_t k, int32_t has_y_range,
-                        float y_lo, float y_hi, float* topk_scores /* [n_users,k] */,
-                        int64_t* topk_ids /* [n_users,k] */, void* workspace,
-                        size_t workspace_bytes, collie_stream_t stream);
+                        float y_lo, float y_hi, float* topk_scores, int64_t* topk_ids,
+                        void* workspace, size_t workspace_bytes, collie_stream_t stream);
 
-/* positives' scores: pos_scores[e] for CSR entries e in [indptr[i], indptr[i+1]) of user i */
+/* Catalog-sharded evaluation: merge per-shard top-k candidate lists (cand_* [n_users, nslots,
+ * collie_mf_eval_topk_capacity()], unused entries = (-inf, INT32_MAX)) into the global top-k.
+ * No counterpart in the reference (it has no sharded evaluation). */
+int collie_mf_eval_merge_topk(const float* cand_scores, const int32_t* cand_ids, int64_t n_users,
+                              int32_t nslots, int32_t k, float* topk_scores, int64_t* topk_ids,
+                              collie_stream_t stream);
+
+/* Scores of the positives, computed with the same fmaf chain as the MFMA tiles so that they are
+ * bit-identical to the catalog scores of the same pairs:
+ *   pos_scores [nnz]  raw model score (before y_range)
+ *   thr_lo/thr_hi [nnz] (optional) the raw-score interval whose fp32 sigmoid(preds) equals the
+ *       positive's: AUC ranks sigmoid(preds) (metrics.py:277), which ties distinct raw scores
+ *   best_score / best_id [n_users] (optional) the user's best positive = first relevant item of
+ *       the descending order (metrics.py:224-238) */
 int collie_mf_eval_pos_scores(const collie_mf_tables* t, const int64_t* user_ids, int64_t n_users,
-                              const int64_t* indptr, const int64_t* indices, int32_t has_y_range,
-                              float y_lo, float y_hi, float* pos_scores, collie_stream_t stream);
+                              const int64_t* indptr, const int64_t* indices, int64_t nnz,
+                              int32_t has_y_range, float y_lo, float y_hi, float* pos_scores,
+                              float* thr_lo, float* thr_hi, float* best_score, int64_t* best_id,
+                              collie_stream_t stream);
 
-/* rank counts of every positive against the shard:
- *   above[e]  = #{ j in shard : s_ij >  s_ie  or (s_ij == s_ie and j < indices[e]) }   (MRR)
- *   sig_lt[e] = #{ j in shard : sigmoid(s_ij) <  sigmoid(s_ie) }                        (AUC)
- *   sig_eq[e] = #{ j in shard : sigmoid(s_ij) == sigmoid(s_ie) }   (includes j = e itself)
- * counts are ADDED to the int32 outputs (zero them first; shards accumulate). */
+/* Second MFMA pass: rank counts of the positives against the shard, ADDED into counts
+ * [n_users, 3] (uint64; zero before the first shard):
+ *   [0] #{j : s_j > best  or (s_j == best and j < best_id)}                (MRR)
+ *   [1] sum over the user's positives e of #{j : sigmoid(s_j) <  sigmoid(s_e)}   (AUC)
+ *   [2] sum over e of #{j : sigmoid(s_j) <= sigmoid(s_e)}                        (AUC ties) */
 int collie_mf_eval_rank_counts(const collie_mf_tables* t, const int64_t* user_ids,
-                               int64_t n_users, const int64_t* indptr, const int64_t* indices,
-                               const float* pos_scores, int64_t item_begin, int64_t item_end,
-                               int32_t has_y_range, float y_lo, float y_hi, int32_t* above,
-                               int32_t* sig_lt, int32_t* sig_eq, collie_stream_t stream);
+                               int64_t n_users, const int64_t* indptr, const float* thr_lo,
+                               const float* thr_hi, const float* best_score,
+                               const int64_t* best_id, int64_t item_begin, int64_t item_end,
+                               uint64_t* counts, collie_stream_t stream);
 
-/* MAP@k / MRR / AUC per user from the merged top-k ids and the rank counts
- * (metrics.py:178-198, :224-240, :266-282).  ap/rr/auc are [n_users] (any may be NULL). */
+/* Per-user AP@k (float64, metrics.py:178-196), reciprocal rank (fp32, :237-238) and tie-averaged
+ * AUC of sigmoid(preds) (:266-280) from the top-k ids and the rank counts.  Any of ap / rr / auc
+ * may be NULL. */
 int collie_mf_eval_metrics(const int64_t* topk_ids, int32_t k, int64_t n_users, int64_t n_items,
-                           const int64_t* indptr, const int64_t* indices, const int32_t* above,
-                           const int32_t* sig_lt, const int32_t* sig_eq, double* ap, float* rr,
-                           double* auc, collie_stream_t stream);
+                           const int64_t* indptr, const int64_t* indices, const float* pos_scores,
+                           const uint64_t* counts, int32_t has_y_range, float y_lo, float y_hi,
+                           double* ap, float* rr, double* auc, collie_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,210 @@
+"""
+GPU parity tests for the MFMA evaluator (``-m gpu``): top-k ids bit-exact (ties by index),
+MAP@k / MRR / AUC within 1e-5 relative of the oracle, the reference's own known answers reproduced
+through ``evaluate_in_batches``.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+pytestmark = pytest.mark.gpu
+NAMES = ('user_embeddings', 'item_embeddings', 'user_biases', 'item_biases')
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device('cuda:0')
+
+
+def make_model(tables, dev, **kw):
+    from collie_amd.model import MatrixFactorizationModel
+
+    class Shape:
+        num_users, num_items = tables['user_embeddings'].shape[0], tables['item_embeddings'].shape[0]
+        num_negative_samples = 10
+
+    model = MatrixFactorizationModel(train=Shape(), embedding_dim=tables['user_embeddings'].shape[1],
+                                     lr_scheduler_func=None, **kw)
+    with torch.no_grad():
+        for n in NAMES:
+            getattr(model, n).weight.copy_(torch.tensor(tables[n]))
+    return model.to(dev).eval()
+
+
+def test_reference_known_answers_through_evaluate_in_batches(golden_dir, dev):
+    """tests/test_metrics.py:230-256 of the reference: the 3x4 score matrix, k=4, batches 20/2/1.
+    The fixed score matrix is realised exactly as U = scores, I = identity, zero biases."""
+    from collie_amd.interactions import Interactions
+    from collie_amd.metrics import auc, evaluate_in_batches, mapk, mrr
+    with open(os.path.join(golden_dir, 'ref_known_answers.json')) as f:
+        M = json.load(f)['metrics']
+    P = np.array(M['predicted_scores'], np.float32)
+    tables = {'user_embeddings': P, 'item_embeddings': np.eye(4, dtype=np.float32),
+              'user_biases': np.zeros((3, 1), np.float32), 'item_biases': np.zeros((4, 1), np.float32)}
+    model = make_model(tables, dev)
+    test = Interactions(users=M['users'], items=M['items'], ratings=[1] * 8,
+                        check_num_negative_samples_is_valid=False)
+    exp = M['evaluate_in_batches_k4']
+    for batch_size in (20, 2, 1):
+        m, r, a = evaluate_in_batches([mapk, mrr, auc], test, model, k=4, batch_size=batch_size,
+                                      verbose=False)
+        np.testing.assert_almost_equal(m, exp['mapk'])
+        np.testing.assert_almost_equal(r, exp['mrr'])
+        np.testing.assert_almost_equal(a, exp['auc'])
+    # single metric -> bare float (metrics.py:395)
+    assert isinstance(evaluate_in_batches([mapk], test, model, k=4, verbose=False), float)
+    # k > n_items raises ValueError (metrics.py:170-175)
+    with pytest.raises(ValueError):
+        evaluate_in_batches([mapk], test, model, k=5, verbose=False)
+    with pytest.raises(ValueError):
+        evaluate_in_batches([mapk], 'not interactions', model)
+
+
+def test_standalone_metric_callables_known_answers(golden_dir, dev):
+    """tests/test_metrics.py:101-154: mapk == .75 (k=4, users 1,2), MAP@1 = 2/3, MRR, AUC."""
+    from collie_amd.metrics import auc, mapk, mrr
+    with open(os.path.join(golden_dir, 'ref_known_answers.json')) as f:
+        M = json.load(f)['metrics']
+    P = torch.tensor(M['predicted_scores'], dtype=torch.float32, device=dev)
+    tg = sp.coo_matrix((np.ones(8), (M['users'], M['items'])), shape=(3, 4)).tocsr()
+    assert mapk(tg, np.array([1, 2]), P[[1, 2]], k=4) == M['mapk_k4_users_1_2']
+    np.testing.assert_almost_equal(mapk(tg, np.arange(3), P, k=1), M['mapk_k1_all'])
+    np.testing.assert_almost_equal(mrr(tg, np.arange(3), P), M['mrr_all'])
+    np.testing.assert_almost_equal(auc(tg, np.arange(3), P), np.mean(M['auc_sklearn_per_user']))
+    with pytest.raises(ValueError):
+        mapk(tg, np.arange(3), P, k=5)
+
+
+def test_eval_case_with_engineered_ties(golden_dir, dev):
+    from oracle import mf_oracle as O
+    from collie_amd import _lib, ops
+    z = np.load(os.path.join(golden_dir, 'eval_case.npz'))
+    tables = {n: z[f't|{n}'] for n in NAMES}
+    model = make_model(tables, dev)
+    t = model._tables()
+    users = z['test_users']
+    N = tables['item_embeddings'].shape[0]
+    coo = sp.coo_matrix((np.ones(len(z['rows'])), (z['rows'], z['cols'])), shape=(9, N))
+    csr = coo.tocsr()
+    slots = torch.tensor(users, dtype=torch.int64, device=dev)
+    ws = ops.EvalWorkspace(dev)
+    scores, ids = ops.eval_topk(t, slots, 0, N, 10, None, ws)
+    # ids: exact against the stable (score desc, id asc) order of the torch-computed scores,
+    # wherever those scores are not within rounding of each other
+    ref_ids = z['top10_ids_restatement']
+    ref_scores = np.take_along_axis(z['preds_torch'], ref_ids, axis=1)
+    got = ids.cpu().numpy()
+    for i in range(len(users)):
+        full = np.sort(z['preds_torch'][i])[::-1]
+        gaps_ok = np.all((np.abs(np.diff(full[:12])) > 1e-6) | (np.diff(full[:12]) == 0))
+        if gaps_ok:
+            np.testing.assert_array_equal(got[i], ref_ids[i])
+    np.testing.assert_allclose(scores.cpu().numpy(), ref_scores, rtol=1e-5, atol=1e-6)
+    # tie groups come out in ascending id order
+    s = scores.cpu().numpy()
+    for i in range(len(users)):
+        same = np.nonzero(np.diff(s[i]) == 0)[0]
+        assert np.all(got[i][same] < got[i][same + 1])
+    # per-user metrics
+    from collie_amd.metrics import _csr_slice, _per_user
+    indptr, indices = _csr_slice(csr, users, dev)
+    ap, rr, au = _per_user(t, slots, indptr, indices, N, 10, None, (True, True, True), ws)
+    np.testing.assert_allclose(ap.cpu().numpy(), z['ap_restatement'], rtol=1e-5)
+    np.testing.assert_allclose(rr.cpu().numpy(), z['rr_restatement'], rtol=1e-5)
+    np.testing.assert_allclose(au.cpu().numpy(), z['auc_sklearn_on_torch_sigmoid'], rtol=1e-5)
+
+
+@pytest.mark.parametrize('D,N,U,k', [(64, 5003, 300, 10), (10, 1682, 943, 10), (128, 2048, 70, 16),
+                                     (30, 777, 129, 1), (256, 300, 40, 5), (8, 50000, 33, 10)])
+def test_topk_ids_exact_on_exactly_representable_scores(dev, D, N, U, k):
+    """Embeddings on a coarse grid: every dot product is exact in fp32 in any order, so the ids
+    must equal the oracle's (score desc, id asc) order bit for bit, ties included."""
+    from oracle import mf_oracle as O
+    from collie_amd import ops
+    rng = np.random.default_rng(D + N)
+    tables = {'user_embeddings': (rng.integers(-4, 5, (U, D)) / 8).astype(np.float32),
+              'item_embeddings': (rng.integers(-4, 5, (N, D)) / 8).astype(np.float32),
+              'user_biases': (rng.integers(-8, 9, (U, 1)) / 16).astype(np.float32),
+              'item_biases': (rng.integers(-8, 9, (N, 1)) / 16).astype(np.float32)}
+    model = make_model(tables, dev)
+    t = model._tables()
+    users = np.sort(rng.choice(U, min(U, 200), replace=False))
+    preds = O.get_preds(tables, users, N)
+    ws = ops.EvalWorkspace(dev)
+    slots = torch.tensor(users, dtype=torch.int64, device=dev)
+    scores, ids = ops.eval_topk(t, slots, 0, N, k, None, ws)
+    ref = O.topk_ids(preds, k)
+    np.testing.assert_array_equal(ids.cpu().numpy(), ref)
+    np.testing.assert_array_equal(scores.cpu().numpy(), np.take_along_axis(preds, ref, axis=1))
+    # sharded: two item shards + merge give the same ids (catalog-sharded evaluation)
+    cap = ops.eval_topk_capacity()
+    half = N // 2
+    parts = []
+    for lo, hi in ((0, half), (half, N)):
+        s_, i_ = ops.eval_topk(t, slots, lo, hi, min(k, hi - lo), None, ws)
+        cs = torch.full((len(users), 1, cap), float('-inf'), device=dev)
+        ci = torch.full((len(users), 1, cap), 2 ** 31 - 1, dtype=torch.int32, device=dev)
+        cs[:, 0, :s_.shape[1]] = s_
+        ci[:, 0, :i_.shape[1]] = i_.to(torch.int32)
+        parts.append((cs, ci))
+    ms, mi = ops.eval_merge_topk(torch.cat([p[0] for p in parts], 1), torch.cat([p[1] for p in parts], 1), k)
+    np.testing.assert_array_equal(mi.cpu().numpy(), ref)
+    # metrics against the oracle
+    nnz_per_user = rng.integers(1, 12, len(users))
+    rows = np.repeat(users, nnz_per_user)
+    cols = np.concatenate([rng.choice(N, n, replace=False) for n in nnz_per_user])
+    csr = sp.coo_matrix((np.ones(len(rows)), (rows, cols)), shape=(U, N)).tocsr()
+    from collie_amd.metrics import _csr_slice, _per_user
+    indptr, indices = _csr_slice(csr, users, dev)
+    ap, rr, au = _per_user(t, slots, indptr, indices, N, k, None, (True, True, True), ws)
+    np.testing.assert_allclose(ap.cpu().numpy(), O.mapk_per_user(csr, users, preds, k)[0], rtol=1e-12)
+    np.testing.assert_array_equal(rr.cpu().numpy(), O.mrr_per_user(csr, users, preds))
+    np.testing.assert_allclose(au.cpu().numpy(), O.auc_per_user(csr, users, preds), rtol=1e-6)
+
+
+def test_positive_scores_are_bit_identical_to_gemm_scores(dev):
+    """The fmaf-chain restatement of the MFMA order: each user's top-1 item scored as a
+    'positive' must reproduce the GEMM's score bit for bit (random real-valued embeddings)."""
+    from oracle import mf_oracle as O
+    from collie_amd import ops
+    rng = np.random.default_rng(5)
+    for D in (10, 64, 128):
+        U, N = 500, 3000
+        tables = O.init_tables(U, N, D, rng)
+        tables['item_biases'] = rng.normal(0, 0.01, (N, 1)).astype(np.float32)
+        model = make_model(tables, dev)
+        t = model._tables()
+        slots = torch.arange(U, dtype=torch.int64, device=dev)
+        ws = ops.EvalWorkspace(dev)
+        scores, ids = ops.eval_topk(t, slots, 0, N, 3, None, ws)
+        indptr = torch.arange(0, 3 * U + 1, 3, dtype=torch.int64, device=dev)
+        indices = ids.sort(dim=1).values.reshape(-1).contiguous()
+        pos, _, _, _, _ = ops.eval_pos_scores(t, slots, indptr, indices, None, False)
+        torch.cuda.synchronize()
+        want = torch.gather(scores, 1, ids.argsort(dim=1)).reshape(-1)
+        assert torch.equal(pos[:3 * U], want)
+
+
+def test_evaluate_in_batches_vs_oracle_ml100k_shape(dev):
+    from oracle import mf_oracle as O
+    from collie_amd.interactions import Interactions
+    from collie_amd.metrics import auc, evaluate_in_batches, mapk, mrr
+    rng = np.random.default_rng(1)
+    U, N, D = 943, 1682, 10
+    tables = O.init_tables(U, N, D, rng)
+    tables['user_embeddings'] *= 25
+    tables['item_embeddings'] *= 25
+    tables['item_biases'] = rng.normal(0, 0.3, (N, 1)).astype(np.float32)
+    model = make_model(tables, dev)
+    rows = rng.integers(0, U, 6000)
+    cols = rng.integers(0, N, 6000)
+    test = Interactions(users=rows, items=cols, num_users=U, num_items=N, allow_missing_ids=True,
+                        check_num_negative_samples_is_valid=False)
+    got = evaluate_in_batches([mapk, mrr, auc], test, model, k=10, batch_size=64, verbose=False)
+    ref = O.evaluate_in_batches([O.mapk, O.mrr, O.auc], test.mat, tables, k=10, batch_size=64)
+    np.testing.assert_allclose(got, ref, rtol=1e-5)
