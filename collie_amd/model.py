@@ -459,6 +459,7 @@ class MatrixFactorizationModel(nn.Module):
             getattr(self, n).weight.requires_grad for n in _TABLES)
         if self._workspace is None:
             self._workspace = ops.TrainWorkspace(dev)
+        self._staged_step = None        # the workspace is about to be overwritten
         B, K = neg_items.shape
         buf = self._workspace.ensure(B, K, self.hparams.embedding_dim)
         if self._meta_codes is None:

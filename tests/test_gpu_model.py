@@ -1,0 +1,225 @@
+"""
+GPU tests of the product API (``-m gpu``): MatrixFactorizationModel / fused optimizers / trainers,
+driven exactly as ``CollieMinimalTrainer`` drives the reference (trainer.py:458-470), against the
+numpy oracle fed with the same batches.
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+pytestmark = pytest.mark.gpu
+NAMES = ('user_embeddings', 'item_embeddings', 'user_biases', 'item_biases')
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device('cuda:0')
+
+
+def close(a, b, rtol=2e-5):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=rtol * max(np.abs(b).max(), 1e-30))
+
+
+def synth(U, N, nnz, seed, K=10):
+    from collie_amd.interactions import Interactions
+    rng = np.random.default_rng(seed)
+    users = (rng.zipf(1.4, nnz) % U)
+    items = (rng.zipf(1.2, nnz) % N)
+    return Interactions(users=users, items=items, num_users=U, num_items=N, allow_missing_ids=True,
+                        num_negative_samples=K, seed=seed, max_number_of_samples_to_consider=0)
+
+
+def tables_of(model):
+    return {n: getattr(model, n).weight.detach().cpu().numpy().copy() for n in NAMES}
+
+
+def step(model, opts, batch, scale=None):
+    for o in opts:
+        o.zero_grad()
+    loss = model.calculate_loss(batch)
+    (loss if scale is None else loss * scale).backward()
+    for i, o in enumerate(opts):
+        model.optimizer_step(optimizer=o, optimizer_idx=i)
+    return loss
+
+
+COMBOS = [
+    dict(sparse=True, optimizer='sparse_adam', bias_optimizer='sgd', loss='bpr', lr=1e-2, bias_lr=1e-1),
+    dict(sparse=False, optimizer='adam', bias_optimizer='sgd', loss='adaptive', lr=1e-1, bias_lr=1e-2),
+    dict(sparse=False, optimizer='adam', bias_optimizer='sgd', loss='adaptive', lr=1e-2, bias_lr=1e-2,
+         weight_decay=1e-3),
+    dict(sparse=True, optimizer='adagrad', bias_optimizer='infer', loss='warp', lr=5e-2, bias_lr='infer'),
+    dict(sparse=False, optimizer='sgd', bias_optimizer=None, loss='hinge', lr=5e-1, bias_lr=None),
+]
+
+
+@pytest.mark.parametrize('cfg', COMBOS)
+def test_model_training_trajectory_vs_oracle(dev, cfg):
+    from oracle import mf_oracle as O
+    from collie_amd.interactions import ApproximateNegativeSamplingInteractionsDataLoader
+    from collie_amd.model import MatrixFactorizationModel
+    from collie_amd.layers import MultiOptimizer
+    inter = synth(400, 300, 6000, seed=1)
+    loader = ApproximateNegativeSamplingInteractionsDataLoader(interactions=inter, batch_size=512,
+                                                               shuffle=True)
+    torch.manual_seed(3)
+    model = MatrixFactorizationModel(train=loader, embedding_dim=16, lr_scheduler_func=None, **cfg)
+    with torch.no_grad():
+        model.user_embeddings.weight.mul_(10.0)
+        model.item_embeddings.weight.mul_(10.0)
+    bopt = cfg['bias_optimizer']
+    oracle = O.TrainState(tables_of(model), optimizer=cfg['optimizer'],
+                          bias_optimizer=cfg['optimizer'] if bopt == 'infer' else bopt,
+                          lr=cfg['lr'], bias_lr=cfg['lr'] if cfg['bias_lr'] == 'infer' else cfg['bias_lr'],
+                          weight_decay=cfg.get('weight_decay', 0.0), sparse=cfg['sparse'])
+    model.to(dev).train()
+    ret = model.configure_optimizers()
+    opts = ret if isinstance(ret, list) else [ret]
+    kind = model._loss_kind
+    n = 0
+    for epoch in range(2):
+        for (u, p), neg in loader:
+            loss = step(model, opts, ((u.to(dev), p.to(dev)), neg.to(dev)))
+            ref = oracle.step(u.numpy(), p.numpy(), neg.numpy(), kind)
+            close(loss.item(), ref['loss'], rtol=5e-5)
+            n += 1
+    model.check_status()
+    got = tables_of(model)
+    for name in NAMES:
+        if name == 'user_biases':
+            assert float(np.abs(got[name]).max()) == 0.0 or cfg.get('weight_decay')
+            continue
+        close(got[name], oracle.t[name], rtol=2e-4)     # n steps of accumulated fp32 rounding
+    assert n == 2 * len(loader)
+
+
+def test_backward_honours_grad_output_and_validation_path(dev):
+    from collie_amd.model import MatrixFactorizationModel
+
+    class Shape:
+        num_users, num_items, num_negative_samples = 100, 80, 5
+
+    rng = np.random.default_rng(0)
+    batch = ((torch.tensor(rng.integers(0, 100, 64), dtype=torch.int32, device=dev),
+              torch.tensor(rng.integers(0, 80, 64), dtype=torch.int32, device=dev)),
+             torch.tensor(rng.integers(0, 80, (64, 5)), device=dev))
+    outs = []
+    for scale in (None, 2.0):
+        torch.manual_seed(0)
+        m = MatrixFactorizationModel(train=Shape(), embedding_dim=8, sparse=True, lr=0.5,
+                                     optimizer='sgd', bias_optimizer=None, loss='bpr',
+                                     lr_scheduler_func=None).to(dev).train()
+        w0 = m.item_embeddings.weight.detach().clone()
+        opt = m.configure_optimizers()
+        step(m, [opt], batch, scale)
+        outs.append((m.item_embeddings.weight.detach() - w0).cpu().numpy())
+    np.testing.assert_allclose(outs[1], 2 * outs[0], rtol=1e-3, atol=1e-7)  # deltas of O(1e-5) on O(0.1) weights
+    # validation: no grad, nothing staged, same loss value
+    m.eval()
+    with torch.no_grad():
+        v = m.calculate_loss(batch)
+    assert not v.requires_grad and m._staged_step is None
+    t = m.calculate_loss(batch)
+    assert t.requires_grad and abs(t.item() - v.item()) < 1e-6
+    # optimizer.step() without backward() is a no-op (nothing armed)
+    before = m.item_embeddings.weight.detach().clone()
+    opt.zero_grad()
+    m.calculate_loss(batch)
+    opt.step()
+    assert torch.equal(before, m.item_embeddings.weight.detach())
+
+
+def test_generic_route_matches_fused_route(dev):
+    """A custom callable loss goes through model(users, items) + autograd + torch's own
+    SparseAdam.step (inherited); results must agree with the fused kernels."""
+    from collie_amd import loss as L
+    from collie_amd.model import MatrixFactorizationModel
+
+    class Shape:
+        num_users, num_items, num_negative_samples = 120, 90, 4
+
+    rng = np.random.default_rng(2)
+    batches = [((torch.tensor(rng.integers(0, 120, 200), dtype=torch.int32, device=dev),
+                 torch.tensor(rng.integers(0, 90, 200), dtype=torch.int32, device=dev)),
+                torch.tensor(rng.integers(0, 90, (200, 4)), device=dev)) for _ in range(3)]
+    results = []
+    for loss in ('bpr', lambda *a, **k: L.adaptive_bpr_loss(*a, **k)):
+        torch.manual_seed(1)
+        m = MatrixFactorizationModel(train=Shape(), embedding_dim=32, sparse=True, lr=1e-2,
+                                     bias_lr=1e-1, optimizer='sparse_adam', bias_optimizer='sgd',
+                                     loss=loss, lr_scheduler_func=None).to(dev).train()
+        with torch.no_grad():
+            m.user_embeddings.weight.mul_(20.0)
+            m.item_embeddings.weight.mul_(20.0)
+        opts = m.configure_optimizers()
+        losses = [step(m, opts, b).item() for b in batches]
+        results.append((losses, tables_of(m)))
+    close(results[1][0], results[0][0])
+    for n in ('user_embeddings', 'item_embeddings', 'item_biases'):
+        close(results[1][1][n], results[0][1][n], rtol=1e-4)
+
+
+def test_quickstart_ml100k_shape_trains_and_evaluates(dev):
+    """BASELINE configs[0] shape (943 x 1682, D=10, adaptive hinge, dense Adam + SGD bias,
+    ReduceLROnPlateau) through CollieMinimalTrainer + evaluate_in_batches: the loss must fall and
+    MAP@10 on held-out positives must beat the untrained model by a wide margin."""
+    from collie_amd.interactions import Interactions
+    from collie_amd.metrics import evaluate_in_batches, mapk
+    from collie_amd.model import MatrixFactorizationModel
+    from collie_amd.trainer import CollieMinimalTrainer
+    rng = np.random.default_rng(42)
+    U, N, nnz = 943, 1682, 55375
+    # low-rank ground truth so that there is something to learn
+    pu, qi = rng.normal(size=(U, 6)), rng.normal(size=(N, 6))
+    users = rng.integers(0, U, nnz * 3)
+    logits = (pu[users] @ qi.T)
+    items = np.array([rng.choice(N, p=np.exp(l - l.max()) / np.exp(l - l.max()).sum())
+                      for l in logits[:nnz]])
+    users = users[:nnz]
+    mask = rng.random(nnz) < 0.8
+    mk = dict(num_users=U, num_items=N, allow_missing_ids=True, seed=1,
+              check_num_negative_samples_is_valid=False)
+    train = Interactions(users=users[mask], items=items[mask], **mk)
+    test = Interactions(users=users[~mask], items=items[~mask], **mk)
+    torch.manual_seed(0)
+    model = MatrixFactorizationModel(train=train, embedding_dim=10, lr=1e-1, loss='adaptive',
+                                     optimizer='adam')
+    before = evaluate_in_batches([mapk], test, model.to(dev), k=10, verbose=False)
+    trainer = CollieMinimalTrainer(model, max_epochs=4, gpus=1, verbosity=0,
+                                   enable_model_summary=False)
+    trainer.fit(model)
+    assert trainer.num_epochs_completed == 4
+    after = evaluate_in_batches([mapk], test, model, k=10, verbose=False)
+    assert after > 5 * before and after > 0.01, (before, after)
+    # save / load on the device keeps predictions identical (tests/test_model.py:1346-1385)
+    import os
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, 'm.pth')
+        model.save_model(path)
+        loaded = MatrixFactorizationModel(load_model_path=path, map_location='cpu').to(dev)
+        a = model.get_item_predictions(user_id=3, sort_values=False)
+        b = loaded.get_item_predictions(user_id=3, sort_values=False)
+        assert (a.values == b.values).all()
+    with pytest.raises(ValueError, match='is not in the model'):
+        model.get_item_predictions(user_id=U)
+
+
+def test_out_of_range_ids_raise_at_check(dev):
+    from collie_amd.model import MatrixFactorizationModel
+
+    class Shape:
+        num_users, num_items, num_negative_samples = 10, 10, 2
+
+    m = MatrixFactorizationModel(train=Shape(), embedding_dim=8, sparse=True, optimizer='sparse_adam',
+                                 lr_scheduler_func=None).to(dev).train()
+    opts = m.configure_optimizers()
+    batch = ((torch.tensor([1, 50], dtype=torch.int32, device=dev),
+              torch.tensor([2, 3], dtype=torch.int32, device=dev)),
+             torch.tensor([[1, 2], [3, 400]], device=dev))
+    step(m, opts, batch)
+    with pytest.raises(IndexError):
+        m.check_status()
