@@ -68,18 +68,25 @@ SIGNATURES = {
                                                     c_int32, c_void_p, c_void_p, c_void_p,
                                                     c_void_p, c_void_p, c_void_p, c_void_p]),
     'collie_loss_partials': (c_int64, [c_int64]),
-    'collie_mf_train_workspace_bytes': (c_size_t, [c_int64, c_int32, c_int32]),
+    'collie_mf_train_workspace_bytes': (c_size_t, [c_int64, c_int32, c_int32, c_int64, c_int64]),
     'collie_mf_train_forward': (ctypes.c_int, [POINTER(Tables), POINTER(Batch), POINTER(LossCfg),
-                                               c_void_p, c_size_t, c_int32, c_void_p, c_void_p,
-                                               c_void_p, c_void_p, c_void_p]),
+                                               c_void_p, c_size_t, c_int32, c_int32, c_void_p,
+                                               c_void_p, c_void_p, c_void_p, c_void_p]),
     'collie_mf_train_build_segments': (ctypes.c_int, [POINTER(Tables), POINTER(Batch), c_void_p,
-                                                      c_size_t, c_int32, c_void_p]),
+                                                      c_size_t, c_void_p]),
     'collie_mf_train_update': (ctypes.c_int, [POINTER(Tables), POINTER(Batch), c_void_p, c_size_t,
-                                              c_int32, c_int32, c_int32, POINTER(OptimCfg),
-                                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                              c_int32, c_int32, c_int32, c_int32,
+                                              POINTER(OptimCfg), POINTER(c_void_p),
+                                              POINTER(c_void_p), POINTER(c_void_p), c_void_p,
+                                              c_void_p]),
     'collie_mf_train_export_grad': (ctypes.c_int, [POINTER(Tables), POINTER(Batch), c_void_p,
-                                                   c_size_t, c_int32, c_int32, c_void_p, c_void_p,
-                                                   c_void_p, c_void_p]),
+                                                   c_size_t, c_int32, c_int32, c_int32, c_void_p,
+                                                   c_void_p, c_void_p, c_void_p, c_void_p]),
+    'collie_sparse_rows_workspace_bytes': (c_size_t, [c_int64]),
+    'collie_sparse_rows_update': (ctypes.c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int32,
+                                                 c_void_p, c_int64, POINTER(OptimCfg), c_void_p,
+                                                 c_void_p, c_void_p, c_size_t, c_void_p,
+                                                 c_void_p]),
     'collie_mf_eval_topk_capacity': (c_int32, []),
     'collie_mf_eval_workspace_bytes': (c_size_t, [c_int64, c_int64]),
     'collie_mf_eval_topk': (ctypes.c_int, [POINTER(Tables), c_void_p, c_int64, c_int64, c_int64,

@@ -67,6 +67,7 @@ struct FwdParams {
   float* s_neg_out;
   int32_t* status;
   int need_grad;
+  int step_id;
   int nchunks;  // ceil(dim / VEC)
   float inv_b;
 };
@@ -74,9 +75,30 @@ struct FwdParams {
 constexpr int kBlock = 256;
 constexpr int kWavesPerBlock = kBlock / kWave;
 
-template <int VEC, int LPR>
+struct SampleIds {
+  int64_t u;
+  int64_t item64;
+};
+
+__device__ __forceinline__ SampleIds load_ids(const FwdParams& p, int64_t b, int lane, int K) {
+  SampleIds s;
+  s.u = load_idx(p.b.users, p.b.users_dtype, b);
+  s.item64 = 0;
+  if (lane == 0) {
+    s.item64 = load_idx(p.b.pos_items, p.b.pos_dtype, b);
+  } else if (lane <= K) {
+    s.item64 = load_idx(p.b.neg_items, p.b.neg_dtype,
+                        b * p.b.neg_stride_b + static_cast<int64_t>(lane - 1) * p.b.neg_stride_k);
+  }
+  return s;
+}
+
+// NPASS > 0: number of row-gather passes is a compile-time constant (all 1+K item rows of a sample
+// are in flight together and stay in registers); NPASS == 0: generic loop (large K or dim).
+template <int VEC, int LPR, int NPASS>
 __global__ __launch_bounds__(kBlock) void mf_train_fwd_kernel(const FwdParams p) {
   constexpr int RPW = kWave / LPR;  // item rows gathered per wave-instruction
+  constexpr int NP = NPASS > 0 ? NPASS : 1;
   const int lane = lane_id();
   const int wave_in_block = threadIdx.x / kWave;
   const int grp = lane / LPR;
@@ -85,41 +107,34 @@ __global__ __launch_bounds__(kBlock) void mf_train_fwd_kernel(const FwdParams p)
   const int D = p.t.dim;
   const int64_t B = p.b.batch;
   const int npass = (K + 1 + RPW - 1) / RPW;
-  const bool single_chunk = p.nchunks <= LPR;
   const bool my_chunk = lig < p.nchunks;
   const int kind = p.loss.kind;
+  const uint32_t key_off = static_cast<uint32_t>(p.t.num_users);
 
   float loss1 = 0.0f, loss2 = 0.0f;
 
   const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
-  for (int64_t b = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave_in_block; b < B;
-       b += nwaves) {
-    // ---- ids: lane 0 = positive item, lanes 1..K = negatives -------------------------------
-    const int64_t u = load_idx(p.b.users, p.b.users_dtype, b);
-    int64_t item64 = 0;
-    if (lane == 0) {
-      item64 = load_idx(p.b.pos_items, p.b.pos_dtype, b);
-    } else if (lane <= K) {
-      item64 = load_idx(p.b.neg_items, p.b.neg_dtype,
-                        b * p.b.neg_stride_b + static_cast<int64_t>(lane - 1) * p.b.neg_stride_k);
-    }
-    const bool bad_item = lane <= K && (item64 < 0 || item64 >= p.t.num_items);
+  int64_t b = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave_in_block;
+  SampleIds next = {0, 0};
+  if (b < B) next = load_ids(p, b, lane, K);
+  for (; b < B; b += nwaves) {
+    // ---- ids: lane 0 = positive item, lanes 1..K = negatives; prefetch the next sample's ----
+    const SampleIds cur = next;
+    if (b + nwaves < B) next = load_ids(p, b + nwaves, lane, K);
+    const int64_t u = cur.u;
+    const bool bad_item = lane <= K && (cur.item64 < 0 || cur.item64 >= p.t.num_items);
     const bool bad = (u < 0 || u >= p.t.num_users) || (__ballot(bad_item) != 0ull);
     if (bad) {  // wave-uniform: never touch memory through a bad id
-      if (lane == 0) {
-        if (p.status) atomicOr(p.status, 1);
-        if (p.need_grad) {
-          p.ws.gcoef[b] = 0.0f;
-          p.ws.side[COLLIE_SIDE_USER].codes[b] = kCodeNone;
-        }
-      }
-      if (p.need_grad && lane <= K) {
-        const int64_t slot = lane == 0 ? b : B + b * K + (lane - 1);
-        p.ws.side[COLLIE_SIDE_ITEM].codes[slot] = kCodeNone;
+      if (lane == 0 && p.status) atomicOr(p.status, 1);
+      if (p.need_grad && lane < 3) {
+        const int64_t slot = lane == 0 ? b : B + 2 * b + (lane - 1);
+        p.ws.sort.ekeys[slot] = lane == 0 ? 0u : key_off;
+        p.ws.sort.ecodes[slot] = kCodeNone;
+        if (lane == 0) p.ws.gcoef[b] = 0.0f;
       }
       continue;
     }
-    const int item = static_cast<int>(item64);
+    const int item = static_cast<int>(cur.item64);
 
     const float ub = p.t.user_bias[u];
     const float ib = lane <= K ? p.t.item_bias[item] : 0.0f;
@@ -128,28 +143,36 @@ __global__ __launch_bounds__(kBlock) void mf_train_fwd_kernel(const FwdParams p)
     // ---- 1+K dot products; lane j ends up with dot_j ---------------------------------------
     float mydot = 0.0f;
     Vec<VEC> uvec = vzero<VEC>();
-    Vec<VEC> ipos = vzero<VEC>();
-    if (single_chunk && my_chunk) uvec = vload<VEC>(urow + lig * VEC);
-    for (int pass = 0; pass < npass; ++pass) {
-      const int j = pass * RPW + grp;
-      const int it = __shfl(item, j <= K ? j : K, kWave);
-      const float* irow = p.t.item_emb + static_cast<int64_t>(it) * D;
-      float part = 0.0f;
-      if (j <= K) {
-        if (single_chunk) {
-          if (my_chunk) {
-            const Vec<VEC> iv = vload<VEC>(irow + lig * VEC);
-            part = vdot<VEC>(uvec, iv);
-            if (pass == 0) ipos = iv;  // group 0 keeps the positive row for the backward stage
-          }
-        } else {
+    Vec<VEC> iv[NP];
+    if (NPASS > 0) {
+      if (my_chunk) uvec = vload<VEC>(urow + lig * VEC);
+#pragma unroll
+      for (int pass = 0; pass < NP; ++pass) {
+        const int j = pass * RPW + grp;
+        const int it = __shfl(item, j <= K ? j : K, kWave);
+        iv[pass] = vzero<VEC>();
+        if (j <= K && my_chunk)
+          iv[pass] = vload<VEC>(p.t.item_emb + static_cast<int64_t>(it) * D + lig * VEC);
+      }
+#pragma unroll
+      for (int pass = 0; pass < NP; ++pass) {
+        const float part = group_sum<LPR>(vdot<VEC>(uvec, iv[pass]));
+        const float got = __shfl(part, (lane % RPW) * LPR, kWave);
+        if (lane / RPW == pass) mydot = got;
+      }
+    } else {
+      for (int pass = 0; pass < npass; ++pass) {
+        const int j = pass * RPW + grp;
+        const int it = __shfl(item, j <= K ? j : K, kWave);
+        const float* irow = p.t.item_emb + static_cast<int64_t>(it) * D;
+        float part = 0.0f;
+        if (j <= K)
           for (int c = lig; c < p.nchunks; c += LPR)
             part += vdot<VEC>(vload<VEC>(urow + c * VEC), vload<VEC>(irow + c * VEC));
-        }
+        part = group_sum<LPR>(part);
+        const float got = __shfl(part, (lane % RPW) * LPR, kWave);
+        if (lane / RPW == pass) mydot = got;
       }
-      part = group_sum<LPR>(part);
-      const float got = __shfl(part, (lane % RPW) * LPR, kWave);
-      if (lane / RPW == pass) mydot = got;
     }
     const float s = (mydot + ub) + ib;  // matrix_factorization.py:146-150
 
@@ -208,49 +231,59 @@ __global__ __launch_bounds__(kBlock) void mf_train_fwd_kernel(const FwdParams p)
     if (!p.need_grad) continue;
 
     // ---- backward staging ---------------------------------------------------------------------
+    // Every looked-up item is stamped as touched (SparseAdam also moves zero-gradient rows); only
+    // the user, the positive and the selected negative become sort entries.
     const bool live = g != 0.0f;
-    if (lane == 0) {
-      p.ws.gcoef[b] = g;
-      p.ws.side[COLLIE_SIDE_USER].codes[b] = live ? static_cast<uint32_t>(b) : kCodeNone;
-      p.ws.side[COLLIE_SIDE_ITEM].codes[b] = live ? static_cast<uint32_t>(b) : kCodeNone;
-    } else if (isneg) {
-      p.ws.side[COLLIE_SIDE_ITEM].codes[B + b * K + (lane - 1)] =
-          (live && lane == sel) ? (static_cast<uint32_t>(b) | kCodeNeg) : kCodeNone;
-    }
-    // shuffles read only from active lanes: take the ids before the divergent region
     const int sel_item = __shfl(item, sel, kWave);
     const int pos_item_b = __shfl(item, 0, kWave);
-    if (live && grp == 0) {
+    if (lane <= K) p.ws.touch_item[item] = p.step_id;
+    if (lane < 3) {  // lane 0: user entry, lane 1: positive item, lane 2: selected negative
+      const int64_t slot = lane == 0 ? b : B + 2 * b + (lane - 1);
+      const uint32_t key =
+          lane == 0 ? static_cast<uint32_t>(u)
+                    : key_off + static_cast<uint32_t>(lane == 1 ? pos_item_b : sel_item);
+      p.ws.sort.ekeys[slot] = key;
+      p.ws.sort.ecodes[slot] =
+          live ? (static_cast<uint32_t>(b) | (lane == 2 ? kCodeNeg : 0u)) : kCodeNone;
+      if (lane == 0) p.ws.gcoef[b] = g;
+    }
+    if (!live) continue;
+    float* su = p.ws.stage_u + b * D;
+    float* si = p.ws.stage_i + b * D;
+    if (NPASS > 0) {
+      // the selected negative's row is already in registers: pass sel / RPW, lane group sel % RPW
+      Vec<VEC> pick = iv[0];
+#pragma unroll
+      for (int pass = 1; pass < NP; ++pass)
+        if (sel / RPW == pass) pick = iv[pass];
+      Vec<VEC> isel;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) isel.v[i] = __shfl(pick.v[i], (sel % RPW) * LPR + lig, kWave);
+      if (grp == 0 && my_chunk) {
+        Vec<VEC> gu, gi;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          gu.v[i] = g * iv[0].v[i] - g * isel.v[i];
+          gi.v[i] = g * uvec.v[i];
+        }
+        vstore<VEC>(su + lig * VEC, gu);
+        vstore<VEC>(si + lig * VEC, gi);
+      }
+    } else if (grp == 0) {
+      const float* prow = p.t.item_emb + static_cast<int64_t>(pos_item_b) * D;
       const float* srow = p.t.item_emb + static_cast<int64_t>(sel_item) * D;
-      float* su = p.ws.stage_u + b * D;
-      float* si = p.ws.stage_i + b * D;
-      if (single_chunk) {
-        if (my_chunk) {
-          const Vec<VEC> isel = vload<VEC>(srow + lig * VEC);
-          Vec<VEC> gu, gi;
+      for (int cidx = lig; cidx < p.nchunks; cidx += LPR) {
+        const Vec<VEC> a = vload<VEC>(prow + cidx * VEC);
+        const Vec<VEC> n = vload<VEC>(srow + cidx * VEC);
+        const Vec<VEC> uu = vload<VEC>(urow + cidx * VEC);
+        Vec<VEC> gu, gi;
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) {
-            gu.v[i] = g * ipos.v[i] - g * isel.v[i];
-            gi.v[i] = g * uvec.v[i];
-          }
-          vstore<VEC>(su + lig * VEC, gu);
-          vstore<VEC>(si + lig * VEC, gi);
+        for (int i = 0; i < VEC; ++i) {
+          gu.v[i] = g * a.v[i] - g * n.v[i];
+          gi.v[i] = g * uu.v[i];
         }
-      } else {
-        const float* prow = p.t.item_emb + static_cast<int64_t>(pos_item_b) * D;
-        for (int cidx = lig; cidx < p.nchunks; cidx += LPR) {
-          const Vec<VEC> a = vload<VEC>(prow + cidx * VEC);
-          const Vec<VEC> n = vload<VEC>(srow + cidx * VEC);
-          const Vec<VEC> uu = vload<VEC>(urow + cidx * VEC);
-          Vec<VEC> gu, gi;
-#pragma unroll
-          for (int i = 0; i < VEC; ++i) {
-            gu.v[i] = g * a.v[i] - g * n.v[i];
-            gi.v[i] = g * uu.v[i];
-          }
-          vstore<VEC>(su + cidx * VEC, gu);
-          vstore<VEC>(si + cidx * VEC, gi);
-        }
+        vstore<VEC>(su + cidx * VEC, gu);
+        vstore<VEC>(si + cidx * VEC, gi);
       }
     }
   }
@@ -273,11 +306,12 @@ __global__ __launch_bounds__(kBlock) void mf_train_fwd_kernel(const FwdParams p)
   }
 }
 
-// loss = (sum l + sum l^2) / B   (bpr.py:89, hinge.py:85, warp.py:133)
-__global__ __launch_bounds__(kWave) void loss_finalize_kernel(const float* partials, int nblocks,
-                                                              float inv_b, float* loss_out) {
+// loss = (sum l + sum l^2) / B   (bpr.py:89, hinge.py:85, warp.py:133); fixed-order reduction
+__global__ __launch_bounds__(kBlock) void loss_finalize_kernel(const float* partials, int nblocks,
+                                                               float inv_b, float* loss_out) {
+  __shared__ double sh[2][kWavesPerBlock];
   double a = 0.0, c = 0.0;
-  for (int i = threadIdx.x; i < nblocks; i += kWave) {
+  for (int i = threadIdx.x; i < nblocks; i += kBlock) {
     a += partials[2 * i];
     c += partials[2 * i + 1];
   }
@@ -285,21 +319,44 @@ __global__ __launch_bounds__(kWave) void loss_finalize_kernel(const float* parti
     a += __shfl_xor(a, o, kWave);
     c += __shfl_xor(c, o, kWave);
   }
-  if (threadIdx.x == 0) *loss_out = static_cast<float>((a + c) * static_cast<double>(inv_b));
+  if (lane_id() == 0) {
+    sh[0][threadIdx.x / kWave] = a;
+    sh[1][threadIdx.x / kWave] = c;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double ta = 0.0, tc = 0.0;
+    for (int w = 0; w < kWavesPerBlock; ++w) {
+      ta += sh[0][w];
+      tc += sh[1][w];
+    }
+    *loss_out = static_cast<float>((ta + tc) * static_cast<double>(inv_b));
+  }
+}
+
+template <int VEC, int LPR>
+int launch_fwd_np(int np, dim3 grid, hipStream_t stream, const FwdParams& p) {
+  switch (np) {
+    case 1: hipLaunchKernelGGL((mf_train_fwd_kernel<VEC, LPR, 1>), grid, dim3(kBlock), 0, stream, p); break;
+    case 2: hipLaunchKernelGGL((mf_train_fwd_kernel<VEC, LPR, 2>), grid, dim3(kBlock), 0, stream, p); break;
+    case 3: hipLaunchKernelGGL((mf_train_fwd_kernel<VEC, LPR, 3>), grid, dim3(kBlock), 0, stream, p); break;
+    case 4: hipLaunchKernelGGL((mf_train_fwd_kernel<VEC, LPR, 4>), grid, dim3(kBlock), 0, stream, p); break;
+    default: hipLaunchKernelGGL((mf_train_fwd_kernel<VEC, LPR, 0>), grid, dim3(kBlock), 0, stream, p); break;
+  }
+  return check_launch("mf_train_fwd_kernel");
 }
 
 template <int VEC>
-int launch_fwd(int lpr, dim3 grid, hipStream_t stream, const FwdParams& p) {
+int launch_fwd(int lpr, int np, dim3 grid, hipStream_t stream, const FwdParams& p) {
   switch (lpr) {
-    case 1: hipLaunchKernelGGL((mf_train_fwd_kernel<VEC, 1>), grid, dim3(kBlock), 0, stream, p); break;
-    case 2: hipLaunchKernelGGL((mf_train_fwd_kernel<VEC, 2>), grid, dim3(kBlock), 0, stream, p); break;
-    case 4: hipLaunchKernelGGL((mf_train_fwd_kernel<VEC, 4>), grid, dim3(kBlock), 0, stream, p); break;
-    case 8: hipLaunchKernelGGL((mf_train_fwd_kernel<VEC, 8>), grid, dim3(kBlock), 0, stream, p); break;
-    case 16: hipLaunchKernelGGL((mf_train_fwd_kernel<VEC, 16>), grid, dim3(kBlock), 0, stream, p); break;
-    case 32: hipLaunchKernelGGL((mf_train_fwd_kernel<VEC, 32>), grid, dim3(kBlock), 0, stream, p); break;
-    default: hipLaunchKernelGGL((mf_train_fwd_kernel<VEC, 64>), grid, dim3(kBlock), 0, stream, p); break;
+    case 1: return launch_fwd_np<VEC, 1>(np, grid, stream, p);
+    case 2: return launch_fwd_np<VEC, 2>(np, grid, stream, p);
+    case 4: return launch_fwd_np<VEC, 4>(np, grid, stream, p);
+    case 8: return launch_fwd_np<VEC, 8>(np, grid, stream, p);
+    case 16: return launch_fwd_np<VEC, 16>(np, grid, stream, p);
+    case 32: return launch_fwd_np<VEC, 32>(np, grid, stream, p);
+    default: return launch_fwd_np<VEC, 64>(np, grid, stream, p);
   }
-  return check_launch("mf_train_fwd_kernel");
 }
 
 }  // namespace
@@ -339,16 +396,17 @@ int pick_vec(const collie_mf_tables* t) {
 
 using namespace collie;
 
-extern "C" size_t collie_mf_train_workspace_bytes(int64_t batch, int32_t num_neg, int32_t dim) {
-  if (batch < 1 || num_neg < 1 || dim < 1) return 0;
-  return carve_train_ws(nullptr, batch, num_neg, dim).bytes;
+extern "C" size_t collie_mf_train_workspace_bytes(int64_t batch, int32_t num_neg, int32_t dim,
+                                                  int64_t num_users, int64_t num_items) {
+  if (batch < 1 || num_neg < 1 || dim < 1 || num_users < 1 || num_items < 1) return 0;
+  return carve_train_ws(nullptr, batch, num_neg, dim, num_users, num_items).bytes;
 }
 
 extern "C" int collie_mf_train_forward(const collie_mf_tables* t, const collie_mf_batch* b,
                                        const collie_loss_cfg* loss, void* workspace,
-                                       size_t workspace_bytes, int32_t need_grad, float* loss_out,
-                                       float* s_pos_out, float* s_neg_out, int32_t* status,
-                                       collie_stream_t stream_) {
+                                       size_t workspace_bytes, int32_t need_grad, int32_t step_id,
+                                       float* loss_out, float* s_pos_out, float* s_neg_out,
+                                       int32_t* status, collie_stream_t stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   if (validate_tables(t) || validate_batch(b)) return -1;
   COLLIE_REQUIRE(loss != nullptr && loss_out != nullptr, "loss cfg / loss_out is NULL");
@@ -360,14 +418,10 @@ extern "C" int collie_mf_train_forward(const collie_mf_tables* t, const collie_m
     COLLIE_REQUIRE(b->num_neg == 1, "non-adaptive losses need exactly one negative per sample");
   if (loss->kind == COLLIE_LOSS_WARP)
     COLLIE_REQUIRE(b->num_neg > 1, "Cannot use WARP loss with a single negative sample!");
-  TrainWs ws = carve_train_ws(workspace, b->batch, b->num_neg, t->dim);
-  if (need_grad) {
-    COLLIE_REQUIRE(workspace != nullptr && workspace_bytes >= ws.bytes,
-                   "workspace too small: need %zu bytes, got %zu", ws.bytes, workspace_bytes);
-  } else if (workspace == nullptr || workspace_bytes < ws.bytes) {
-    COLLIE_REQUIRE(false, "workspace too small: need %zu bytes, got %zu", ws.bytes,
-                   workspace_bytes);
-  }
+  COLLIE_REQUIRE(step_id >= 1, "step_id must be >= 1 (got %d)", step_id);
+  TrainWs ws = carve_train_ws(workspace, b->batch, b->num_neg, t->dim, t->num_users, t->num_items);
+  COLLIE_REQUIRE(workspace != nullptr && workspace_bytes >= ws.bytes,
+                 "workspace too small: need %zu bytes, got %zu", ws.bytes, workspace_bytes);
 
   FwdParams p;
   p.t = *t;
@@ -378,21 +432,25 @@ extern "C" int collie_mf_train_forward(const collie_mf_tables* t, const collie_m
   p.s_neg_out = s_neg_out;
   p.status = status;
   p.need_grad = need_grad;
+  p.step_id = step_id;
   p.inv_b = 1.0f / static_cast<float>(b->batch);
   const int vec = pick_vec(t);
   p.nchunks = (t->dim + vec - 1) / vec;
   int lpr = 1;
   while (lpr < p.nchunks && lpr < kWave) lpr *= 2;
+  const int rpw = kWave / lpr;
+  int np = (b->num_neg + 1 + rpw - 1) / rpw;
+  if (p.nchunks > lpr || np > 4) np = 0;  // generic loop
 
   int64_t nblocks = (b->batch + kWavesPerBlock - 1) / kWavesPerBlock;
   if (nblocks > kMaxLossBlocks) nblocks = kMaxLossBlocks;
   dim3 grid(static_cast<unsigned>(nblocks));
   int rc;
-  if (vec == 4) rc = launch_fwd<4>(lpr, grid, stream, p);
-  else if (vec == 2) rc = launch_fwd<2>(lpr, grid, stream, p);
-  else rc = launch_fwd<1>(lpr, grid, stream, p);
+  if (vec == 4) rc = launch_fwd<4>(lpr, np, grid, stream, p);
+  else if (vec == 2) rc = launch_fwd<2>(lpr, np, grid, stream, p);
+  else rc = launch_fwd<1>(lpr, np, grid, stream, p);
   if (rc) return rc;
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(kWave), 0, stream, ws.loss_partials,
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(kBlock), 0, stream, ws.loss_partials,
                      static_cast<int>(nblocks), p.inv_b, loss_out);
   return check_launch("loss_finalize_kernel");
 }

@@ -11,7 +11,7 @@
 // and moves the parameter exactly as torch does after coalesce().
 //
 // Compiled with -ffp-contract=off so that every rounding step of the torch formulas is kept.
-#include "train_ws.h"
+#include "rowsort.h"
 
 namespace collie {
 namespace {
@@ -65,12 +65,19 @@ __device__ __forceinline__ float apply_update(const Hyper& h, float p, float g, 
   }
 }
 
-struct UpdParams {
-  float* table;      // [rows, D] (D = 1 for a bias table)
+struct TableDesc {
+  float* table;        // [rows, D] (D = 1 for a bias table); NULL = not owned by this call
   float* s1;
   float* s2;
-  int32_t* stamp;    // dense algorithms: stamp[row] = step for touched rows (else NULL)
-  const float* stage;  // [B, D] staged rows (embedding) | gcoef [B] (bias)
+  int32_t* row_stamp;  // dense algorithms: row_stamp[row] = step for rows that had a segment
+  int32_t* seg_stamp;  // sparse item side: seg_stamp[row] = step for rows that had a segment
+  const float* stage;  // [*, D] staged rows (embedding) | gcoef [*] (bias) | NULL = zero gradient
+  Hyper h;
+};
+
+struct UpdParams {
+  TableDesc d[2];      // [0]: keys < split, [1]: keys >= split (row = key - split)
+  uint32_t split;
   const uint32_t* keys;
   const uint32_t* vals;
   const uint32_t* seg_start;
@@ -79,99 +86,116 @@ struct UpdParams {
   int64_t* rows_out;   // export mode
   float* vals_out;
   int32_t* count_out;
+  int export_side;
   int D;
   int step;
-  int user_bias;       // user-bias table: the gradient is identically zero (see below)
-  Hyper h;
 };
 
-// EXPORT = true writes the coalesced gradient instead of updating the table.
+// EXPORT = true writes the coalesced gradient of one side instead of updating the tables.
 template <bool EXPORT>
 __global__ __launch_bounds__(kBlock) void emb_rows_kernel(const UpdParams p) {
   const int lane = lane_id();
-  const uint32_t nseg = *p.nseg;
+  const uint32_t nseg = p.nseg[0];
+  const uint32_t first1 = p.nseg[1];
   const float scale = p.grad_scale ? *p.grad_scale : 1.0f;
   const int D = p.D;
   const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
-  if (EXPORT && blockIdx.x == 0 && threadIdx.x == 0) *p.count_out = static_cast<int32_t>(nseg);
+  if (EXPORT && blockIdx.x == 0 && threadIdx.x == 0)
+    *p.count_out = static_cast<int32_t>(p.export_side ? nseg - first1 : first1);
   for (int64_t seg = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + threadIdx.x / kWave;
        seg < nseg; seg += nwaves) {
     const uint32_t start = p.seg_start[seg];
     const uint32_t end = p.seg_start[seg + 1];
-    const int64_t row = p.keys[start];
-    if (EXPORT && lane == 0) p.rows_out[seg] = row;
+    const uint32_t key = p.keys[start];
+    const int side = key >= p.split ? 1 : 0;
+    const TableDesc& t = p.d[side];
+    if (EXPORT ? side != p.export_side : t.table == nullptr) continue;
+    const int64_t row = side ? key - p.split : key;
+    const int64_t oseg = EXPORT ? (side ? seg - first1 : seg) : 0;
+    if (EXPORT && lane == 0) p.rows_out[oseg] = row;
     for (int d0 = 0; d0 < D; d0 += kWave) {
       const int d = d0 + lane;
       const bool on = d < D;
       float pv = 0.0f, s1 = 0.0f, s2 = 0.0f;
       if (!EXPORT && on) {
-        pv = p.table[row * D + d];
-        if (p.s1) s1 = p.s1[row * D + d];
-        if (p.s2) s2 = p.s2[row * D + d];
+        pv = t.table[row * D + d];
+        if (t.s1) s1 = t.s1[row * D + d];
+        if (t.s2) s2 = t.s2[row * D + d];
       }
       float acc = 0.0f;
-      for (uint32_t e0 = start; e0 < end; e0 += kWave) {
-        const uint32_t code = (e0 + lane < end) ? p.vals[e0 + lane] : kCodeNone;
-        unsigned long long live = __ballot(code != kCodeNone);
-        while (live) {
-          // up to four staged rows in flight, added in batch order
-          float x[4];
-          float sg[4];
-          int n = 0;
+      if (t.stage) {
+        for (uint32_t e0 = start; e0 < end; e0 += kWave) {
+          const uint32_t code = (e0 + lane < end) ? p.vals[e0 + lane] : kCodeNone;
+          unsigned long long live = __ballot(code != kCodeNone);
+          while (live) {
+            // up to four staged rows in flight, added in batch order
+            float x[4];
+            float sg[4];
+            int n = 0;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            x[q] = 0.0f;
-            sg[q] = 0.0f;
-            if (live) {
-              const int l = __ffsll(static_cast<long long>(live)) - 1;
-              live &= live - 1;
-              const uint32_t c = __shfl(code, l, kWave);
-              sg[q] = (c & kCodeNeg) ? -1.0f : 1.0f;
-              if (on) x[q] = p.stage[static_cast<int64_t>(c & kCodeMask) * D + d];
-              ++n;
+            for (int q = 0; q < 4; ++q) {
+              x[q] = 0.0f;
+              sg[q] = 0.0f;
+              if (live) {
+                const int l = __ffsll(static_cast<long long>(live)) - 1;
+                live &= live - 1;
+                const uint32_t c = __shfl(code, l, kWave);
+                sg[q] = (c & kCodeNeg) ? -1.0f : 1.0f;
+                if (on) x[q] = t.stage[static_cast<int64_t>(c & kCodeMask) * D + d];
+                ++n;
+              }
             }
-          }
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
-            if (q < n) acc += sg[q] * x[q];
+            for (int q = 0; q < 4; ++q)
+              if (q < n) acc += sg[q] * x[q];
+          }
         }
       }
       const float g = acc * scale;
       if (EXPORT) {
-        if (on) p.vals_out[seg * D + d] = g;
+        if (on) p.vals_out[oseg * D + d] = g;
       } else if (on) {
-        const float np = apply_update(p.h, pv, g, s1, s2);
-        p.table[row * D + d] = np;
-        if (p.s1) p.s1[row * D + d] = s1;
-        if (p.s2) p.s2[row * D + d] = s2;
+        const float np = apply_update(t.h, pv, g, s1, s2);
+        t.table[row * D + d] = np;
+        if (t.s1) t.s1[row * D + d] = s1;
+        if (t.s2) t.s2[row * D + d] = s2;
       }
     }
-    if (!EXPORT && p.stamp && lane == 0) p.stamp[row] = p.step;
+    if (!EXPORT && lane == 0) {
+      if (t.row_stamp) t.row_stamp[row] = p.step;
+      if (t.seg_stamp) t.seg_stamp[row] = p.step;
+    }
   }
 }
 
 // bias tables: one wave per segment, lanes stride the segment, fixed-shape butterfly sum.
 // d loss / d user_bias is identically zero for every pairwise loss (the user bias cancels in
 // s+ - s-); the reference's value is only the fp32 residue of (+g) + (-g) in coalesce order, so
-// the user-bias gradient is produced as an exact 0 (the row is still "touched").
+// the user-bias gradient is produced as an exact 0 (stage == NULL; the row is still "touched").
 template <bool EXPORT>
 __global__ __launch_bounds__(kBlock) void bias_rows_kernel(const UpdParams p) {
   const int lane = lane_id();
-  const uint32_t nseg = *p.nseg;
+  const uint32_t nseg = p.nseg[0];
+  const uint32_t first1 = p.nseg[1];
   const float scale = p.grad_scale ? *p.grad_scale : 1.0f;
   const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
-  if (EXPORT && blockIdx.x == 0 && threadIdx.x == 0) *p.count_out = static_cast<int32_t>(nseg);
+  if (EXPORT && blockIdx.x == 0 && threadIdx.x == 0)
+    *p.count_out = static_cast<int32_t>(p.export_side ? nseg - first1 : first1);
   for (int64_t seg = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + threadIdx.x / kWave;
        seg < nseg; seg += nwaves) {
     const uint32_t start = p.seg_start[seg];
     const uint32_t end = p.seg_start[seg + 1];
-    const int64_t row = p.keys[start];
+    const uint32_t key = p.keys[start];
+    const int side = key >= p.split ? 1 : 0;
+    const TableDesc& t = p.d[side];
+    if (EXPORT ? side != p.export_side : t.table == nullptr) continue;
+    const int64_t row = side ? key - p.split : key;
     float acc = 0.0f;
-    if (!p.user_bias) {
+    if (t.stage) {
       for (uint32_t e = start + lane; e < end; e += kWave) {
         const uint32_t c = p.vals[e];
         if (c != kCodeNone) {
-          const float gv = p.stage[c & kCodeMask];
+          const float gv = t.stage[c & kCodeMask];
           acc += (c & kCodeNeg) ? -gv : gv;
         }
       }
@@ -180,21 +204,23 @@ __global__ __launch_bounds__(kBlock) void bias_rows_kernel(const UpdParams p) {
     const float g = acc * scale;
     if (lane == 0) {
       if (EXPORT) {
-        p.rows_out[seg] = row;
-        p.vals_out[seg] = g;
+        const int64_t oseg = side ? seg - first1 : seg;
+        p.rows_out[oseg] = row;
+        p.vals_out[oseg] = g;
       } else {
-        float s1 = p.s1 ? p.s1[row] : 0.0f;
-        float s2 = p.s2 ? p.s2[row] : 0.0f;
-        p.table[row] = apply_update(p.h, p.table[row], g, s1, s2);
-        if (p.s1) p.s1[row] = s1;
-        if (p.s2) p.s2[row] = s2;
-        if (p.stamp) p.stamp[row] = p.step;
+        float s1 = t.s1 ? t.s1[row] : 0.0f;
+        float s2 = t.s2 ? t.s2[row] : 0.0f;
+        t.table[row] = apply_update(t.h, t.table[row], g, s1, s2);
+        if (t.s1) t.s1[row] = s1;
+        if (t.s2) t.s2[row] = s2;
+        if (t.row_stamp) t.row_stamp[row] = p.step;
+        if (t.seg_stamp) t.seg_stamp[row] = p.step;
       }
     }
   }
 }
 
-// K5: dense optimizers also move every row that was NOT looked up this step (gradient 0, plus
+// K5: dense optimizers also move every row that had NO segment this step (gradient 0, plus
 // weight decay): Adam decays m, v and keeps stepping along m.
 __global__ __launch_bounds__(kBlock) void dense_sweep_kernel(float* __restrict__ table,
                                                              float* __restrict__ s1p,
@@ -216,6 +242,56 @@ __global__ __launch_bounds__(kBlock) void dense_sweep_kernel(float* __restrict__
   }
 }
 
+// SparseAdam "touched" semantics for the items that were looked up (stamped by the forward
+// kernel) but carry no gradient entry: their moments decay and the parameter moves along m.
+__global__ __launch_bounds__(kBlock) void touched_sweep_kernel(float* __restrict__ table,
+                                                               float* __restrict__ s1p,
+                                                               float* __restrict__ s2p,
+                                                               const int32_t* __restrict__ touch,
+                                                               const int32_t* __restrict__ seg,
+                                                               int64_t rows, int D, int step,
+                                                               const Hyper h) {
+  const int64_t total = rows * D;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < total;
+       i += stride) {
+    const int64_t row = i / D;
+    if (touch[row] != step || seg[row] == step) continue;
+    float s1 = s1p[i];
+    float s2 = s2p[i];
+    table[i] = apply_update(h, table[i], 0.0f, s1, s2);
+    s1p[i] = s1;
+    s2p[i] = s2;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void export_touched_kernel(const int32_t* __restrict__ touch,
+                                                                int64_t rows, int step,
+                                                                uint8_t* __restrict__ out) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i < rows) out[i] = touch[i] == step ? 1 : 0;
+}
+
+// entries of a stand-alone sparse gradient: key = row id (clamped), code = position in vals
+__global__ __launch_bounds__(kBlock) void coo_entries_kernel(const void* __restrict__ rows,
+                                                             int dtype, int64_t m,
+                                                             int64_t num_rows,
+                                                             uint32_t* __restrict__ ekeys,
+                                                             uint32_t* __restrict__ ecodes,
+                                                             int32_t* __restrict__ status) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= m) return;
+  int64_t r = load_idx(rows, dtype, i);
+  uint32_t code = static_cast<uint32_t>(i);
+  if (r < 0 || r >= num_rows) {
+    if (status) atomicOr(status, 1);
+    r = 0;
+    code = kCodeNone;
+  }
+  ekeys[i] = static_cast<uint32_t>(r);
+  ecodes[i] = code;
+}
+
 }  // namespace
 
 int validate_tables(const collie_mf_tables* t);
@@ -223,58 +299,9 @@ int validate_batch(const collie_mf_batch* b);
 
 namespace {
 
-int fill_common(UpdParams& p, const collie_mf_tables* t, const collie_mf_batch* b, void* workspace,
-                size_t workspace_bytes, int side, int is_bias) {
-  if (validate_tables(t) || validate_batch(b)) return -1;
-  COLLIE_REQUIRE(side == COLLIE_SIDE_USER || side == COLLIE_SIDE_ITEM, "bad side %d", side);
-  TrainWs ws = carve_train_ws(workspace, b->batch, b->num_neg, t->dim);
-  COLLIE_REQUIRE(workspace != nullptr && workspace_bytes >= ws.bytes,
-                 "workspace too small: need %zu bytes, got %zu", ws.bytes, workspace_bytes);
-  const SideWs& sw = ws.side[side];
-  const int64_t rows = side == COLLIE_SIDE_USER ? t->num_users : t->num_items;
-  const int fin = (radix_passes(rows) - 1) & 1;
-  memset(&p, 0, sizeof(p));
-  p.keys = sw.keys[fin];
-  p.vals = sw.vals[fin];
-  p.seg_start = sw.seg_start;
-  p.nseg = sw.nseg;
-  if (is_bias) {
-    p.table = side == COLLIE_SIDE_USER ? t->user_bias : t->item_bias;
-    p.stage = ws.gcoef;
-    p.D = 1;
-    p.user_bias = side == COLLIE_SIDE_USER;
-  } else {
-    p.table = side == COLLIE_SIDE_USER ? t->user_emb : t->item_emb;
-    p.stage = side == COLLIE_SIDE_USER ? ws.stage_u : ws.stage_i;
-    p.D = t->dim;
-  }
-  return 0;
-}
-
-unsigned grid_for(int64_t ids) {
-  int64_t blocks = (ids + kWavesPerBlock - 1) / kWavesPerBlock;
-  if (blocks > kUpdateBlocks) blocks = kUpdateBlocks;
-  if (blocks < 1) blocks = 1;
-  return static_cast<unsigned>(blocks);
-}
-
-}  // namespace
-}  // namespace collie
-
-using namespace collie;
-
-extern "C" int collie_mf_train_update(const collie_mf_tables* t, const collie_mf_batch* b,
-                                      void* workspace, size_t workspace_bytes, int32_t side,
-                                      int32_t is_bias, int32_t dense,
-                                      const collie_optim_cfg* cfg, float* state1, float* state2,
-                                      int32_t* row_stamp, const float* grad_scale,
-                                      collie_stream_t stream_) {
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
-  UpdParams p;
-  if (fill_common(p, t, b, workspace, workspace_bytes, side, is_bias)) return -1;
-  COLLIE_REQUIRE(cfg != nullptr, "optimizer cfg is NULL");
+int make_hyper(Hyper& h, const collie_optim_cfg* cfg, int dense, bool need_s1, float* s1,
+               float* s2) {
   COLLIE_REQUIRE(cfg->step >= 1, "optimizer step must be >= 1 (got %d)", cfg->step);
-  Hyper& h = p.h;
   h.algo = cfg->algo;
   h.dense = dense ? 1 : 0;
   h.eps = cfg->eps;
@@ -284,26 +311,29 @@ extern "C" int collie_mf_train_update(const collie_mf_tables* t, const collie_mf
   h.c2 = static_cast<float>(1.0 - static_cast<double>(cfg->beta2));
   h.bc2_sqrt = 1.0f;
   const double lr = cfg->lr;
-  int32_t* stamp = nullptr;
+  (void)need_s1;
   switch (cfg->algo) {
     case COLLIE_OPT_SGD:
       h.neg_lr = static_cast<float>(-lr);
       break;
     case COLLIE_OPT_ADAGRAD:
-      COLLIE_REQUIRE(state1 != nullptr, "Adagrad needs state1 = state_sum");
-      h.neg_lr = static_cast<float>(-(lr / (1.0 + (cfg->step - 1) * static_cast<double>(cfg->lr_decay))));
+      COLLIE_REQUIRE(s1 != nullptr, "Adagrad needs state1 = state_sum");
+      h.neg_lr = static_cast<float>(
+          -(lr / (1.0 + (cfg->step - 1) * static_cast<double>(cfg->lr_decay))));
       break;
     case COLLIE_OPT_SPARSE_ADAM: {
-      COLLIE_REQUIRE(!dense, "SparseAdam does not support dense gradients, please consider Adam instead");
-      COLLIE_REQUIRE(state1 && state2, "SparseAdam needs state1 = exp_avg, state2 = exp_avg_sq");
+      COLLIE_REQUIRE(!dense,
+                     "SparseAdam does not support dense gradients, please consider Adam instead");
+      COLLIE_REQUIRE(s1 && s2, "SparseAdam needs state1 = exp_avg, state2 = exp_avg_sq");
       const double bc1 = 1.0 - pow(static_cast<double>(cfg->beta1), cfg->step);
       const double bc2 = 1.0 - pow(static_cast<double>(cfg->beta2), cfg->step);
       h.neg_lr = static_cast<float>(-(lr * sqrt(bc2) / bc1));
       break;
     }
     case COLLIE_OPT_ADAM: {
-      COLLIE_REQUIRE(dense, "Adam does not support sparse gradients, please consider SparseAdam instead");
-      COLLIE_REQUIRE(state1 && state2, "Adam needs state1 = exp_avg, state2 = exp_avg_sq");
+      COLLIE_REQUIRE(dense,
+                     "Adam does not support sparse gradients, please consider SparseAdam instead");
+      COLLIE_REQUIRE(s1 && s2, "Adam needs state1 = exp_avg, state2 = exp_avg_sq");
       const double bc1 = 1.0 - pow(static_cast<double>(cfg->beta1), cfg->step);
       const double bc2 = 1.0 - pow(static_cast<double>(cfg->beta2), cfg->step);
       h.neg_lr = static_cast<float>(-(lr / bc1));
@@ -316,54 +346,193 @@ extern "C" int collie_mf_train_update(const collie_mf_tables* t, const collie_mf
   if (!dense)
     COLLIE_REQUIRE(cfg->weight_decay == 0.0f,
                    "weight_decay option is not compatible with sparse gradients");
-  p.s1 = state1;
-  p.s2 = state2;
-  p.grad_scale = grad_scale;
-  p.step = cfg->step;
+  return 0;
+}
 
-  // dense algorithms whose zero-gradient update is not the identity need the untouched-row sweep
-  const bool sweep = dense && (cfg->algo == COLLIE_OPT_ADAM || cfg->weight_decay != 0.0f);
-  const int64_t rows = side == COLLIE_SIDE_USER ? t->num_users : t->num_items;
-  if (sweep) {
-    COLLIE_REQUIRE(row_stamp != nullptr,
-                   "dense Adam / weight decay need row_stamp = int32[rows] scratch");
-    stamp = row_stamp;
-    p.stamp = stamp;
+unsigned grid_for(int64_t ids) {
+  int64_t blocks = (ids + kWavesPerBlock - 1) / kWavesPerBlock;
+  if (blocks > kUpdateBlocks) blocks = kUpdateBlocks;
+  if (blocks < 1) blocks = 1;
+  return static_cast<unsigned>(blocks);
+}
+
+unsigned sweep_grid(int64_t total) {
+  int64_t blocks = (total + kBlock - 1) / kBlock;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  return static_cast<unsigned>(blocks);
+}
+
+void fill_sorted(UpdParams& p, const SortWs& s, int64_t nkeys, uint32_t split) {
+  p.keys = sorted_keys(s, nkeys);
+  p.vals = sorted_vals(s, nkeys);
+  p.seg_start = s.seg_start;
+  p.nseg = s.nseg;
+  p.split = split;
+}
+
+}  // namespace
+}  // namespace collie
+
+using namespace collie;
+
+extern "C" int collie_mf_train_update(const collie_mf_tables* t, const collie_mf_batch* b,
+                                      void* workspace, size_t workspace_bytes, int32_t table_mask,
+                                      int32_t is_bias, int32_t dense, int32_t step_id,
+                                      const collie_optim_cfg* cfg, float* const* state1,
+                                      float* const* state2, int32_t* const* row_stamp,
+                                      const float* grad_scale, collie_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (validate_tables(t) || validate_batch(b)) return -1;
+  COLLIE_REQUIRE(cfg && state1 && state2 && row_stamp, "update: NULL argument array");
+  COLLIE_REQUIRE((table_mask & 3) != 0 && (table_mask & ~3) == 0, "bad table_mask %d", table_mask);
+  TrainWs ws = carve_train_ws(workspace, b->batch, b->num_neg, t->dim, t->num_users, t->num_items);
+  COLLIE_REQUIRE(workspace != nullptr && workspace_bytes >= ws.bytes,
+                 "workspace too small: need %zu bytes, got %zu", ws.bytes, workspace_bytes);
+  UpdParams p;
+  memset(&p, 0, sizeof(p));
+  fill_sorted(p, ws.sort, t->num_users + t->num_items, static_cast<uint32_t>(t->num_users));
+  p.grad_scale = grad_scale;
+  p.step = step_id;
+  p.D = is_bias ? 1 : t->dim;
+  bool sweep[2] = {false, false}, touched[2] = {false, false};
+  for (int side = 0; side < 2; ++side) {
+    if (!(table_mask & (1 << side))) continue;
+    TableDesc& d = p.d[side];
+    if (is_bias) {
+      d.table = side == COLLIE_SIDE_USER ? t->user_bias : t->item_bias;
+      d.stage = side == COLLIE_SIDE_USER ? nullptr : ws.gcoef;
+    } else {
+      d.table = side == COLLIE_SIDE_USER ? t->user_emb : t->item_emb;
+      d.stage = side == COLLIE_SIDE_USER ? ws.stage_u : ws.stage_i;
+    }
+    d.s1 = cfg[side].algo == COLLIE_OPT_SGD ? nullptr : state1[side];
+    d.s2 = (cfg[side].algo == COLLIE_OPT_SPARSE_ADAM || cfg[side].algo == COLLIE_OPT_ADAM)
+               ? state2[side]
+               : nullptr;
+    if (make_hyper(d.h, &cfg[side], dense, true, d.s1, d.s2)) return -1;
+    // dense algorithms whose zero-gradient update is not the identity sweep the other rows
+    sweep[side] = dense && (cfg[side].algo == COLLIE_OPT_ADAM || cfg[side].weight_decay != 0.0f);
+    if (sweep[side]) {
+      COLLIE_REQUIRE(row_stamp[side] != nullptr,
+                     "dense Adam / weight decay need row_stamp = int32[rows] scratch");
+      d.row_stamp = row_stamp[side];
+    }
+    // SparseAdam moves looked-up rows even with a zero gradient: the K-1 other negatives
+    touched[side] = !dense && side == COLLIE_SIDE_ITEM && cfg[side].algo == COLLIE_OPT_SPARSE_ADAM;
+    if (touched[side]) d.seg_stamp = ws.seg_item;
   }
-  const unsigned grid = grid_for(side == COLLIE_SIDE_USER ? b->batch
-                                                          : b->batch * (1 + int64_t{b->num_neg}));
+  const unsigned grid = grid_for(3 * b->batch);
   if (is_bias)
     hipLaunchKernelGGL(bias_rows_kernel<false>, dim3(grid), dim3(kBlock), 0, stream, p);
   else
     hipLaunchKernelGGL(emb_rows_kernel<false>, dim3(grid), dim3(kBlock), 0, stream, p);
   if (check_launch("rows_kernel")) return -2;
-  if (sweep) {
-    const int64_t total = rows * p.D;
-    int64_t blocks = (total + kBlock - 1) / kBlock;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(dense_sweep_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0,
-                       stream, p.table, p.s1, p.s2, stamp, rows, p.D, p.step, p.h);
-    return check_launch("dense_sweep_kernel");
+  for (int side = 0; side < 2; ++side) {
+    const TableDesc& d = p.d[side];
+    const int64_t rows = side == COLLIE_SIDE_USER ? t->num_users : t->num_items;
+    if (sweep[side]) {
+      hipLaunchKernelGGL(dense_sweep_kernel, dim3(sweep_grid(rows * p.D)), dim3(kBlock), 0, stream,
+                         d.table, d.s1, d.s2, d.row_stamp, rows, p.D, p.step, d.h);
+      if (check_launch("dense_sweep_kernel")) return -2;
+    }
+    if (touched[side]) {
+      hipLaunchKernelGGL(touched_sweep_kernel, dim3(sweep_grid(rows * p.D)), dim3(kBlock), 0,
+                         stream, d.table, d.s1, d.s2, ws.touch_item, ws.seg_item, rows, p.D, p.step,
+                         d.h);
+      if (check_launch("touched_sweep_kernel")) return -2;
+    }
   }
   return 0;
 }
 
 extern "C" int collie_mf_train_export_grad(const collie_mf_tables* t, const collie_mf_batch* b,
                                            void* workspace, size_t workspace_bytes, int32_t side,
-                                           int32_t is_bias, int64_t* rows_out, float* vals_out,
-                                           int32_t* count_out, collie_stream_t stream_) {
+                                           int32_t is_bias, int32_t step_id, int64_t* rows_out,
+                                           float* vals_out, int32_t* count_out,
+                                           uint8_t* touched_out, collie_stream_t stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  UpdParams p;
-  if (fill_common(p, t, b, workspace, workspace_bytes, side, is_bias)) return -1;
+  if (validate_tables(t) || validate_batch(b)) return -1;
+  COLLIE_REQUIRE(side == COLLIE_SIDE_USER || side == COLLIE_SIDE_ITEM, "bad side %d", side);
   COLLIE_REQUIRE(rows_out && vals_out && count_out, "export: NULL output");
+  TrainWs ws = carve_train_ws(workspace, b->batch, b->num_neg, t->dim, t->num_users, t->num_items);
+  COLLIE_REQUIRE(workspace != nullptr && workspace_bytes >= ws.bytes,
+                 "workspace too small: need %zu bytes, got %zu", ws.bytes, workspace_bytes);
+  UpdParams p;
+  memset(&p, 0, sizeof(p));
+  fill_sorted(p, ws.sort, t->num_users + t->num_items, static_cast<uint32_t>(t->num_users));
+  p.D = is_bias ? 1 : t->dim;
+  p.export_side = side;
   p.rows_out = rows_out;
   p.vals_out = vals_out;
   p.count_out = count_out;
-  const unsigned grid = grid_for(side == COLLIE_SIDE_USER ? b->batch
-                                                          : b->batch * (1 + int64_t{b->num_neg}));
+  if (is_bias) {
+    p.d[0].stage = nullptr;
+    p.d[1].stage = ws.gcoef;
+  } else {
+    p.d[0].stage = ws.stage_u;
+    p.d[1].stage = ws.stage_i;
+  }
+  const unsigned grid = grid_for(3 * b->batch);
   if (is_bias)
     hipLaunchKernelGGL(bias_rows_kernel<true>, dim3(grid), dim3(kBlock), 0, stream, p);
   else
     hipLaunchKernelGGL(emb_rows_kernel<true>, dim3(grid), dim3(kBlock), 0, stream, p);
-  return check_launch("export_grad");
+  if (check_launch("export_grad")) return -2;
+  if (touched_out && side == COLLIE_SIDE_ITEM) {
+    hipLaunchKernelGGL(export_touched_kernel,
+                       dim3(static_cast<unsigned>((t->num_items + kBlock - 1) / kBlock)),
+                       dim3(kBlock), 0, stream, ws.touch_item, t->num_items, step_id, touched_out);
+    return check_launch("export_touched_kernel");
+  }
+  return 0;
+}
+
+extern "C" size_t collie_sparse_rows_workspace_bytes(int64_t m) {
+  if (m < 1) return 0;
+  Carver c(nullptr);
+  SortWs s;
+  carve_sort_ws(c, s, m);
+  return align_up(c.off, 256);
+}
+
+extern "C" int collie_sparse_rows_update(float* table, int64_t num_rows, int32_t dim,
+                                         const void* rows, int32_t rows_dtype, const float* vals,
+                                         int64_t m, const collie_optim_cfg* cfg, float* state1,
+                                         float* state2, void* workspace, size_t workspace_bytes,
+                                         int32_t* status, collie_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  COLLIE_REQUIRE(table && rows && vals && cfg, "sparse_rows_update: NULL pointer");
+  COLLIE_REQUIRE(num_rows >= 1 && num_rows < (int64_t{1} << 31) && dim >= 1,
+                 "sparse_rows_update: bad table shape");
+  COLLIE_REQUIRE(m >= 1 && m < (int64_t{1} << 30), "sparse_rows_update: bad entry count");
+  Carver c(workspace);
+  SortWs s;
+  carve_sort_ws(c, s, m);
+  COLLIE_REQUIRE(workspace && workspace_bytes >= align_up(c.off, 256),
+                 "workspace too small: need %zu bytes, got %zu", align_up(c.off, 256),
+                 workspace_bytes);
+  hipLaunchKernelGGL(coo_entries_kernel, dim3(static_cast<unsigned>((m + kBlock - 1) / kBlock)),
+                     dim3(kBlock), 0, stream, rows, rows_dtype, m, num_rows, s.ekeys, s.ecodes,
+                     status);
+  if (check_launch("coo_entries_kernel")) return -2;
+  if (sort_and_segment(s, num_rows, 0xffffffffu, stream)) return -1;
+  UpdParams p;
+  memset(&p, 0, sizeof(p));
+  fill_sorted(p, s, num_rows, 0xffffffffu);
+  p.D = dim;
+  p.step = cfg->step;
+  TableDesc& d = p.d[0];
+  d.table = table;
+  d.stage = vals;
+  d.s1 = cfg->algo == COLLIE_OPT_SGD ? nullptr : state1;
+  d.s2 = cfg->algo == COLLIE_OPT_SPARSE_ADAM ? state2 : nullptr;
+  COLLIE_REQUIRE(cfg->algo != COLLIE_OPT_ADAM,
+                 "Adam does not support sparse gradients, please consider SparseAdam instead");
+  if (make_hyper(d.h, cfg, 0, true, d.s1, d.s2)) return -1;
+  if (dim == 1)
+    hipLaunchKernelGGL(bias_rows_kernel<false>, dim3(grid_for(m)), dim3(kBlock), 0, stream, p);
+  else
+    hipLaunchKernelGGL(emb_rows_kernel<false>, dim3(grid_for(m)), dim3(kBlock), 0, stream, p);
+  return check_launch("sparse_rows_update");
 }

@@ -1,4 +1,7 @@
 // Layout of the caller-provided training workspace (one per model, reused every step).
+//
+// The workspace must be zero-filled when it is created (the two stamp arrays compare against the
+// caller's step id, which starts at 1) and must not be shared between models.
 #pragma once
 
 #include "common.h"
@@ -7,63 +10,87 @@ namespace collie {
 
 constexpr uint32_t kCodeNone = 0x80000000u;  // entry contributes nothing (zero gradient)
 constexpr uint32_t kCodeNeg = 0x40000000u;   // contribution enters with a minus sign
-constexpr uint32_t kCodeMask = 0x3fffffffu;  // sample index b
+constexpr uint32_t kCodeMask = 0x3fffffffu;  // index of the staged row (sample index b)
 
-constexpr int kSortTile = 2048;      // keys per workgroup per radix pass
+constexpr int kSortTile = 2048;       // entries per workgroup per radix pass
+constexpr int kMaxRadixBits = 11;
 constexpr int kMaxLossBlocks = 2048;  // grid of the fused forward kernel (fixed -> deterministic)
 
-struct SideWs {
-  int64_t m;           // number of looked-up ids on this side
-  int64_t ntiles;      // ceil(m / kSortTile)
-  uint32_t* codes;     // [m] sort payload written by the forward kernel
-  uint32_t* keys[2];   // [m] ping-pong
-  uint32_t* vals[2];   // [m]
-  uint32_t* hist;      // [256 * ntiles]
-  uint32_t* totals;    // [4 * 256]
-  uint32_t* seg_start; // [m + 1]
-  uint32_t* blk_heads; // [ntiles + 1]
-  uint32_t* nseg;      // [1]
+// Sort + segment scratch for `m` (key, code) entries.
+struct SortWs {
+  int64_t m;
+  int64_t ntiles;
+  uint32_t* ekeys;      // [m] unsorted keys
+  uint32_t* ecodes;     // [m] unsorted payload
+  uint32_t* keys[2];    // [m] ping-pong
+  uint32_t* vals[2];    // [m]
+  uint32_t* hist;       // [2^bits * ntiles]
+  uint32_t* totals;     // [4 * 2^kMaxRadixBits]
+  uint32_t* seg_start;  // [m + 1]
+  uint32_t* blk_heads;  // [ntiles + 1]
+  uint32_t* nseg;       // [0] number of segments, [1] index of the first segment with key >= split
 };
 
+inline void carve_sort_ws(Carver& c, SortWs& s, int64_t m) {
+  s.m = m;
+  s.ntiles = (m + kSortTile - 1) / kSortTile;
+  s.ekeys = c.take<uint32_t>(m);
+  s.ecodes = c.take<uint32_t>(m);
+  for (int i = 0; i < 2; ++i) {
+    s.keys[i] = c.take<uint32_t>(m);
+    s.vals[i] = c.take<uint32_t>(m);
+  }
+  s.hist = c.take<uint32_t>((size_t{1} << kMaxRadixBits) * static_cast<size_t>(s.ntiles));
+  s.totals = c.take<uint32_t>(4 * (size_t{1} << kMaxRadixBits));
+  s.seg_start = c.take<uint32_t>(m + 1);
+  s.blk_heads = c.take<uint32_t>(s.ntiles + 1);
+  s.nseg = c.take<uint32_t>(64);
+}
+
+// radix plan for keys in [0, nkeys)
+struct RadixPlan {
+  int passes;
+  int bits;  // per pass
+};
+inline RadixPlan radix_plan(int64_t nkeys) {
+  int total = 1;
+  while ((int64_t{1} << total) < nkeys) ++total;
+  RadixPlan p;
+  p.passes = (total + kMaxRadixBits - 1) / kMaxRadixBits;
+  p.bits = (total + p.passes - 1) / p.passes;
+  if (p.bits < 8) p.bits = 8;
+  return p;
+}
+
+// The fused training step: 3B entries. [0, B): user rows (key = user id); [B, 3B): two item rows
+// per sample, positive and selected negative (key = num_users + item id).
 struct TrainWs {
-  float* stage_u;        // [B, D]  g * (I[pos] - I[neg_sel])   -> user-row gradients
-  float* stage_i;        // [B, D]  g * U[user]                 -> +pos / -neg_sel item-row gradients
+  float* stage_u;        // [B, D]  g * I[pos] - g * I[neg_sel]   -> user-row gradients
+  float* stage_i;        // [B, D]  g * U[user]                   -> +pos / -neg_sel item rows
   float* gcoef;          // [B]     g = dL/ds+ (dL/ds-_sel = -g)
   float* loss_partials;  // [2 * kMaxLossBlocks]
-  SideWs side[2];
+  SortWs sort;
+  int32_t* touch_item;   // [num_items] step id of the last forward that looked the item up
+  int32_t* seg_item;     // [num_items] step id of the last update in which the item had a segment
   size_t bytes;
 };
 
-inline TrainWs carve_train_ws(void* base, int64_t B, int K, int D) {
+inline TrainWs carve_train_ws(void* base, int64_t B, int K, int D, int64_t num_users,
+                              int64_t num_items) {
+  (void)K;
+  (void)num_users;
   Carver c(base);
   TrainWs w;
+  // persistent part first: its offsets must not move when the batch size changes
+  w.touch_item = c.take<int32_t>(num_items);
+  w.seg_item = c.take<int32_t>(num_items);
   w.stage_u = c.take<float>(static_cast<size_t>(B) * D);
   w.stage_i = c.take<float>(static_cast<size_t>(B) * D);
   w.gcoef = c.take<float>(B);
   w.loss_partials = c.take<float>(2 * kMaxLossBlocks);
-  for (int s = 0; s < 2; ++s) {
-    SideWs& sw = w.side[s];
-    sw.m = (s == COLLIE_SIDE_USER) ? B : B * (1 + static_cast<int64_t>(K));
-    sw.ntiles = (sw.m + kSortTile - 1) / kSortTile;
-    sw.codes = c.take<uint32_t>(sw.m);
-    for (int i = 0; i < 2; ++i) {
-      sw.keys[i] = c.take<uint32_t>(sw.m);
-      sw.vals[i] = c.take<uint32_t>(sw.m);
-    }
-    sw.hist = c.take<uint32_t>(256 * static_cast<size_t>(sw.ntiles));
-    sw.totals = c.take<uint32_t>(4 * 256);
-    sw.seg_start = c.take<uint32_t>(sw.m + 1);
-    sw.blk_heads = c.take<uint32_t>(sw.ntiles + 1);
-    sw.nseg = c.take<uint32_t>(64);
-  }
+  carve_sort_ws(c, w.sort, 3 * B);
   w.bytes = align_up(c.off, 256);
   return w;
-}
-
-inline int radix_passes(int64_t rows) {
-  int bits = 1;
-  while ((int64_t{1} << bits) < rows) ++bits;
-  return (bits + 7) / 8;
 }
 
 }  // namespace collie

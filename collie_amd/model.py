@@ -78,25 +78,27 @@ class _MFScore(torch.autograd.Function):
 
 # ---- fused route: calculate_loss ---------------------------------------------------------------
 class _FusedStep:
-    """One staged backward: batch, workspace and which sides already have their segments."""
+    """One staged backward: batch, workspace, step id and whether the segments exist yet."""
 
-    def __init__(self, model, tables, batch, buf):
+    def __init__(self, model, tables, batch, buf, step_id):
         self.model, self.tables, self.batch, self.buf = model, tables, batch, buf
+        self.step_id = step_id
         self.armed = False
         self.grad_scale = None
-        self.segments = [False, False]
+        self.segments = False
         self.done = set()
 
-    def update(self, slot, dense, cfg, state1, state2, stamp):
-        side, is_bias = slot
-        if slot in self.done:
+    def update(self, is_bias, dense, per_side):
+        """per_side: {side: (cfg, state1, state2, row_stamp)}; one launch for both sides."""
+        per_side = {s: v for s, v in per_side.items() if (s, is_bias) not in self.done}
+        if not per_side:
             return                      # a table is updated at most once per staged backward
-        if not self.segments[side]:
-            ops.train_build_segments(self.tables, self.batch, self.buf, side)
-            self.segments[side] = True
-        ops.train_update(self.tables, self.batch, self.buf, side, is_bias, dense, cfg, state1,
-                         state2, stamp, self.grad_scale)
-        self.done.add(slot)
+        if not self.segments:
+            ops.train_build_segments(self.tables, self.batch, self.buf)
+            self.segments = True
+        ops.train_update(self.tables, self.batch, self.buf, is_bias, dense, self.step_id, per_side,
+                         self.grad_scale)
+        self.done.update((s, is_bias) for s in per_side)
 
 
 class _FusedLoss(torch.autograd.Function):
@@ -461,7 +463,8 @@ class MatrixFactorizationModel(nn.Module):
             self._workspace = ops.TrainWorkspace(dev)
         self._staged_step = None        # the workspace is about to be overwritten
         B, K = neg_items.shape
-        buf = self._workspace.ensure(B, K, self.hparams.embedding_dim)
+        buf = self._workspace.ensure(B, K, self.hparams.embedding_dim, self.hparams.num_users,
+                                     self.hparams.num_items)
         if self._meta_codes is None:
             self._meta_codes = loss_mod.metadata_to_codes(
                 self.hparams.get('metadata_for_loss'),
@@ -471,11 +474,12 @@ class MatrixFactorizationModel(nn.Module):
         hbatch = ops.make_batch(users, pos_items, neg_items)
         cfg = ops.make_loss_cfg(self._loss_kind, self.hparams.num_items, codes, weights)
         loss_value = torch.empty(1, dtype=torch.float32, device=dev)
-        ops.train_forward(tables, hbatch, cfg, buf, need_grad, loss_value, None, None,
+        step_id = self._workspace.next_step() if need_grad else max(self._workspace.step_id, 1)
+        ops.train_forward(tables, hbatch, cfg, buf, need_grad, step_id, loss_value, None, None,
                           self._status_flag())
         if not need_grad:
             return loss_value.reshape(())
-        staged = _FusedStep(self, tables, hbatch, buf)
+        staged = _FusedStep(self, tables, hbatch, buf, step_id)
         self._staged_step = staged
         weights_ = [getattr(self, n).weight for n in _TABLES]
         return _FusedLoss.apply(self, staged, loss_value, *weights_)

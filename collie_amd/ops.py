@@ -50,64 +50,126 @@ def make_loss_cfg(kind, num_items, metadata_codes=None, metadata_weights=None):
     return cfg
 
 
-def train_workspace_bytes(batch_size, num_neg, dim):
-    return int(load().collie_mf_train_workspace_bytes(batch_size, num_neg, dim))
+def train_workspace_bytes(batch_size, num_neg, dim, num_users, num_items):
+    return int(load().collie_mf_train_workspace_bytes(batch_size, num_neg, dim, num_users,
+                                                      num_items))
 
 
 class TrainWorkspace:
-    """Device scratch of one model; grows on demand, reused every step."""
+    """
+    Device scratch of ONE model: zero-filled at creation (it holds per-item step stamps), grown
+    on demand, reused every step.  ``next_step()`` hands out the step ids the stamps compare to.
+    """
 
     def __init__(self, device):
         self.device = device
         self.buf = None
-        self.key = None
+        self.step_id = 0
 
-    def ensure(self, batch_size, num_neg, dim):
-        need = train_workspace_bytes(batch_size, num_neg, dim)
+    def ensure(self, batch_size, num_neg, dim, num_users, num_items):
+        need = train_workspace_bytes(batch_size, num_neg, dim, num_users, num_items)
         if need == 0:
             raise ValueError('empty batch')
         if self.buf is None or self.buf.numel() < need:
-            self.buf = torch.empty(need, dtype=torch.uint8, device=self.device)
-        self.key = (batch_size, num_neg, dim)
+            self.buf = torch.zeros(need, dtype=torch.uint8, device=self.device)
+            self.step_id = 0
         return self.buf
 
+    def next_step(self):
+        self.step_id += 1
+        if self.step_id >= 2 ** 31 - 1:
+            self.buf.zero_()
+            self.step_id = 1
+        return self.step_id
 
-def train_forward(tables, batch, loss_cfg, ws_buf, need_grad, loss_out, s_pos_out=None,
+
+def train_forward(tables, batch, loss_cfg, ws_buf, need_grad, step_id, loss_out, s_pos_out=None,
                   s_neg_out=None, status=None):
     check(load().collie_mf_train_forward(
         byref(tables), byref(batch), byref(loss_cfg), ptr(ws_buf), ws_buf.numel(),
-        1 if need_grad else 0, ptr(loss_out), ptr(s_pos_out), ptr(s_neg_out), ptr(status),
-        stream_ptr()), 'collie_mf_train_forward')
+        1 if need_grad else 0, step_id, ptr(loss_out), ptr(s_pos_out), ptr(s_neg_out),
+        ptr(status), stream_ptr()), 'collie_mf_train_forward')
 
 
-def train_build_segments(tables, batch, ws_buf, side):
+def train_build_segments(tables, batch, ws_buf):
     check(load().collie_mf_train_build_segments(
-        byref(tables), byref(batch), ptr(ws_buf), ws_buf.numel(), side, stream_ptr()),
+        byref(tables), byref(batch), ptr(ws_buf), ws_buf.numel(), stream_ptr()),
         'collie_mf_train_build_segments')
 
 
-def train_update(tables, batch, ws_buf, side, is_bias, dense, cfg, state1=None, state2=None,
-                 row_stamp=None, grad_scale=None):
+def _ptr_array(tensors):
+    arr = (c_void_p * 2)()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr() if t is not None else None
+    return arr
+
+
+def train_update(tables, batch, ws_buf, is_bias, dense, step_id, per_side, grad_scale=None):
+    """
+    per_side: {side: (OptimCfg, state1, state2, row_stamp)} for the tables this optimizer owns
+    (side = _lib.SIDE_USER / _lib.SIDE_ITEM); both sides are updated by one launch.
+    """
+    cfgs = (OptimCfg * 2)()
+    s1, s2, st = [None, None], [None, None], [None, None]
+    mask = 0
+    for side, (cfg, a, b, c) in per_side.items():
+        cfgs[side] = cfg
+        s1[side], s2[side], st[side] = a, b, c
+        mask |= 1 << side
     check(load().collie_mf_train_update(
-        byref(tables), byref(batch), ptr(ws_buf), ws_buf.numel(), side, 1 if is_bias else 0,
-        1 if dense else 0, byref(cfg), ptr(state1), ptr(state2), ptr(row_stamp), ptr(grad_scale),
-        stream_ptr()), 'collie_mf_train_update')
+        byref(tables), byref(batch), ptr(ws_buf), ws_buf.numel(), mask, 1 if is_bias else 0,
+        1 if dense else 0, step_id, cfgs, _ptr_array(s1), _ptr_array(s2), _ptr_array(st),
+        ptr(grad_scale), stream_ptr()), 'collie_mf_train_update')
 
 
-def train_export_grad(tables, batch, ws_buf, side, is_bias):
-    """Coalesced gradient of one table: (rows int64 [n], values [n, D or 1]).  Synchronises."""
-    B, K = batch.batch, batch.num_neg
-    cap = B if side == _lib.SIDE_USER else B * (1 + K)
+def train_export_grad(tables, batch, ws_buf, side, is_bias, step_id):
+    """
+    Coalesced gradient of one table as torch's ``grad.coalesce()`` would hold it: (rows int64 [n],
+    values [n, D or 1]) over every looked-up row, zero-gradient rows included.  Synchronises;
+    meant for tests and for callers that want ``.grad``.
+    """
+    B = batch.batch
+    cap = 2 * B
     D = 1 if is_bias else tables.dim
     dev = ws_buf.device
     rows = torch.empty(cap, dtype=torch.int64, device=dev)
     vals = torch.empty(cap, D, dtype=torch.float32, device=dev)
     count = torch.zeros(1, dtype=torch.int32, device=dev)
+    touched = None
+    if side == _lib.SIDE_ITEM:
+        touched = torch.zeros(tables.num_items, dtype=torch.uint8, device=dev)
     check(load().collie_mf_train_export_grad(
         byref(tables), byref(batch), ptr(ws_buf), ws_buf.numel(), side, 1 if is_bias else 0,
-        ptr(rows), ptr(vals), ptr(count), stream_ptr()), 'collie_mf_train_export_grad')
+        step_id, ptr(rows), ptr(vals), ptr(count), ptr(touched), stream_ptr()),
+        'collie_mf_train_export_grad')
     n = int(count.item())
-    return rows[:n], vals[:n]
+    rows, vals = rows[:n], vals[:n]
+    if touched is None:
+        return rows, vals
+    all_rows = torch.nonzero(touched).reshape(-1)
+    full = torch.zeros(all_rows.shape[0], D, dtype=torch.float32, device=dev)
+    full[torch.searchsorted(all_rows, rows)] = vals
+    return all_rows, full
+
+
+def sparse_rows_update(table, rows, vals, cfg, state1=None, state2=None, status=None,
+                       workspace=None):
+    """``optimizer.step()`` of SGD / Adagrad / SparseAdam on an uncoalesced COO gradient."""
+    require_hip(table, 'table')
+    rows = rows.contiguous()
+    vals = vals.contiguous().float()
+    m = rows.shape[0]
+    if m == 0:
+        return workspace
+    need = int(load().collie_sparse_rows_workspace_bytes(m))
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=table.device)
+    dim = table.shape[1] if table.dim() == 2 else 1
+    check(load().collie_sparse_rows_update(
+        ptr(table), table.shape[0], dim, ptr(rows), idx_dtype(rows), ptr(vals), m, byref(cfg),
+        ptr(state1), ptr(state2), ptr(workspace), workspace.numel(), ptr(status), stream_ptr()),
+        'collie_sparse_rows_update')
+    return workspace
 
 
 def optim_cfg(algo, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, lr_decay=0.0):

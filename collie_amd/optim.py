@@ -47,6 +47,8 @@ class _FusedMixin:
             with torch.enable_grad():
                 loss = closure()
         model = self._collie_model
+        dense = not model.hparams.sparse
+        launches = {False: {}, True: {}}            # is_bias -> {side: (cfg, s1, s2, stamp)}
         for group in self.param_groups:
             for p in group['params']:
                 slot = model._table_slot(p)
@@ -56,8 +58,18 @@ class _FusedMixin:
                     continue
                 if not p.requires_grad:
                     continue
-                self._fused_update(staged, model, p, group, slot)
+                side, is_bias = slot
+                launches[is_bias][side] = self._table_args(model, p, group, dense)
+        for is_bias, per_side in launches.items():
+            if per_side:
+                staged.update(is_bias, dense, per_side)
         return loss
+
+    @staticmethod
+    def _stamp(state, p):
+        if '_row_stamp' not in state:
+            state['_row_stamp'] = torch.zeros(p.shape[0], dtype=torch.int32, device=p.device)
+        return state['_row_stamp']
 
 
 def _step_count(state):
@@ -68,8 +80,8 @@ def _step_count(state):
 class FusedSparseAdam(_FusedMixin, torch.optim.SparseAdam):
     """``torch.optim.SparseAdam`` (``torch/optim/_functional.py:24-84``) on touched rows."""
 
-    def _fused_update(self, staged, model, p, group, slot):
-        if not model.hparams.sparse:
+    def _table_args(self, model, p, group, dense):
+        if dense:
             raise RuntimeError('SparseAdam does not support dense gradients, please consider '
                                'Adam instead')
         state = self.state[p]
@@ -81,68 +93,56 @@ class FusedSparseAdam(_FusedMixin, torch.optim.SparseAdam):
         beta1, beta2 = group['betas']
         cfg = ops.optim_cfg(_lib.OPT_SPARSE_ADAM, state['step'], group['lr'], beta1, beta2,
                             group['eps'])
-        staged.update(slot, False, cfg, state['exp_avg'], state['exp_avg_sq'], None)
+        return cfg, state['exp_avg'], state['exp_avg_sq'], None
 
 
 class FusedAdam(_FusedMixin, torch.optim.Adam):
     """``torch.optim.Adam`` (dense, ``torch/optim/adam.py:396-547``): every row, every step."""
 
-    def _fused_update(self, staged, model, p, group, slot):
-        if model.hparams.sparse:
+    def _table_args(self, model, p, group, dense):
+        if not dense:
             raise RuntimeError('Adam does not support sparse gradients, please consider '
                                'SparseAdam instead')
         if group.get('amsgrad') or group.get('maximize'):
             raise RuntimeError('amsgrad / maximize are not supported by the fused Adam')
         state = self.state[p]
-        if len(state) == 0:
+        if 'exp_avg' not in state:
             state['step'] = torch.tensor(0.0, dtype=torch.float32)
             state['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
             state['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
-        if '_row_stamp' not in state:
-            state['_row_stamp'] = torch.zeros(p.shape[0], dtype=torch.int32, device=p.device)
         state['step'] += 1
         beta1, beta2 = group['betas']
         cfg = ops.optim_cfg(_lib.OPT_ADAM, _step_count(state), group['lr'], beta1, beta2,
                             group['eps'], group['weight_decay'])
-        staged.update(slot, True, cfg, state['exp_avg'], state['exp_avg_sq'], state['_row_stamp'])
+        return cfg, state['exp_avg'], state['exp_avg_sq'], self._stamp(state, p)
 
 
 class FusedAdagrad(_FusedMixin, torch.optim.Adagrad):
     """``torch.optim.Adagrad`` (``torch/optim/adagrad.py:346-388``), sparse or dense gradients."""
 
-    def _fused_update(self, staged, model, p, group, slot):
+    def _table_args(self, model, p, group, dense):
         state = self.state[p]           # torch creates 'step' and 'sum' at construction
-        dense = not model.hparams.sparse
         if state['sum'].device != p.device:
             state['sum'] = state['sum'].to(p.device)
         state['step'] += 1
-        stamp = None
-        if dense and group['weight_decay'] != 0:
-            if '_row_stamp' not in state:
-                state['_row_stamp'] = torch.zeros(p.shape[0], dtype=torch.int32, device=p.device)
-            stamp = state['_row_stamp']
+        stamp = self._stamp(state, p) if (dense and group['weight_decay'] != 0) else None
         cfg = ops.optim_cfg(_lib.OPT_ADAGRAD, _step_count(state), group['lr'], eps=group['eps'],
                             weight_decay=group['weight_decay'], lr_decay=group['lr_decay'])
-        staged.update(slot, dense, cfg, state['sum'], None, stamp)
+        return cfg, state['sum'], None, stamp
 
 
 class FusedSGD(_FusedMixin, torch.optim.SGD):
     """``torch.optim.SGD`` with momentum 0 (the only form the reference constructs)."""
 
-    def _fused_update(self, staged, model, p, group, slot):
+    def _table_args(self, model, p, group, dense):
         if group['momentum'] != 0 or group['nesterov'] or group.get('maximize'):
             raise RuntimeError('the fused SGD supports momentum=0 only')
         state = self.state[p]
-        dense = not model.hparams.sparse
         state['_steps'] = state.get('_steps', 0) + 1
-        stamp = None
-        if dense and group['weight_decay'] != 0:
-            if '_row_stamp' not in state:
-                state['_row_stamp'] = torch.zeros(p.shape[0], dtype=torch.int32, device=p.device)
-            stamp = state['_row_stamp']
+        stamp = self._stamp(state, p) if (dense and group['weight_decay'] != 0) else None
         cfg = ops.optim_cfg(_lib.OPT_SGD, state['_steps'], group['lr'],
                             weight_decay=group['weight_decay'])
-        staged.update(slot, dense, cfg, None, None, stamp)
+        return cfg, None, None, stamp
 
 
 FUSED_OPTIMIZERS = {'sgd': FusedSGD, 'adagrad': FusedAdagrad, 'adam': FusedAdam,

@@ -150,42 +150,68 @@ int64_t collie_loss_partials(int64_t batch);
  * sample, loss, and the per-sample gradient rows staged in `workspace` for the optimizers.
  * need_grad = 0 (validation_step) skips the staging.
  * s_pos_out [B] and s_neg_out [K,B] (reference layout) are optional (NULL to skip).
+ *
+ * The workspace belongs to ONE model: it must be zero-filled when created and is then reused by
+ * every step.  step_id (>= 1, increasing by one per forward with need_grad) tags the per-item
+ * "looked up in this step" stamps kept inside it.
  * ------------------------------------------------------------------------------------------- */
-size_t collie_mf_train_workspace_bytes(int64_t batch, int32_t num_neg, int32_t dim);
+size_t collie_mf_train_workspace_bytes(int64_t batch, int32_t num_neg, int32_t dim,
+                                       int64_t num_users, int64_t num_items);
 int collie_mf_train_forward(const collie_mf_tables* t, const collie_mf_batch* b,
                             const collie_loss_cfg* loss, void* workspace, size_t workspace_bytes,
-                            int32_t need_grad, float* loss_out, float* s_pos_out,
+                            int32_t need_grad, int32_t step_id, float* loss_out, float* s_pos_out,
                             float* s_neg_out, int32_t* status, collie_stream_t stream);
 
-/* A8 (grad.coalesce(), torch/optim/_functional.py:44): stable LSD radix sort of the looked-up row
- * ids of one side (users: B ids; items: (1+K)*B ids) + segment heads.  Deterministic: no atomics
- * on floating-point data anywhere.  Must follow collie_mf_train_forward on the same workspace. */
+/* A8 (grad.coalesce(), torch/optim/_functional.py:44): ONE stable LSD radix sort over the 3B
+ * gradient-carrying lookups of the step (B user rows, B positive and B selected-negative item
+ * rows; keys = row id, item rows offset by num_users) + segment heads.  Deterministic: no atomics
+ * on floating-point data anywhere.  Must follow collie_mf_train_forward on the same workspace.
+ * Looked-up rows that carry no gradient (the K-1 other negatives) are not sorted; they are found
+ * through the per-item stamps when an optimizer needs them (SparseAdam). */
 int collie_mf_train_build_segments(const collie_mf_tables* t, const collie_mf_batch* b,
-                                   void* workspace, size_t workspace_bytes, int32_t side,
+                                   void* workspace, size_t workspace_bytes,
                                    collie_stream_t stream);
 
-/* A10/A11  optimizer.step() for ONE table of one side:
- *   is_bias = 0 -> the embedding table, 1 -> the bias table.
- * Sparse algorithms (sparse=True models): SGD / ADAGRAD / SPARSE_ADAM touch exactly the looked-up
- * rows, zero-gradient rows included.  Dense algorithms (sparse=False): ADAM / SGD / ADAGRAD with
- * dense=1 additionally sweep every untouched row with a zero gradient (+ weight decay).
+/* A10/A11  optimizer.step() for the embedding tables (is_bias = 0) or the bias tables
+ * (is_bias = 1) of one or both sides in one launch.  table_mask: bit 0 = user table, bit 1 = item
+ * table; cfg / state1 / state2 / row_stamp are indexed [COLLIE_SIDE_USER], [COLLIE_SIDE_ITEM]
+ * (entries of sides not in the mask are ignored).
+ * Sparse algorithms (sparse=True models, dense = 0): SGD / ADAGRAD / SPARSE_ADAM touch exactly the
+ * looked-up rows, zero-gradient rows included.  Dense algorithms (sparse=False, dense = 1): ADAM /
+ * SGD / ADAGRAD additionally sweep every other row with a zero gradient (+ weight decay).
  * state1 = exp_avg | state_sum, state2 = exp_avg_sq (NULL where the algorithm has none).
  * row_stamp: int32 [rows] scratch owned by the optimizer, required when dense != 0 and the
  * zero-gradient update is not the identity (Adam, or weight_decay != 0); NULL otherwise.
  * grad_scale: optional device float the staged gradient is multiplied by (the grad_output that
- * autograd hands to backward; NULL = 1). */
+ * autograd hands to backward; NULL = 1).  step_id: the value given to collie_mf_train_forward. */
 int collie_mf_train_update(const collie_mf_tables* t, const collie_mf_batch* b, void* workspace,
-                           size_t workspace_bytes, int32_t side, int32_t is_bias, int32_t dense,
-                           const collie_optim_cfg* cfg, float* state1, float* state2,
-                           int32_t* row_stamp, const float* grad_scale, collie_stream_t stream);
+                           size_t workspace_bytes, int32_t table_mask, int32_t is_bias,
+                           int32_t dense, int32_t step_id, const collie_optim_cfg* cfg /*[2]*/,
+                           float* const* state1 /*[2]*/, float* const* state2 /*[2]*/,
+                           int32_t* const* row_stamp /*[2]*/, const float* grad_scale,
+                           collie_stream_t stream);
 
 /* Materialise the coalesced gradient of one table (tests, and `.grad` for callers that ask):
- * rows_out [cap] int64 (sorted unique looked-up rows), vals_out [cap, dim or 1], count_out [1]
- * int32 (device).  cap must be >= number of ids on that side. */
+ * rows_out [cap] int64 (sorted unique rows that carry gradient entries), vals_out [cap, dim or 1],
+ * count_out [1] int32 (device); cap >= 2 * batch.  touched_out (optional, uint8 [num_items], item
+ * side only) = 1 for every item looked up in step_id, zero-gradient negatives included. */
 int collie_mf_train_export_grad(const collie_mf_tables* t, const collie_mf_batch* b,
                                 void* workspace, size_t workspace_bytes, int32_t side,
-                                int32_t is_bias, int64_t* rows_out, float* vals_out,
-                                int32_t* count_out, collie_stream_t stream);
+                                int32_t is_bias, int32_t step_id, int64_t* rows_out,
+                                float* vals_out, int32_t* count_out, uint8_t* touched_out,
+                                collie_stream_t stream);
+
+/* torch.optim.{SparseAdam,Adagrad,SGD}.step on an UNCOALESCED sparse COO gradient of one table
+ * (torch/optim/_functional.py:41-84): rows [m] (int32/int64) with values vals [m, dim].  Sorts,
+ * sums duplicates in input order (deterministic) and updates the rows in place.  Used by the
+ * row-sharded multi-GPU step (owners apply the gradient rows they receive) and by the generic
+ * route.  workspace: collie_sparse_rows_workspace_bytes(m) bytes (need not be zeroed). */
+size_t collie_sparse_rows_workspace_bytes(int64_t m);
+int collie_sparse_rows_update(float* table, int64_t num_rows, int32_t dim, const void* rows,
+                              int32_t rows_dtype, const float* vals, int64_t m,
+                              const collie_optim_cfg* cfg, float* state1, float* state2,
+                              void* workspace, size_t workspace_bytes, int32_t* status,
+                              collie_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * A13-A17  get_preds + mapk / mrr / auc   collie/metrics.py:77-107,144-282

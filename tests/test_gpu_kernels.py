@@ -92,20 +92,42 @@ def test_standalone_losses_vs_reference(golden_dir, dev):
         close(gn.cpu().numpy(), z[tag + '|g_neg'], scale=scale)
 
 
-def run_fused(td, users, pos, neg, kind, dev, codes=None, weights=None, need_grad=True):
-    from collie_amd import ops
-    t = tables_struct(td)
-    batch = ops.make_batch(users, pos, neg)
-    B, K = neg.shape
-    ws = ops.TrainWorkspace(dev)
-    buf = ws.ensure(B, K, t.dim)
-    cfg = ops.make_loss_cfg(kind, t.num_items, codes, weights)
-    loss = torch.empty(1, device=dev)
-    s_pos = torch.empty(B, device=dev)
-    s_neg = torch.empty(K, B, device=dev)
-    status = torch.zeros(1, dtype=torch.int32, device=dev)
-    ops.train_forward(t, batch, cfg, buf, need_grad, loss, s_pos, s_neg, status)
-    return t, batch, buf, loss, s_pos, s_neg, status
+class Fused:
+    """One fused forward on a fresh (zeroed) workspace, kept for the following update calls."""
+
+    def __init__(self, td, users, pos, neg, kind, dev, codes=None, weights=None, need_grad=True,
+                 ws=None):
+        from collie_amd import ops
+        self.t = tables_struct(td)
+        self.batch = ops.make_batch(users, pos, neg)
+        B, K = neg.shape
+        self.ws = ws or ops.TrainWorkspace(dev)
+        self.buf = self.ws.ensure(B, K, self.t.dim, self.t.num_users, self.t.num_items)
+        self.step_id = self.ws.next_step()
+        cfg = ops.make_loss_cfg(kind, self.t.num_items, codes, weights)
+        self.loss = torch.empty(1, device=dev)
+        self.s_pos = torch.empty(B, device=dev)
+        self.s_neg = torch.empty(K, B, device=dev)
+        self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+        ops.train_forward(self.t, self.batch, cfg, self.buf, need_grad, self.step_id, self.loss,
+                          self.s_pos, self.s_neg, self.status)
+        self.built = False
+
+    def segments(self):
+        from collie_amd import ops
+        if not self.built:
+            ops.train_build_segments(self.t, self.batch, self.buf)
+            self.built = True
+
+    def export(self, side, is_bias):
+        from collie_amd import ops
+        self.segments()
+        return ops.train_export_grad(self.t, self.batch, self.buf, side, is_bias, self.step_id)
+
+    def update(self, is_bias, dense, per_side):
+        from collie_amd import ops
+        self.segments()
+        ops.train_update(self.t, self.batch, self.buf, is_bias, dense, self.step_id, per_side)
 
 
 def test_fused_calculate_loss_and_grads_vs_reference(golden_dir, dev):
@@ -119,17 +141,16 @@ def test_fused_calculate_loss_and_grads_vs_reference(golden_dir, dev):
         pos = torch.tensor(z[f'{tag}|pos'], device=dev)          # int32
         neg = torch.tensor(z[f'{tag}|neg'], device=dev)          # int64 [B, K]
         kw = dict(codes=codes, weights=weights) if m == 'm1' else {}
-        t, batch, buf, loss, s_pos, s_neg, status = run_fused(td, users, pos, neg, kind, dev, **kw)
-        close(loss.item(), z[f'{tag}|loss'])
-        close(s_pos.cpu().numpy(), z[f'{tag}|s_pos'])
-        close(s_neg.cpu().numpy(), z[f'{tag}|s_neg'])
-        assert int(status.item()) == 0
+        f = Fused(td, users, pos, neg, kind, dev, **kw)
+        close(f.loss.item(), z[f'{tag}|loss'])
+        close(f.s_pos.cpu().numpy(), z[f'{tag}|s_pos'])
+        close(f.s_neg.cpu().numpy(), z[f'{tag}|s_neg'])
+        assert int(f.status.item()) == 0
         gscale = max(np.abs(z[f'{tag}|g|item_embeddings|vals']).max(), 1e-12)
         for side, names in ((_lib.SIDE_USER, ('user_embeddings', 'user_biases')),
                             (_lib.SIDE_ITEM, ('item_embeddings', 'item_biases'))):
-            ops.train_build_segments(t, batch, buf, side)
             for name in names:
-                rows, vals = ops.train_export_grad(t, batch, buf, side, 'bias' in name)
+                rows, vals = f.export(side, 'bias' in name)
                 # touched-row set (zero-gradient rows included): exact
                 np.testing.assert_array_equal(rows.cpu().numpy(), z[f'{tag}|g|{name}|rows'])
                 ref = z[f'{tag}|g|{name}|vals']
@@ -155,26 +176,28 @@ def test_optimizer_trajectories_vs_torch(golden_dir, dev):
         state = {n: {'s1': torch.zeros_like(td[n]), 's2': torch.zeros_like(td[n]),
                      'stamp': torch.zeros(td[n].shape[0], dtype=torch.int32, device=dev)}
                  for n in NAMES}
+        ws = ops.TrainWorkspace(dev)
         for s in range(4):
             users = torch.tensor(z[f'{tag}|s{s}|users'], device=dev)
             pos = torch.tensor(z[f'{tag}|s{s}|pos'], device=dev)
             neg = torch.tensor(z[f'{tag}|s{s}|neg'], device=dev)
-            t, batch, buf, loss, _, _, _ = run_fused(td, users, pos, neg, kind, dev)
-            close(loss.item(), z[f'{tag}|s{s}|loss'], rtol=2e-5)
-            for side in (_lib.SIDE_USER, _lib.SIDE_ITEM):
-                ops.train_build_segments(t, batch, buf, side)
-            for n in NAMES:
-                is_bias = 'bias' in n
-                algo, rate = (bopt, blr) if (is_bias and bopt is not None) else (opt, lr)
-                side = _lib.SIDE_USER if n.startswith('user') else _lib.SIDE_ITEM
-                eps = 1e-10 if algo == 'adagrad' else 1e-8
-                cfg = ops.optim_cfg(algo, s + 1, rate, eps=eps,
-                                    weight_decay=0.0 if algo == 'sparse_adam' else wd)
-                st = state[n]
-                ops.train_update(t, batch, buf, side, is_bias, not sparse, cfg,
-                                 st['s1'] if algo != 'sgd' else None,
-                                 st['s2'] if algo in ('adam', 'sparse_adam') else None,
-                                 st['stamp'] if not sparse else None)
+            f = Fused(td, users, pos, neg, kind, dev, ws=ws)
+            close(f.loss.item(), z[f'{tag}|s{s}|loss'], rtol=2e-5)
+            for is_bias in (False, True):
+                per_side = {}
+                for n in NAMES:
+                    if ('bias' in n) != is_bias:
+                        continue
+                    algo, rate = (bopt, blr) if (is_bias and bopt is not None) else (opt, lr)
+                    side = _lib.SIDE_USER if n.startswith('user') else _lib.SIDE_ITEM
+                    eps = 1e-10 if algo == 'adagrad' else 1e-8
+                    cfg = ops.optim_cfg(algo, s + 1, rate, eps=eps,
+                                        weight_decay=0.0 if algo == 'sparse_adam' else wd)
+                    st = state[n]
+                    per_side[side] = (cfg, st['s1'] if algo != 'sgd' else None,
+                                      st['s2'] if algo in ('adam', 'sparse_adam') else None,
+                                      st['stamp'] if not sparse else None)
+                f.update(is_bias, not sparse, per_side)
             for n in NAMES:
                 if n == 'user_biases':
                     assert float(td[n].abs().max()) == 0.0   # exact zero gradient, see above
@@ -209,30 +232,29 @@ def test_fused_step_vs_oracle_seeded(dev, B, K, D, U, N):
     td = to_dev(tables, dev)
     m = {n: torch.zeros_like(td[n]) for n in NAMES}
     v = {n: torch.zeros_like(td[n]) for n in NAMES}
+    ws = ops.TrainWorkspace(dev)
     for step in range(2):
         # Zipf-ish popularity so that hot rows have long segments
         users = (rng.zipf(1.3, B) % U).astype(np.int32)
         pos = (rng.zipf(1.2, B) % N).astype(np.int32)
         neg = rng.integers(0, N, (B, K)).astype(np.int64)
         out = st.step(users, pos, neg, kind)
-        t, batch, buf, loss, s_pos, s_neg, status = run_fused(
-            td, torch.tensor(users, device=dev), torch.tensor(pos, device=dev),
-            torch.tensor(neg, device=dev), kind, dev)
-        close(loss.item(), out['loss'])
-        close(s_pos.cpu().numpy(), out['s_pos'])
-        close(s_neg.cpu().numpy(), out['s_neg'])
-        for side in (_lib.SIDE_USER, _lib.SIDE_ITEM):
-            ops.train_build_segments(t, batch, buf, side)
+        f = Fused(td, torch.tensor(users, device=dev), torch.tensor(pos, device=dev),
+                  torch.tensor(neg, device=dev), kind, dev, ws=ws)
+        close(f.loss.item(), out['loss'])
+        close(f.s_pos.cpu().numpy(), out['s_pos'])
+        close(f.s_neg.cpu().numpy(), out['s_neg'])
+        per_side = {}
         for n in ('user_embeddings', 'item_embeddings'):
             side = _lib.SIDE_USER if n.startswith('user') else _lib.SIDE_ITEM
-            rows, vals = ops.train_export_grad(t, batch, buf, side, False)
+            rows, vals = f.export(side, False)
             np.testing.assert_array_equal(rows.cpu().numpy(), out['grads'][n][0])
             close(vals.cpu().numpy(), out['grads'][n][1], rtol=5e-5)
-            ops.train_update(t, batch, buf, side, False, False,
-                             ops.optim_cfg('sparse_adam', step + 1, 1e-2), m[n], v[n])
-        for n in ('user_biases', 'item_biases'):
-            side = _lib.SIDE_USER if n.startswith('user') else _lib.SIDE_ITEM
-            ops.train_update(t, batch, buf, side, True, False, ops.optim_cfg('sgd', step + 1, 1e-1))
+            per_side[side] = (ops.optim_cfg('sparse_adam', step + 1, 1e-2), m[n], v[n], None)
+        f.update(False, False, per_side)
+        sgd = ops.optim_cfg('sgd', step + 1, 1e-1)
+        f.update(True, False, {_lib.SIDE_USER: (sgd, None, None, None),
+                               _lib.SIDE_ITEM: (sgd, None, None, None)})
         for n in ('user_embeddings', 'item_embeddings', 'item_biases'):
             close(td[n].cpu().numpy(), st.t[n], rtol=5e-5)
             if 'bias' not in n:
@@ -255,13 +277,17 @@ def test_fused_step_is_deterministic(dev):
         td = to_dev(tables, dev)
         m = {n: torch.zeros_like(td[n]) for n in NAMES}
         v = {n: torch.zeros_like(td[n]) for n in NAMES}
+        ws = ops.TrainWorkspace(dev)
         for step in range(3):
-            t, batch, buf, loss, _, _, _ = run_fused(td, users, pos, neg, 'adaptive_bpr', dev)
-            for side, n in ((_lib.SIDE_USER, 'user_embeddings'), (_lib.SIDE_ITEM, 'item_embeddings')):
-                ops.train_build_segments(t, batch, buf, side)
-                ops.train_update(t, batch, buf, side, False, False,
-                                 ops.optim_cfg('sparse_adam', step + 1, 1e-2), m[n], v[n])
-                ops.train_update(t, batch, buf, side, True, False, ops.optim_cfg('sgd', step + 1, 1e-1))
+            f = Fused(td, users, pos, neg, 'adaptive_bpr', dev, ws=ws)
+            loss = f.loss
+            adam = ops.optim_cfg('sparse_adam', step + 1, 1e-2)
+            f.update(False, False, {
+                _lib.SIDE_USER: (adam, m['user_embeddings'], v['user_embeddings'], None),
+                _lib.SIDE_ITEM: (adam, m['item_embeddings'], v['item_embeddings'], None)})
+            sgd = ops.optim_cfg('sgd', step + 1, 1e-1)
+            f.update(True, False, {_lib.SIDE_USER: (sgd, None, None, None),
+                                   _lib.SIDE_ITEM: (sgd, None, None, None)})
         results.append([td[n].cpu().numpy().copy() for n in NAMES] + [loss.item()])
     for a, b in zip(*results):
         np.testing.assert_array_equal(a, b)

@@ -33,8 +33,9 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.SIGNATURES) == names
     assert lib.collie_version() >= 100
     # size queries are pure host functions
-    assert lib.collie_mf_train_workspace_bytes(1024, 10, 64) > 1024 * 64 * 4 * 2
-    assert lib.collie_mf_train_workspace_bytes(0, 10, 64) == 0
+    assert lib.collie_mf_train_workspace_bytes(1024, 10, 64, 1000, 500) > 1024 * 64 * 4 * 2
+    assert lib.collie_mf_train_workspace_bytes(0, 10, 64, 1000, 500) == 0
+    assert lib.collie_sparse_rows_workspace_bytes(1000) > 1000 * 4 * 6
     assert lib.collie_mf_eval_topk_capacity() >= 10
 
 
@@ -49,7 +50,7 @@ def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
     cfg = _lib.LossCfg()
     cfg.kind = _lib.LOSS_ADAPTIVE_BPR
     rc = lib.collie_mf_train_forward(ctypes.byref(t2), ctypes.byref(b), ctypes.byref(cfg), None, 0,
-                                     1, 1, None, None, None, None)
+                                     1, 1, 1, None, None, None, None)
     assert rc != 0 and b'num_negative_samples' in lib.collie_last_error()
 
 
