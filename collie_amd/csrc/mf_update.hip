@@ -91,118 +91,178 @@ struct UpdParams {
   int step;
 };
 
+template <int VEC>
+struct RVec {
+  float v[VEC];
+};
+template <int VEC>
+__device__ __forceinline__ RVec<VEC> rload(const float* p) {
+  RVec<VEC> r;
+  if (VEC == 4) {
+    const float4 x = *reinterpret_cast<const float4*>(p);
+    r.v[0] = x.x; r.v[1 % VEC] = x.y; r.v[2 % VEC] = x.z; r.v[3 % VEC] = x.w;
+  } else if (VEC == 2) {
+    const float2 x = *reinterpret_cast<const float2*>(p);
+    r.v[0] = x.x; r.v[1 % VEC] = x.y;
+  } else {
+    r.v[0] = *p;
+  }
+  return r;
+}
+template <int VEC>
+__device__ __forceinline__ void rstore(float* p, const RVec<VEC>& r) {
+  if (VEC == 4) {
+    *reinterpret_cast<float4*>(p) = make_float4(r.v[0], r.v[1 % VEC], r.v[2 % VEC], r.v[3 % VEC]);
+  } else if (VEC == 2) {
+    *reinterpret_cast<float2*>(p) = make_float2(r.v[0], r.v[1 % VEC]);
+  } else {
+    *p = r.v[0];
+  }
+}
+
 // EXPORT = true writes the coalesced gradient of one side instead of updating the tables.
-template <bool EXPORT>
+// LPR lanes own one segment (VEC floats per lane per chunk), so 64 / LPR segments are reduced and
+// updated concurrently by a wave: independent rows keep 64 / LPR times more loads in flight than
+// one-wave-per-row.  The sum over a segment is still formed entry by entry in batch order.
+template <bool EXPORT, int VEC, int LPR>
 __global__ __launch_bounds__(kBlock) void emb_rows_kernel(const UpdParams p) {
+  constexpr int GPW = kWave / LPR;  // segments per wave
   const int lane = lane_id();
+  const int grp = lane / LPR;
+  const int lig = lane % LPR;
   const uint32_t nseg = p.nseg[0];
   const uint32_t first1 = p.nseg[1];
   const float scale = p.grad_scale ? *p.grad_scale : 1.0f;
   const int D = p.D;
+  const int nchunks = (D + VEC - 1) / VEC;
   const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
   if (EXPORT && blockIdx.x == 0 && threadIdx.x == 0)
     *p.count_out = static_cast<int32_t>(p.export_side ? nseg - first1 : first1);
-  for (int64_t seg = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + threadIdx.x / kWave;
-       seg < nseg; seg += nwaves) {
-    const uint32_t start = p.seg_start[seg];
-    const uint32_t end = p.seg_start[seg + 1];
-    const uint32_t key = p.keys[start];
+  for (int64_t seg0 = (static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + threadIdx.x / kWave) * GPW;
+       seg0 < nseg; seg0 += nwaves * GPW) {
+    const int64_t seg = seg0 + grp;
+    bool active = seg < nseg;
+    uint32_t start = 0, end = 0, key = 0;
+    if (active) {
+      start = p.seg_start[seg];
+      end = p.seg_start[seg + 1];
+      key = p.keys[start];
+    }
     const int side = key >= p.split ? 1 : 0;
     const TableDesc& t = p.d[side];
-    if (EXPORT ? side != p.export_side : t.table == nullptr) continue;
+    if (EXPORT ? side != p.export_side : t.table == nullptr) active = false;
+    if (!active) end = start;
     const int64_t row = side ? key - p.split : key;
     const int64_t oseg = EXPORT ? (side ? seg - first1 : seg) : 0;
-    if (EXPORT && lane == 0) p.rows_out[oseg] = row;
-    for (int d0 = 0; d0 < D; d0 += kWave) {
-      const int d = d0 + lane;
-      const bool on = d < D;
-      float pv = 0.0f, s1 = 0.0f, s2 = 0.0f;
+    if (EXPORT && active && lig == 0) p.rows_out[oseg] = row;
+    const float* stage = active ? t.stage : nullptr;
+    for (int c0 = 0; c0 < nchunks; c0 += LPR) {
+      const int chunk = c0 + lig;
+      const bool on = active && chunk < nchunks;
+      const int64_t off = row * D + chunk * VEC;
+      RVec<VEC> pv, s1, s2, acc;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) pv.v[i] = s1.v[i] = s2.v[i] = acc.v[i] = 0.0f;
       if (!EXPORT && on) {
-        pv = t.table[row * D + d];
-        if (t.s1) s1 = t.s1[row * D + d];
-        if (t.s2) s2 = t.s2[row * D + d];
+        pv = rload<VEC>(t.table + off);
+        if (t.s1) s1 = rload<VEC>(t.s1 + off);
+        if (t.s2) s2 = rload<VEC>(t.s2 + off);
       }
-      float acc = 0.0f;
-      if (t.stage) {
-        for (uint32_t e0 = start; e0 < end; e0 += kWave) {
-          const uint32_t code = (e0 + lane < end) ? p.vals[e0 + lane] : kCodeNone;
-          unsigned long long live = __ballot(code != kCodeNone);
-          while (live) {
-            // up to four staged rows in flight, added in batch order
-            float x[4];
-            float sg[4];
-            int n = 0;
+      uint32_t e0 = start;
+      while (__any(e0 < end)) {
+        const uint32_t code = (e0 + lig < end) ? p.vals[e0 + lig] : kCodeNone;
+        const int n_here = e0 < end ? static_cast<int>(min(end - e0, static_cast<uint32_t>(LPR))) : 0;
+        for (int j0 = 0; j0 < LPR; j0 += 4) {
+          if (!__any(j0 < n_here)) break;
+          // up to four staged rows in flight per segment, added in batch order
+          RVec<VEC> x[4];
+          float sg[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              x[q] = 0.0f;
-              sg[q] = 0.0f;
-              if (live) {
-                const int l = __ffsll(static_cast<long long>(live)) - 1;
-                live &= live - 1;
-                const uint32_t c = __shfl(code, l, kWave);
-                sg[q] = (c & kCodeNeg) ? -1.0f : 1.0f;
-                if (on) x[q] = t.stage[static_cast<int64_t>(c & kCodeMask) * D + d];
-                ++n;
-              }
-            }
+          for (int q = 0; q < 4; ++q) {
+            const uint32_t c = __shfl(code, (j0 + q) % LPR, LPR);
+            const bool live = (j0 + q < LPR) && c != kCodeNone;
+            sg[q] = live ? ((c & kCodeNeg) ? -1.0f : 1.0f) : 0.0f;
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-              if (q < n) acc += sg[q] * x[q];
+            for (int i = 0; i < VEC; ++i) x[q].v[i] = 0.0f;
+            if (live && on && stage)
+              x[q] = rload<VEC>(stage + static_cast<int64_t>(c & kCodeMask) * D + chunk * VEC);
           }
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (sg[q] != 0.0f) {
+#pragma unroll
+              for (int i = 0; i < VEC; ++i) acc.v[i] += sg[q] * x[q].v[i];
+            }
+        }
+        e0 += LPR;
+      }
+      if (on) {
+        RVec<VEC> g;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) g.v[i] = acc.v[i] * scale;
+        if (EXPORT) {
+          rstore<VEC>(p.vals_out + oseg * D + chunk * VEC, g);
+        } else {
+          RVec<VEC> np;
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) np.v[i] = apply_update(t.h, pv.v[i], g.v[i], s1.v[i], s2.v[i]);
+          rstore<VEC>(t.table + off, np);
+          if (t.s1) rstore<VEC>(t.s1 + off, s1);
+          if (t.s2) rstore<VEC>(t.s2 + off, s2);
         }
       }
-      const float g = acc * scale;
-      if (EXPORT) {
-        if (on) p.vals_out[oseg * D + d] = g;
-      } else if (on) {
-        const float np = apply_update(t.h, pv, g, s1, s2);
-        t.table[row * D + d] = np;
-        if (t.s1) t.s1[row * D + d] = s1;
-        if (t.s2) t.s2[row * D + d] = s2;
-      }
     }
-    if (!EXPORT && lane == 0) {
+    if (!EXPORT && active && lig == 0) {
       if (t.row_stamp) t.row_stamp[row] = p.step;
       if (t.seg_stamp) t.seg_stamp[row] = p.step;
     }
   }
 }
 
-// bias tables: one wave per segment, lanes stride the segment, fixed-shape butterfly sum.
+// bias tables: 16 lanes per segment stride its entries, fixed-shape butterfly sum.
 // d loss / d user_bias is identically zero for every pairwise loss (the user bias cancels in
 // s+ - s-); the reference's value is only the fp32 residue of (+g) + (-g) in coalesce order, so
 // the user-bias gradient is produced as an exact 0 (stage == NULL; the row is still "touched").
 template <bool EXPORT>
 __global__ __launch_bounds__(kBlock) void bias_rows_kernel(const UpdParams p) {
+  constexpr int LPS = 16;  // lanes per segment
+  constexpr int GPW = kWave / LPS;
   const int lane = lane_id();
+  const int grp = lane / LPS;
+  const int lig = lane % LPS;
   const uint32_t nseg = p.nseg[0];
   const uint32_t first1 = p.nseg[1];
   const float scale = p.grad_scale ? *p.grad_scale : 1.0f;
   const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
   if (EXPORT && blockIdx.x == 0 && threadIdx.x == 0)
     *p.count_out = static_cast<int32_t>(p.export_side ? nseg - first1 : first1);
-  for (int64_t seg = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + threadIdx.x / kWave;
-       seg < nseg; seg += nwaves) {
-    const uint32_t start = p.seg_start[seg];
-    const uint32_t end = p.seg_start[seg + 1];
-    const uint32_t key = p.keys[start];
+  for (int64_t seg0 = (static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + threadIdx.x / kWave) * GPW;
+       seg0 < nseg; seg0 += nwaves * GPW) {
+    const int64_t seg = seg0 + grp;
+    bool active = seg < nseg;
+    uint32_t start = 0, end = 0, key = 0;
+    if (active) {
+      start = p.seg_start[seg];
+      end = p.seg_start[seg + 1];
+      key = p.keys[start];
+    }
     const int side = key >= p.split ? 1 : 0;
     const TableDesc& t = p.d[side];
-    if (EXPORT ? side != p.export_side : t.table == nullptr) continue;
+    if (EXPORT ? side != p.export_side : t.table == nullptr) active = false;
     const int64_t row = side ? key - p.split : key;
     float acc = 0.0f;
-    if (t.stage) {
-      for (uint32_t e = start + lane; e < end; e += kWave) {
+    if (active && t.stage) {
+      for (uint32_t e = start + lig; e < end; e += LPS) {
         const uint32_t c = p.vals[e];
         if (c != kCodeNone) {
           const float gv = t.stage[c & kCodeMask];
           acc += (c & kCodeNeg) ? -gv : gv;
         }
       }
-      acc = wave_sum(acc);
     }
+    acc = group_sum<LPS>(acc);
     const float g = acc * scale;
-    if (lane == 0) {
+    if (active && lig == 0) {
       if (EXPORT) {
         const int64_t oseg = side ? seg - first1 : seg;
         p.rows_out[oseg] = row;
@@ -363,6 +423,57 @@ unsigned sweep_grid(int64_t total) {
   return static_cast<unsigned>(blocks);
 }
 
+// widest vector every row start of every buffer the kernel touches is aligned for
+int rows_vec(const UpdParams& p) {
+  auto ok = [&](int v) {
+    if (p.D % v) return false;
+    const size_t a = sizeof(float) * v;
+    auto al = [&](const void* q) { return q == nullptr || reinterpret_cast<uintptr_t>(q) % a == 0; };
+    for (int i = 0; i < 2; ++i)
+      if (!(al(p.d[i].table) && al(p.d[i].s1) && al(p.d[i].s2) && al(p.d[i].stage))) return false;
+    return al(p.vals_out);
+  };
+  return ok(4) ? 4 : (ok(2) ? 2 : 1);
+}
+
+template <bool EXPORT, int VEC>
+void launch_emb_lpr(int lpr, unsigned grid, hipStream_t stream, const UpdParams& p) {
+  switch (lpr) {
+    case 1: hipLaunchKernelGGL((emb_rows_kernel<EXPORT, VEC, 1>), dim3(grid), dim3(kBlock), 0, stream, p); break;
+    case 2: hipLaunchKernelGGL((emb_rows_kernel<EXPORT, VEC, 2>), dim3(grid), dim3(kBlock), 0, stream, p); break;
+    case 4: hipLaunchKernelGGL((emb_rows_kernel<EXPORT, VEC, 4>), dim3(grid), dim3(kBlock), 0, stream, p); break;
+    case 8: hipLaunchKernelGGL((emb_rows_kernel<EXPORT, VEC, 8>), dim3(grid), dim3(kBlock), 0, stream, p); break;
+    case 16: hipLaunchKernelGGL((emb_rows_kernel<EXPORT, VEC, 16>), dim3(grid), dim3(kBlock), 0, stream, p); break;
+    case 32: hipLaunchKernelGGL((emb_rows_kernel<EXPORT, VEC, 32>), dim3(grid), dim3(kBlock), 0, stream, p); break;
+    default: hipLaunchKernelGGL((emb_rows_kernel<EXPORT, VEC, 64>), dim3(grid), dim3(kBlock), 0, stream, p); break;
+  }
+}
+
+// segs: upper bound on the number of segments
+template <bool EXPORT>
+int launch_emb(const UpdParams& p, int64_t segs, hipStream_t stream) {
+  const int vec = rows_vec(p);
+  const int nchunks = (p.D + vec - 1) / vec;
+  int lpr = 1;
+  while (lpr < nchunks && lpr < kWave) lpr *= 2;
+  const int gpw = kWave / lpr;
+  int64_t blocks = (segs + gpw * kWavesPerBlock - 1) / (gpw * kWavesPerBlock);
+  if (blocks > 4 * kUpdateBlocks) blocks = 4 * kUpdateBlocks;
+  if (blocks < 1) blocks = 1;
+  const unsigned grid = static_cast<unsigned>(blocks);
+  if (vec == 4) launch_emb_lpr<EXPORT, 4>(lpr, grid, stream, p);
+  else if (vec == 2) launch_emb_lpr<EXPORT, 2>(lpr, grid, stream, p);
+  else launch_emb_lpr<EXPORT, 1>(lpr, grid, stream, p);
+  return check_launch("emb_rows_kernel");
+}
+
+unsigned bias_grid(int64_t segs) {
+  int64_t blocks = (segs + 4 * kWavesPerBlock - 1) / (4 * kWavesPerBlock);
+  if (blocks > 4 * kUpdateBlocks) blocks = 4 * kUpdateBlocks;
+  if (blocks < 1) blocks = 1;
+  return static_cast<unsigned>(blocks);
+}
+
 void fill_sorted(UpdParams& p, const SortWs& s, int64_t nkeys, uint32_t split) {
   p.keys = sorted_keys(s, nkeys);
   p.vals = sorted_vals(s, nkeys);
@@ -422,12 +533,13 @@ extern "C" int collie_mf_train_update(const collie_mf_tables* t, const collie_mf
     touched[side] = !dense && side == COLLIE_SIDE_ITEM && cfg[side].algo == COLLIE_OPT_SPARSE_ADAM;
     if (touched[side]) d.seg_stamp = ws.seg_item;
   }
-  const unsigned grid = grid_for(3 * b->batch);
-  if (is_bias)
-    hipLaunchKernelGGL(bias_rows_kernel<false>, dim3(grid), dim3(kBlock), 0, stream, p);
-  else
-    hipLaunchKernelGGL(emb_rows_kernel<false>, dim3(grid), dim3(kBlock), 0, stream, p);
-  if (check_launch("rows_kernel")) return -2;
+  if (is_bias) {
+    hipLaunchKernelGGL(bias_rows_kernel<false>, dim3(bias_grid(3 * b->batch)), dim3(kBlock), 0,
+                       stream, p);
+    if (check_launch("bias_rows_kernel")) return -2;
+  } else if (launch_emb<false>(p, 3 * b->batch, stream)) {
+    return -2;
+  }
   for (int side = 0; side < 2; ++side) {
     const TableDesc& d = p.d[side];
     const int64_t rows = side == COLLIE_SIDE_USER ? t->num_users : t->num_items;
@@ -473,12 +585,13 @@ extern "C" int collie_mf_train_export_grad(const collie_mf_tables* t, const coll
     p.d[0].stage = ws.stage_u;
     p.d[1].stage = ws.stage_i;
   }
-  const unsigned grid = grid_for(3 * b->batch);
-  if (is_bias)
-    hipLaunchKernelGGL(bias_rows_kernel<true>, dim3(grid), dim3(kBlock), 0, stream, p);
-  else
-    hipLaunchKernelGGL(emb_rows_kernel<true>, dim3(grid), dim3(kBlock), 0, stream, p);
-  if (check_launch("export_grad")) return -2;
+  if (is_bias) {
+    hipLaunchKernelGGL(bias_rows_kernel<true>, dim3(bias_grid(3 * b->batch)), dim3(kBlock), 0,
+                       stream, p);
+    if (check_launch("export_grad")) return -2;
+  } else if (launch_emb<true>(p, 3 * b->batch, stream)) {
+    return -2;
+  }
   if (touched_out && side == COLLIE_SIDE_ITEM) {
     hipLaunchKernelGGL(export_touched_kernel,
                        dim3(static_cast<unsigned>((t->num_items + kBlock - 1) / kBlock)),
@@ -530,9 +643,9 @@ extern "C" int collie_sparse_rows_update(float* table, int64_t num_rows, int32_t
   COLLIE_REQUIRE(cfg->algo != COLLIE_OPT_ADAM,
                  "Adam does not support sparse gradients, please consider SparseAdam instead");
   if (make_hyper(d.h, cfg, 0, true, d.s1, d.s2)) return -1;
-  if (dim == 1)
-    hipLaunchKernelGGL(bias_rows_kernel<false>, dim3(grid_for(m)), dim3(kBlock), 0, stream, p);
-  else
-    hipLaunchKernelGGL(emb_rows_kernel<false>, dim3(grid_for(m)), dim3(kBlock), 0, stream, p);
-  return check_launch("sparse_rows_update");
+  if (dim == 1) {
+    hipLaunchKernelGGL(bias_rows_kernel<false>, dim3(bias_grid(m)), dim3(kBlock), 0, stream, p);
+    return check_launch("sparse_rows_update");
+  }
+  return launch_emb<false>(p, m, stream);
 }
