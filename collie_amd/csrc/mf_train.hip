@@ -306,6 +306,278 @@ __global__ __launch_bounds__(kBlock) void mf_train_fwd_kernel(const FwdParams p)
   }
 }
 
+// ---- DPP reductions: one VALU instruction per butterfly step inside a 16-lane row ---------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int o = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false);
+  return v + __int_as_float(o);
+}
+// sum over LPR consecutive lanes; every lane of the group receives the total
+template <int LPR>
+__device__ __forceinline__ float group_sum_dpp(float v) {
+  if (LPR >= 2) v = dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
+  if (LPR >= 4) v = dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
+  if (LPR >= 8) v = dpp_add<0x141>(v);   // row_half_mirror
+  if (LPR >= 16) v = dpp_add<0x140>(v);  // row_mirror
+  if (LPR >= 32) v += __shfl_xor(v, 16, kWave);
+  if (LPR >= 64) v += __shfl_xor(v, 32, kWave);
+  return v;
+}
+
+struct FastIds {
+  int64_t u;       // wave-uniform (scalar loads)
+  int64_t pos;     // wave-uniform
+  int64_t neg[4];  // per lane group: negative j - 1 of pass
+};
+
+// STD: the loaders' dtypes (users / pos int32, negatives int64) -> no dtype dispatch in the loop
+template <int LPR, int NP, bool STD>
+__device__ __forceinline__ FastIds load_fast_ids(const FwdParams& p, int64_t b, int grp, int K) {
+  constexpr int RPW = kWave / LPR;
+  FastIds s;
+  // b is wave-uniform, but the prefetched ids must stay in VGPRs until they are used one
+  // iteration later (an eager v_readfirstlane would put a full s_waitcnt vmcnt(0) right behind
+  // the prefetch): hide the uniformity of the address from the compiler.
+  int64_t zero = 0;
+  asm volatile("" : "+v"(zero));
+  const int64_t bv = b + zero;
+  if (STD) {
+    s.u = static_cast<const int32_t*>(p.b.users)[bv];
+    s.pos = static_cast<const int32_t*>(p.b.pos_items)[bv];
+  } else {
+    s.u = load_idx(p.b.users, p.b.users_dtype, bv);
+    s.pos = load_idx(p.b.pos_items, p.b.pos_dtype, bv);
+  }
+#pragma unroll
+  for (int pass = 0; pass < NP; ++pass) {
+    int j = pass * RPW + grp;
+    j = j < 1 ? 1 : (j > K ? K : j);  // clamped: rows outside 1..K are masked later
+    const int64_t off = b * p.b.neg_stride_b + static_cast<int64_t>(j - 1) * p.b.neg_stride_k;
+    s.neg[pass] = STD ? static_cast<const int64_t*>(p.b.neg_items)[off]
+                      : load_idx(p.b.neg_items, p.b.neg_dtype, off);
+  }
+  return s;
+}
+
+// Fast path of K1 (dim <= LPR * VEC, 1 + K <= NPASS * 64 / LPR): row j of a sample (0 = positive,
+// 1..K = negatives) belongs to lane group j % RPW in pass j / RPW and never leaves it: every lane
+// of the group holds the row's id, dot product, bias and score, so the loss selection is a few
+// compare-selects per lane plus log2(RPW) cross-group steps.  All 1 + K rows are in flight together.
+template <int VEC, int LPR, int NPASS, bool STD, bool META>
+__global__ __launch_bounds__(kBlock) void mf_train_fwd_fast(const FwdParams p) {
+  constexpr int RPW = kWave / LPR;
+  const int lane = lane_id();
+  const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);  // scalar
+  const int grp = lane / LPR;
+  const int lig = lane % LPR;
+  const int K = p.b.num_neg;
+  const int D = p.t.dim;
+  const int64_t B = p.b.batch;
+  const bool my_chunk = lig < p.nchunks;
+  const int kind = p.loss.kind;
+  const bool warp_kind = kind == COLLIE_LOSS_WARP;
+  const bool bpr_kind = kind == COLLIE_LOSS_BPR || kind == COLLIE_LOSS_ADAPTIVE_BPR;
+  const uint32_t key_off = static_cast<uint32_t>(p.t.num_users);
+  const int n_meta = META ? p.loss.n_meta : 0;
+
+  float loss1 = 0.0f, loss2 = 0.0f;
+
+  const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+  int64_t b = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave_in_block;
+  FastIds next;
+  if (b < B) next = load_fast_ids<LPR, NPASS, STD>(p, b, grp, K);
+  for (; b < B; b += nwaves) {
+    const FastIds cur = next;
+    if (b + nwaves < B) next = load_fast_ids<LPR, NPASS, STD>(p, b + nwaves, grp, K);
+    // ids are < 2^31 (validated): scalarise them now that they are needed
+    const int64_t u = cur.u < 0 || cur.u > 0x7fffffff
+                          ? -1
+                          : __builtin_amdgcn_readfirstlane(static_cast<int>(cur.u));
+    const int64_t pos64 = cur.pos < 0 || cur.pos > 0x7fffffff
+                              ? -1
+                              : __builtin_amdgcn_readfirstlane(static_cast<int>(cur.pos));
+    bool bad_lane = false;
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass)
+      bad_lane |= cur.neg[pass] < 0 || cur.neg[pass] >= p.t.num_items;
+    const bool bad = (u < 0 || u >= p.t.num_users) || (pos64 < 0 || pos64 >= p.t.num_items) ||
+                     (__ballot(bad_lane) != 0ull);
+    if (bad) {  // wave-uniform: never touch memory through a bad id
+      if (lane == 0 && p.status) atomicOr(p.status, 1);
+      if (p.need_grad && lane < 3) {
+        const int64_t slot = lane == 0 ? b : B + 2 * b + (lane - 1);
+        p.ws.sort.ekeys[slot] = lane == 0 ? 0u : key_off;
+        p.ws.sort.ecodes[slot] = kCodeNone;
+        if (lane == 0) p.ws.gcoef[b] = 0.0f;
+      }
+      continue;
+    }
+
+    // ---- gathers: user row once, all 1+K item rows (+ biases) in flight ---------------------
+    const float ub = p.t.user_bias[u];
+    Vec<VEC> uvec = vzero<VEC>();
+    if (my_chunk) uvec = vload<VEC>(p.t.user_emb + u * D + lig * VEC);
+    Vec<VEC> iv[NPASS];
+    float ib[NPASS];
+    int item[NPASS];
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+      const int j = pass * RPW + grp;
+      item[pass] = static_cast<int>(j == 0 ? pos64 : cur.neg[pass]);
+      // rows past K re-read negative K (ids are clamped): no exec masking around the loads
+      ib[pass] = p.t.item_bias[item[pass]];
+      iv[pass] = vzero<VEC>();
+      if (my_chunk)
+        iv[pass] = vload<VEC>(p.t.item_emb + static_cast<int64_t>(item[pass]) * D + lig * VEC);
+    }
+    float s[NPASS];
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass)
+      s[pass] = (group_sum_dpp<LPR>(vdot<VEC>(uvec, iv[pass])) + ub) + ib[pass];
+
+    const float sp =  // row 0 lives on lane 0
+        __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s[0])));
+    const int pos_item = static_cast<int>(pos64);
+
+    // ---- candidate selection inside the lane, then across the RPW lane groups ----------------
+    // adaptive / plain: highest negative score, lowest j on ties (torch.max).
+    // warp: lowest j with c_j - s+ + s_j > 0 (warp.py:143-152).
+    float best_v = -INFINITY;  // negative score (adaptive) or h (warp) of the candidate
+    float best_c = 1.0f;
+    int best_j = 0x7fffffff;
+    int best_item = 0;
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+      const int j = pass * RPW + grp;
+      float c = 1.0f;
+      if (META && j >= 1 && j <= K) {
+        float frac = 0.0f;
+        for (int m = 0; m < n_meta; ++m)
+          frac += (p.loss.meta[m][pos_item] == p.loss.meta[m][item[pass]]) ? p.loss.meta_weight[m]
+                                                                           : 0.0f;
+        c = 1.0f - frac;
+      }
+      const float v = warp_kind ? (c - sp) + s[pass] : s[pass];
+      const bool cand = j >= 1 && j <= K &&
+                        (warp_kind ? (v > 0.0f && best_j == 0x7fffffff) : (v > best_v));
+      if (cand) {
+        best_v = v;
+        best_c = c;
+        best_j = j;
+        best_item = item[pass];
+      }
+    }
+#pragma unroll
+    for (int off = LPR; off < kWave; off <<= 1) {
+      const float ov = __shfl_xor(best_v, off, kWave);
+      const int oj = __shfl_xor(best_j, off, kWave);
+      const int oi = __shfl_xor(best_item, off, kWave);
+      float oc = 1.0f;
+      if (META) oc = __shfl_xor(best_c, off, kWave);
+      const bool take = warp_kind ? (oj < best_j) : (ov > best_v || (ov == best_v && oj < best_j));
+      if (take) {
+        best_v = ov;
+        best_c = oc;
+        best_j = oj;
+        best_item = oi;
+      }
+    }
+    // every lane now holds the same (best_v, best_c, best_j, best_item)
+    int sel = best_j == 0x7fffffff ? 1 : best_j;
+    float ell = 0.0f, g = 0.0f;
+    if (warp_kind) {
+      if (best_j != 0x7fffffff) {
+        const float w = logf(static_cast<float>(p.loss.num_items) / static_cast<float>(sel));
+        ell = w * best_v;
+        g = -(w * (1.0f + 2.0f * ell)) * p.inv_b;
+      }
+    } else {
+      const float d = sp - best_v;
+      if (bpr_kind) {
+        const float sig = sigmoidf_(d);
+        ell = best_c - sig;
+        g = -(sig * (1.0f - sig)) * (1.0f + 2.0f * ell) * p.inv_b;
+      } else {
+        const float x = best_c - d;
+        ell = fmaxf(x, 0.0f);
+        g = x >= 0.0f ? -(1.0f + 2.0f * ell) * p.inv_b : 0.0f;  // clamp passes grad at the kink
+      }
+    }
+    loss1 += ell;
+    loss2 += ell * ell;
+
+    if (p.s_pos_out || p.s_neg_out) {
+#pragma unroll
+      for (int pass = 0; pass < NPASS; ++pass) {
+        const int j = pass * RPW + grp;
+        if (lig == 0 && j <= K) {
+          if (j == 0) {
+            if (p.s_pos_out) p.s_pos_out[b] = s[pass];
+          } else if (p.s_neg_out) {
+            p.s_neg_out[static_cast<int64_t>(j - 1) * B + b] = s[pass];
+          }
+        }
+      }
+    }
+    if (!p.need_grad) continue;
+
+    // ---- backward staging ---------------------------------------------------------------------
+    const bool live = g != 0.0f;
+    if (best_j == 0x7fffffff) {
+      // no candidate (warp without violation): the "selected" row is negative 1, gradient 0
+      best_item = __shfl(item[(1 / RPW) % NPASS], (1 % RPW) * LPR, kWave);
+    }
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass)
+      if (lig == 0 && pass * RPW + grp <= K) p.ws.touch_item[item[pass]] = p.step_id;
+    if (lane < 3) {  // lane 0: user entry, lane 1: positive item, lane 2: selected negative
+      const int64_t slot = lane == 0 ? b : B + 2 * b + (lane - 1);
+      const uint32_t key =
+          lane == 0 ? static_cast<uint32_t>(u)
+                    : key_off + static_cast<uint32_t>(lane == 1 ? pos_item : best_item);
+      p.ws.sort.ekeys[slot] = key;
+      p.ws.sort.ecodes[slot] =
+          live ? (static_cast<uint32_t>(b) | (lane == 2 ? kCodeNeg : 0u)) : kCodeNone;
+      if (lane == 0) p.ws.gcoef[b] = g;
+    }
+    if (!live) continue;
+    // the selected negative's row is in registers: pass sel / RPW, lane group sel % RPW
+    Vec<VEC> pick = iv[0];
+#pragma unroll
+    for (int pass = 1; pass < NPASS; ++pass)
+      if (sel / RPW == pass) pick = iv[pass];
+    Vec<VEC> isel;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) isel.v[i] = __shfl(pick.v[i], (sel % RPW) * LPR + lig, kWave);
+    if (grp == 0 && my_chunk) {
+      Vec<VEC> gu, gi;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        gu.v[i] = g * iv[0].v[i] - g * isel.v[i];
+        gi.v[i] = g * uvec.v[i];
+      }
+      vstore<VEC>(p.ws.stage_u + b * D + lig * VEC, gu);
+      vstore<VEC>(p.ws.stage_i + b * D + lig * VEC, gi);
+    }
+  }
+
+  __shared__ float red[2][kWavesPerBlock];
+  if (lane == 0) {
+    red[0][wave_in_block] = loss1;
+    red[1][wave_in_block] = loss2;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = 0.0f, c2 = 0.0f;
+    for (int w = 0; w < kWavesPerBlock; ++w) {
+      a += red[0][w];
+      c2 += red[1][w];
+    }
+    p.ws.loss_partials[2 * blockIdx.x] = a;
+    p.ws.loss_partials[2 * blockIdx.x + 1] = c2;
+  }
+}
+
 // loss = (sum l + sum l^2) / B   (bpr.py:89, hinge.py:85, warp.py:133); fixed-order reduction
 __global__ __launch_bounds__(kBlock) void loss_finalize_kernel(const float* partials, int nblocks,
                                                                float inv_b, float* loss_out) {
@@ -334,29 +606,56 @@ __global__ __launch_bounds__(kBlock) void loss_finalize_kernel(const float* part
   }
 }
 
-template <int VEC, int LPR>
-int launch_fwd_np(int np, dim3 grid, hipStream_t stream, const FwdParams& p) {
+template <int LPR, int NP>
+void launch_fast(bool std_ids, bool meta, dim3 grid, hipStream_t stream, const FwdParams& p) {
+  if (std_ids && !meta)
+    hipLaunchKernelGGL((mf_train_fwd_fast<4, LPR, NP, true, false>), grid, dim3(kBlock), 0, stream, p);
+  else if (std_ids)
+    hipLaunchKernelGGL((mf_train_fwd_fast<4, LPR, NP, true, true>), grid, dim3(kBlock), 0, stream, p);
+  else if (!meta)
+    hipLaunchKernelGGL((mf_train_fwd_fast<4, LPR, NP, false, false>), grid, dim3(kBlock), 0, stream, p);
+  else
+    hipLaunchKernelGGL((mf_train_fwd_fast<4, LPR, NP, false, true>), grid, dim3(kBlock), 0, stream, p);
+}
+
+template <int LPR>
+void launch_fast_np(int np, bool std_ids, bool meta, dim3 grid, hipStream_t stream,
+                    const FwdParams& p) {
   switch (np) {
-    case 1: hipLaunchKernelGGL((mf_train_fwd_kernel<VEC, LPR, 1>), grid, dim3(kBlock), 0, stream, p); break;
-    case 2: hipLaunchKernelGGL((mf_train_fwd_kernel<VEC, LPR, 2>), grid, dim3(kBlock), 0, stream, p); break;
-    case 3: hipLaunchKernelGGL((mf_train_fwd_kernel<VEC, LPR, 3>), grid, dim3(kBlock), 0, stream, p); break;
-    case 4: hipLaunchKernelGGL((mf_train_fwd_kernel<VEC, LPR, 4>), grid, dim3(kBlock), 0, stream, p); break;
-    default: hipLaunchKernelGGL((mf_train_fwd_kernel<VEC, LPR, 0>), grid, dim3(kBlock), 0, stream, p); break;
+    case 1: launch_fast<LPR, 1>(std_ids, meta, grid, stream, p); break;
+    case 2: launch_fast<LPR, 2>(std_ids, meta, grid, stream, p); break;
+    case 3: launch_fast<LPR, 3>(std_ids, meta, grid, stream, p); break;
+    default: launch_fast<LPR, 4>(std_ids, meta, grid, stream, p); break;
   }
-  return check_launch("mf_train_fwd_kernel");
+}
+
+// fast path: float4 rows (dim % 4 == 0), 16 <= dim <= 256, at most 4 gather passes
+int launch_fwd_fast(int lpr, int np, dim3 grid, hipStream_t stream, const FwdParams& p) {
+  const bool std_ids = p.b.users_dtype == COLLIE_I32 && p.b.pos_dtype == COLLIE_I32 &&
+                       p.b.neg_dtype == COLLIE_I64;
+  const bool meta = p.loss.n_meta > 0;
+  switch (lpr) {
+    case 4: launch_fast_np<4>(np, std_ids, meta, grid, stream, p); break;
+    case 8: launch_fast_np<8>(np, std_ids, meta, grid, stream, p); break;
+    case 16: launch_fast_np<16>(np, std_ids, meta, grid, stream, p); break;
+    case 32: launch_fast_np<32>(np, std_ids, meta, grid, stream, p); break;
+    default: launch_fast_np<64>(np, std_ids, meta, grid, stream, p); break;
+  }
+  return check_launch("mf_train_fwd_fast");
 }
 
 template <int VEC>
-int launch_fwd(int lpr, int np, dim3 grid, hipStream_t stream, const FwdParams& p) {
+int launch_fwd(int lpr, dim3 grid, hipStream_t stream, const FwdParams& p) {
   switch (lpr) {
-    case 1: return launch_fwd_np<VEC, 1>(np, grid, stream, p);
-    case 2: return launch_fwd_np<VEC, 2>(np, grid, stream, p);
-    case 4: return launch_fwd_np<VEC, 4>(np, grid, stream, p);
-    case 8: return launch_fwd_np<VEC, 8>(np, grid, stream, p);
-    case 16: return launch_fwd_np<VEC, 16>(np, grid, stream, p);
-    case 32: return launch_fwd_np<VEC, 32>(np, grid, stream, p);
-    default: return launch_fwd_np<VEC, 64>(np, grid, stream, p);
+    case 1: hipLaunchKernelGGL((mf_train_fwd_kernel<VEC, 1, 0>), grid, dim3(kBlock), 0, stream, p); break;
+    case 2: hipLaunchKernelGGL((mf_train_fwd_kernel<VEC, 2, 0>), grid, dim3(kBlock), 0, stream, p); break;
+    case 4: hipLaunchKernelGGL((mf_train_fwd_kernel<VEC, 4, 0>), grid, dim3(kBlock), 0, stream, p); break;
+    case 8: hipLaunchKernelGGL((mf_train_fwd_kernel<VEC, 8, 0>), grid, dim3(kBlock), 0, stream, p); break;
+    case 16: hipLaunchKernelGGL((mf_train_fwd_kernel<VEC, 16, 0>), grid, dim3(kBlock), 0, stream, p); break;
+    case 32: hipLaunchKernelGGL((mf_train_fwd_kernel<VEC, 32, 0>), grid, dim3(kBlock), 0, stream, p); break;
+    default: hipLaunchKernelGGL((mf_train_fwd_kernel<VEC, 64, 0>), grid, dim3(kBlock), 0, stream, p); break;
   }
+  return check_launch("mf_train_fwd_kernel");
 }
 
 }  // namespace
@@ -439,16 +738,17 @@ extern "C" int collie_mf_train_forward(const collie_mf_tables* t, const collie_m
   int lpr = 1;
   while (lpr < p.nchunks && lpr < kWave) lpr *= 2;
   const int rpw = kWave / lpr;
-  int np = (b->num_neg + 1 + rpw - 1) / rpw;
-  if (p.nchunks > lpr || np > 4) np = 0;  // generic loop
+  const int np = (b->num_neg + 1 + rpw - 1) / rpw;
+  const bool fast = vec == 4 && lpr >= 4 && p.nchunks <= lpr && np <= 4;
 
   int64_t nblocks = (b->batch + kWavesPerBlock - 1) / kWavesPerBlock;
   if (nblocks > kMaxLossBlocks) nblocks = kMaxLossBlocks;
   dim3 grid(static_cast<unsigned>(nblocks));
   int rc;
-  if (vec == 4) rc = launch_fwd<4>(lpr, np, grid, stream, p);
-  else if (vec == 2) rc = launch_fwd<2>(lpr, np, grid, stream, p);
-  else rc = launch_fwd<1>(lpr, np, grid, stream, p);
+  if (fast) rc = launch_fwd_fast(lpr, np, grid, stream, p);
+  else if (vec == 4) rc = launch_fwd<4>(lpr, grid, stream, p);
+  else if (vec == 2) rc = launch_fwd<2>(lpr, grid, stream, p);
+  else rc = launch_fwd<1>(lpr, grid, stream, p);
   if (rc) return rc;
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(kBlock), 0, stream, ws.loss_partials,
                      static_cast<int>(nblocks), p.inv_b, loss_out);
