@@ -67,6 +67,7 @@ struct EvalParams {
   const int64_t* user_ids;
   int64_t n_users;
   int64_t item_begin, item_end;
+  int64_t id_stride, id_offset;  // global item id = local row * id_stride + id_offset
   int tiles_per_chunk;
   int nchunks;
   int k;
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(kBlock) void eval_gemm_kernel(const EvalParams p) {
           if (in && s > top_s[kCap - 1]) {
             // insertion into the sorted list (rare after warm-up; divergent lanes wait)
             float cs = s;
-            int ci = static_cast<int>(item);
+            int ci = static_cast<int>(item * p.id_stride + p.id_offset);
 #pragma unroll
             for (int i = 0; i < kCap; ++i) {
               const bool better = cs > top_s[i];
@@ -207,7 +208,8 @@ __global__ __launch_bounds__(kBlock) void eval_gemm_kernel(const EvalParams p) {
             }
           }
         } else if (in && user_ok) {
-          c_above += (s > bscore || (s == bscore && item < bid)) ? 1ull : 0ull;
+          const int64_t gid = item * p.id_stride + p.id_offset;
+          c_above += (s > bscore || (s == bscore && gid < bid)) ? 1ull : 0ull;
           for (int64_t e = e_begin; e < e_end; ++e) {
             c_lt += s < p.thr_lo[e] ? 1ull : 0ull;
             c_le += s <= p.thr_hi[e] ? 1ull : 0ull;
@@ -283,8 +285,8 @@ __global__ __launch_bounds__(kBlock) void merge_topk_kernel(const float* __restr
 __global__ __launch_bounds__(kBlock) void pos_scores_kernel(
     const collie_mf_tables t, const int64_t* __restrict__ user_ids, int64_t n_users,
     const int64_t* __restrict__ indptr, const int64_t* __restrict__ indices, int D8, int has_y,
-    float y_lo, float y_hi, float* __restrict__ pos_scores, float* __restrict__ thr_lo,
-    float* __restrict__ thr_hi) {
+    float y_lo, float y_hi, int compute, int64_t id_stride, int64_t id_offset,
+    float* __restrict__ pos_scores, float* __restrict__ thr_lo, float* __restrict__ thr_hi) {
   const int64_t nnz = indptr[n_users];
   const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
   for (int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; e < nnz; e += stride) {
@@ -294,15 +296,24 @@ __global__ __launch_bounds__(kBlock) void pos_scores_kernel(
       const int64_t mid = (lo + hi) / 2;
       if (indptr[mid] <= e) lo = mid; else hi = mid;
     }
-    int64_t uid = user_ids[lo];
-    int64_t item = indices[e];
-    if (uid < 0) uid = 0;
-    if (uid >= t.num_users) uid = t.num_users - 1;
-    if (item < 0) item = 0;
-    if (item >= t.num_items) item = t.num_items - 1;
-    const float dot = chain_dot(t.user_emb + uid * t.dim, t.item_emb + item * t.dim, t.dim, D8);
-    const float s = finish_score(dot, t.user_bias[uid], t.item_bias[item]);
-    pos_scores[e] = s;
+    float s;
+    if (compute) {
+      int64_t uid = user_ids[lo];
+      if (uid < 0) uid = 0;
+      if (uid >= t.num_users) uid = t.num_users - 1;
+      // global item id -> row of this shard (rows of other shards contribute 0: all-reduced later)
+      const int64_t rel = indices[e] - id_offset;
+      const int64_t item = rel / id_stride;
+      if (rel >= 0 && rel % id_stride == 0 && item < t.num_items) {
+        const float dot = chain_dot(t.user_emb + uid * t.dim, t.item_emb + item * t.dim, t.dim, D8);
+        s = finish_score(dot, t.user_bias[uid], t.item_bias[item]);
+      } else {
+        s = 0.0f;
+      }
+      pos_scores[e] = s;
+    } else {
+      s = pos_scores[e];
+    }
     if (thr_lo) {
       // [lo, hi] = the raw-score interval whose sigmoid(preds) equals this positive's
       // (metrics.py:277 ranks sigmoid(preds) in fp32, which ties scores the raw values do not)
@@ -477,13 +488,17 @@ extern "C" size_t collie_mf_eval_workspace_bytes(int64_t n_users, int64_t n_item
 
 extern "C" int collie_mf_eval_topk(const collie_mf_tables* t, const int64_t* user_ids,
                                    int64_t n_users, int64_t item_begin, int64_t item_end,
-                                   int32_t k, int32_t has_y_range, float y_lo, float y_hi,
+                                   int64_t id_stride, int64_t id_offset, int32_t k,
+                                   int32_t has_y_range, float y_lo, float y_hi,
                                    float* topk_scores, int64_t* topk_ids, void* workspace,
                                    size_t workspace_bytes, collie_stream_t stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   if (validate_tables(t) || check_range(t, n_users, item_begin, item_end)) return -1;
   COLLIE_REQUIRE(user_ids && topk_scores && topk_ids, "eval_topk: NULL pointer");
   COLLIE_REQUIRE(k >= 1 && k <= kCap, "eval_topk: k must be in [1, %d] (got %d)", kCap, k);
+  COLLIE_REQUIRE(id_stride >= 1 && id_offset >= 0 &&
+                     (item_end - 1) * id_stride + id_offset < (int64_t{1} << 31),
+                 "eval_topk: bad global id mapping");
   COLLIE_REQUIRE(k <= item_end - item_begin, "eval_topk: k (%d) exceeds the number of items", k);
   EvalWs ws = carve_eval_ws(workspace, n_users, item_end - item_begin);
   COLLIE_REQUIRE(workspace && workspace_bytes >= ws.bytes,
@@ -495,6 +510,8 @@ extern "C" int collie_mf_eval_topk(const collie_mf_tables* t, const int64_t* use
   p.n_users = n_users;
   p.item_begin = item_begin;
   p.item_end = item_end;
+  p.id_stride = id_stride;
+  p.id_offset = id_offset;
   p.tiles_per_chunk = ws.tiles_per_chunk;
   p.nchunks = ws.nchunks;
   p.k = k;
@@ -526,20 +543,23 @@ extern "C" int collie_mf_eval_merge_topk(const float* cand_scores, const int32_t
 extern "C" int collie_mf_eval_pos_scores(const collie_mf_tables* t, const int64_t* user_ids,
                                          int64_t n_users, const int64_t* indptr,
                                          const int64_t* indices, int64_t nnz, int32_t has_y_range,
-                                         float y_lo, float y_hi, float* pos_scores, float* thr_lo,
-                                         float* thr_hi, float* best_score, int64_t* best_id,
-                                         collie_stream_t stream_) {
+                                         float y_lo, float y_hi, int32_t compute_scores,
+                                         int64_t id_stride, int64_t id_offset, float* pos_scores,
+                                         float* thr_lo, float* thr_hi, float* best_score,
+                                         int64_t* best_id, collie_stream_t stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   if (validate_tables(t)) return -1;
   COLLIE_REQUIRE(user_ids && indptr && indices && pos_scores, "eval_pos_scores: NULL pointer");
-  COLLIE_REQUIRE(n_users >= 1 && nnz >= 0, "eval_pos_scores: bad sizes");
+  COLLIE_REQUIRE(n_users >= 1 && nnz >= 0 && id_stride >= 1 && id_offset >= 0,
+                 "eval_pos_scores: bad sizes");
   COLLIE_REQUIRE(t->dim <= 256, "embedding_dim > 256 is not supported by the MFMA evaluator");
   if (nnz > 0) {
     int64_t blocks = (nnz + kBlock - 1) / kBlock;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(pos_scores_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0,
                        stream, *t, user_ids, n_users, indptr, indices, d8_bucket(t->dim),
-                       has_y_range, y_lo, y_hi, pos_scores, thr_lo, thr_hi);
+                       has_y_range, y_lo, y_hi, compute_scores, id_stride, id_offset, pos_scores,
+                       thr_lo, thr_hi);
     if (check_launch("pos_scores_kernel")) return -2;
   }
   if (best_score && best_id) {
@@ -555,7 +575,8 @@ extern "C" int collie_mf_eval_rank_counts(const collie_mf_tables* t, const int64
                                           int64_t n_users, const int64_t* indptr,
                                           const float* thr_lo, const float* thr_hi,
                                           const float* best_score, const int64_t* best_id,
-                                          int64_t item_begin, int64_t item_end, uint64_t* counts,
+                                          int64_t item_begin, int64_t item_end, int64_t id_stride,
+                                          int64_t id_offset, uint64_t* counts,
                                           collie_stream_t stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   if (validate_tables(t) || check_range(t, n_users, item_begin, item_end)) return -1;
@@ -569,6 +590,8 @@ extern "C" int collie_mf_eval_rank_counts(const collie_mf_tables* t, const int64
   p.n_users = n_users;
   p.item_begin = item_begin;
   p.item_end = item_end;
+  p.id_stride = id_stride;
+  p.id_offset = id_offset;
   p.tiles_per_chunk = ws.tiles_per_chunk;
   p.nchunks = ws.nchunks;
   p.k = 1;

@@ -259,7 +259,7 @@ class EvalWorkspace:
         return self.buf
 
 
-def eval_topk(tables, user_ids, item_begin, item_end, k, y_range, ws):
+def eval_topk(tables, user_ids, item_begin, item_end, k, y_range, ws, id_stride=1, id_offset=0):
     """(scores [n, k] float32, ids [n, k] int64): descending score, ascending id on ties."""
     require_hip(user_ids, 'user_ids')
     assert user_ids.dtype == torch.int64 and user_ids.is_contiguous()
@@ -269,17 +269,20 @@ def eval_topk(tables, user_ids, item_begin, item_end, k, y_range, ws):
     scores = torch.empty(n, k, dtype=torch.float32, device=dev)
     ids = torch.empty(n, k, dtype=torch.int64, device=dev)
     has_y, lo, hi = _y(y_range)
-    check(load().collie_mf_eval_topk(byref(tables), ptr(user_ids), n, item_begin, item_end, k,
-                                     has_y, lo, hi, ptr(scores), ptr(ids), ptr(buf), buf.numel(),
-                                     stream_ptr()), 'collie_mf_eval_topk')
+    check(load().collie_mf_eval_topk(byref(tables), ptr(user_ids), n, item_begin, item_end,
+                                     id_stride, id_offset, k, has_y, lo, hi, ptr(scores),
+                                     ptr(ids), ptr(buf), buf.numel(), stream_ptr()),
+          'collie_mf_eval_topk')
     return scores, ids
 
 
-def eval_pos_scores(tables, user_ids, indptr, indices, y_range, want_thresholds):
+def eval_pos_scores(tables, user_ids, indptr, indices, y_range, want_thresholds, id_stride=1,
+                    id_offset=0, given_scores=None):
     n = user_ids.shape[0]
     nnz = indices.shape[0]
     dev = user_ids.device
-    pos = torch.empty(max(nnz, 1), dtype=torch.float32, device=dev)
+    pos = given_scores if given_scores is not None else torch.empty(
+        max(nnz, 1), dtype=torch.float32, device=dev)
     lo = hi = best_s = best_id = None
     if want_thresholds:
         lo = torch.empty(max(nnz, 1), dtype=torch.float32, device=dev)
@@ -289,16 +292,18 @@ def eval_pos_scores(tables, user_ids, indptr, indices, y_range, want_thresholds)
     has_y, ylo, yhi = _y(y_range)
     check(load().collie_mf_eval_pos_scores(
         byref(tables), ptr(user_ids), n, ptr(indptr), ptr(indices), nnz, has_y, ylo, yhi,
-        ptr(pos), ptr(lo), ptr(hi), ptr(best_s), ptr(best_id), stream_ptr()),
+        0 if given_scores is not None else 1, id_stride, id_offset, ptr(pos), ptr(lo), ptr(hi),
+        ptr(best_s), ptr(best_id), stream_ptr()),
         'collie_mf_eval_pos_scores')
     return pos, lo, hi, best_s, best_id
 
 
 def eval_rank_counts(tables, user_ids, indptr, lo, hi, best_s, best_id, item_begin, item_end,
-                     counts):
+                     counts, id_stride=1, id_offset=0):
     check(load().collie_mf_eval_rank_counts(
         byref(tables), ptr(user_ids), user_ids.shape[0], ptr(indptr), ptr(lo), ptr(hi),
-        ptr(best_s), ptr(best_id), item_begin, item_end, ptr(counts), stream_ptr()),
+        ptr(best_s), ptr(best_id), item_begin, item_end, id_stride, id_offset, ptr(counts),
+        stream_ptr()),
         'collie_mf_eval_rank_counts')
 
 

@@ -1,0 +1,573 @@
+"""
+Row-sharded training and catalog-sharded evaluation of the matrix-factorization path over the GPUs
+of one node (the reference has no multi-GPU path for these tables, so the semantics
+below are those of ONE ``MatrixFactorizationModel`` trained on the concatenation of the ranks'
+batches: ``base_pipeline.py:603-634`` for the loss, ``torch.optim.SparseAdam`` / ``Adagrad`` / ``SGD``
+on the coalesced sparse gradient for the update, ``metrics.py:285-395`` for evaluation).
+
+Layout.  One process per GPU.  Global row ``r`` of a table lives on rank ``r mod G`` at local row
+``r div G`` (round robin: balanced under Zipf-distributed ids).  A rank keeps its user rows and its
+item rows in ONE combined table ``emb [U_loc + N_loc, D]`` (user rows first) with a parallel
+``bias [U_loc + N_loc]`` and parallel optimizer state, so that a request for rows of both kinds is one
+gather and the owner-side optimizer step is one ``collie_sparse_rows_update`` call.
+
+Training step on a rank (``train_step``), for its slice of the global batch:
+  1. unique user ids and unique item ids of the slice (positives and all K negatives), ordered by
+     (owner, kind, id): that order IS the compact row numbering of the step;
+  2. all-to-all of the per-peer counts, then of the requested local row numbers;
+  3. owners gather the rows; all-to-all of embedding rows and bias values back.  The requester now
+     holds compact tables ``[n, D]`` / ``[n]`` in its compact numbering;
+  4. the fused forward kernel (``collie_mf_train_forward``) runs on the compact tables and compact
+     ids; the segment kernels reduce the staged rows into ``[n, D]`` / ``[n]`` gradient buffers
+     (``collie_mf_train_update`` with SGD, lr = -1, on zero-filled buffers: ``0 + 1 * g``), scaled by
+     ``B_local / B_global`` so that the sum over ranks is the gradient of the global-batch loss;
+  5. all-to-all of the gradient rows back to the owners along the same routes (every looked-up row
+     travels, zero-gradient rows included: SparseAdam decays their moments);
+  6. owners coalesce what the requesters sent (rank order, deterministic) and update their rows.
+There is no float atomic and every row has exactly one writer.  The loss returned is the
+global-batch loss: all-reduce of ``loss_local * B_local / B_global``.
+
+Evaluation (``evaluate_in_batches``): every rank scores the same group of users against ITS item
+rows (``id_stride = G, id_offset = rank`` in the eval kernels), emits its local top-k with global
+ids, the scores of the positives it owns and the rank counters over its rows; an all-gather of
+G x k candidates per user followed by ``collie_mf_eval_merge_topk``, and two sum all-reduces
+(positive scores: exact, every other rank contributes 0.0; integer counters) finish the metrics.
+
+The index plumbing (``torch.unique``, stable ``argsort``, ``index_select``) and the collectives
+are torch calls; all floating-point arithmetic is in the HIP library through ``HipEngine``.  The
+engine is a constructor argument only so that the world_size-2 ``gloo`` tests can drive the same
+exchange code on CPU tensors with the oracle as the arithmetic (tests/sharded_cpu_engine.py);
+the product never imports the oracle and ``HipEngine`` refuses CPU tensors.
+"""
+import math
+from typing import Iterable, Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from collie_amd import _lib, ops
+from collie_amd import loss as loss_mod
+
+_SPARSE_ALGOS = ('sparse_adam', 'adagrad', 'sgd')
+_I31 = 0x7fffffff
+
+
+# ---- counter-based initialisation -------------------------------------------------------------
+def _mix64(z):
+    """splitmix64 finaliser on int64 tensors (wrapping arithmetic, logical shifts by masking)."""
+    def lsr(x, s):
+        return (x >> s) & ((1 << (64 - s)) - 1)
+    z = (z ^ lsr(z, 30)) * -4658895280553007687        # 0xBF58476D1CE4E5B9
+    z = (z ^ lsr(z, 27)) * -7723592293110705685        # 0x94D049BB133111EB
+    return z ^ lsr(z, 31)
+
+
+def counter_normal(rows: torch.Tensor, dim: int, seed: int, stream: int, std: float,
+                   chunk_rows: int = 1 << 18) -> torch.Tensor:
+    """
+    ``[len(rows), dim]`` float32 draws of N(0, std^2) that depend only on (seed, stream, global row,
+    column): the tables a model starts from are the same for every G and every rank layout
+    (replaces the ``torch.manual_seed`` + ``nn.Embedding.weight.normal_`` init of
+    ``collie/model/base/layers.py:6-17``, which is tied to one process's generator).
+    Box-Muller in float64 on a splitmix64 hash, rounded to float32 at the end.
+    """
+    dev = rows.device
+    out = torch.empty(rows.shape[0], dim, dtype=torch.float32, device=dev)
+    cols = torch.arange(dim, dtype=torch.int64, device=dev)
+    base = _mix64(torch.tensor([seed * 2 + 1], dtype=torch.int64, device=dev)
+                  * -7046029254386353131 + stream)      # 0x9E3779B97F4A7C15
+    for s in range(0, rows.shape[0], chunk_rows):
+        r = rows[s:s + chunk_rows].to(torch.int64)
+        ctr = (r[:, None] * dim + cols[None, :]) * -7046029254386353131 + base
+        z = _mix64(ctr)
+        u1 = (((z >> 40) & 0xffffff).to(torch.float64) + 0.5) / 16777216.0
+        u2 = (((z >> 16) & 0xffffff).to(torch.float64) + 0.5) / 16777216.0
+        n = torch.sqrt(-2.0 * torch.log(u1)) * torch.cos((2.0 * math.pi) * u2)
+        out[s:s + chunk_rows] = (n * std).to(torch.float32)
+    return out
+
+
+# ---- arithmetic engine ---------------------------------------------------------------------------
+class HipEngine:
+    """Every floating-point operation of the sharded path, through ``libcollie_hip.so``."""
+
+    name = 'hip'
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise _lib.CollieHipError('HipEngine computes on a HIP device only (no CPU fallback)')
+        _lib.load()
+        self._train_ws = ops.TrainWorkspace(self.device)
+        self._rows_ws = None
+        self._eval_ws = ops.EvalWorkspace(self.device)
+        self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._acc = ops.optim_cfg('sgd', 1, -1.0)
+
+    # compact tables + compact ids -> (loss[1], grad rows [n, D], grad bias [n]), both * scale
+    def train_grads(self, cemb, cbias, cu, cp, cn, kind, num_items, codes, weights, scale):
+        n, D = cemb.shape
+        B, K = cn.shape
+        cb = cbias.view(n, 1)
+        tables = _lib.make_tables(cemb, cemb, cb, cb)       # one table, two id ranges
+        batch = ops.make_batch(cu, cp, cn)
+        buf = self._train_ws.ensure(B, K, D, n, n)
+        step_id = self._train_ws.next_step()
+        cfg = ops.make_loss_cfg(kind, num_items, codes, weights)
+        loss = torch.empty(1, dtype=torch.float32, device=self.device)
+        ops.train_forward(tables, batch, cfg, buf, True, step_id, loss, None, None, self._status)
+        ops.train_build_segments(tables, batch, buf)
+        gemb = torch.zeros(n, D, dtype=torch.float32, device=self.device)
+        gbias = torch.zeros(n, dtype=torch.float32, device=self.device)
+        gb = gbias.view(n, 1)
+        gt = _lib.make_tables(gemb, gemb, gb, gb)
+        both = {_lib.SIDE_USER: (self._acc, None, None, None),
+                _lib.SIDE_ITEM: (self._acc, None, None, None)}
+        ops.train_update(gt, batch, buf, False, False, step_id, both, scale)
+        ops.train_update(gt, batch, buf, True, False, step_id, both, scale)
+        return loss, gemb, gbias
+
+    # optimizer.step() of one combined shard table on an uncoalesced COO gradient
+    def rows_update(self, table, rows, vals, algo, step, lr, state, hyper):
+        cfg = ops.optim_cfg(algo, step, lr, hyper.get('beta1', 0.9), hyper.get('beta2', 0.999),
+                            hyper['eps'], 0.0, hyper.get('lr_decay', 0.0))
+        s1 = state.get('exp_avg', state.get('sum'))
+        s2 = state.get('exp_avg_sq')
+        self._rows_ws = ops.sparse_rows_update(table, rows, vals, cfg, s1, s2, self._status,
+                                               self._rows_ws)
+
+    # ---- catalog-sharded evaluation --------------------------------------------------------------
+    def _eval_tables(self, utile, ubias, iemb, ibias):
+        return _lib.make_tables(utile, iemb, ubias.view(-1, 1), ibias.view(-1, 1))
+
+    def shard_topk(self, utile, ubias, iemb, ibias, stride, offset, k):
+        slots = torch.arange(utile.shape[0], dtype=torch.int64, device=self.device)
+        t = self._eval_tables(utile, ubias, iemb, ibias)
+        return ops.eval_topk(t, slots, 0, iemb.shape[0], k, None, self._eval_ws, stride, offset)
+
+    def merge_topk(self, cand_scores, cand_ids, k):
+        return ops.eval_merge_topk(cand_scores, cand_ids, k)[1]
+
+    def shard_pos_scores(self, utile, ubias, iemb, ibias, stride, offset, indptr, indices):
+        slots = torch.arange(utile.shape[0], dtype=torch.int64, device=self.device)
+        t = self._eval_tables(utile, ubias, iemb, ibias)
+        return ops.eval_pos_scores(t, slots, indptr, indices, None, False, stride, offset)[0]
+
+    def thresholds(self, utile, ubias, iemb, ibias, indptr, indices, pos, y_range):
+        slots = torch.arange(utile.shape[0], dtype=torch.int64, device=self.device)
+        t = self._eval_tables(utile, ubias, iemb, ibias)
+        return ops.eval_pos_scores(t, slots, indptr, indices, y_range, True, given_scores=pos)[1:]
+
+    def shard_rank_counts(self, utile, ubias, iemb, ibias, stride, offset, indptr, thr):
+        n = utile.shape[0]
+        slots = torch.arange(n, dtype=torch.int64, device=self.device)
+        t = self._eval_tables(utile, ubias, iemb, ibias)
+        counts = torch.zeros(n, 3, dtype=torch.int64, device=self.device)
+        lo, hi, best_s, best_id = thr
+        ops.eval_rank_counts(t, slots, indptr, lo, hi, best_s, best_id, 0, iemb.shape[0], counts,
+                             stride, offset)
+        return counts
+
+    def metrics(self, topk_ids, k, n_users, n_items, indptr, indices, pos, counts, y_range, want):
+        return ops.eval_metrics(topk_ids, k, n_users, n_items, indptr, indices, pos, counts,
+                                y_range, *want)
+
+
+# ---- collectives ---------------------------------------------------------------------------------
+class _Comm:
+    """
+    The few collectives the path needs; world size 1 needs no process group at all.  Backend
+    ``nccl`` (RCCL over xGMI) moves device buffers directly; under ``gloo`` device tensors are staged
+    through the host (tests with several ranks on one GPU, hosts without RCCL).
+    """
+
+    def __init__(self, group=None):
+        self.group = group
+        self.staged = False
+        if dist.is_available() and dist.is_initialized():
+            self.world = dist.get_world_size(group)
+            self.rank = dist.get_rank(group)
+            self.staged = dist.get_backend(group) == 'gloo'
+        else:
+            self.world, self.rank = 1, 0
+
+    def all_to_all(self, inp, in_splits, out_splits):
+        """Rows of ``inp`` split by ``in_splits`` go to the peers; returns the rows received."""
+        shape = (int(sum(out_splits)),) + tuple(inp.shape[1:])
+        out = torch.empty(shape, dtype=inp.dtype, device=inp.device)
+        if self.world == 1:
+            out.copy_(inp)
+            return out
+        if self.staged and inp.is_cuda:
+            host = torch.empty(shape, dtype=inp.dtype)
+            dist.all_to_all_single(host, inp.cpu().contiguous(), list(out_splits), list(in_splits),
+                                   group=self.group)
+            return out.copy_(host)
+        dist.all_to_all_single(out, inp.contiguous(), list(out_splits), list(in_splits),
+                               group=self.group)
+        return out
+
+    def all_reduce(self, t):
+        if self.world > 1:
+            if self.staged and t.is_cuda:
+                host = t.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+                t.copy_(host)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def all_gather(self, t):
+        if self.world == 1:
+            return [t]
+        src = t.cpu() if (self.staged and t.is_cuda) else t.contiguous()
+        out = [torch.empty_like(src) for _ in range(self.world)]
+        dist.all_gather(out, src, group=self.group)
+        return [o.to(t.device) for o in out]
+
+
+def shard_batch(batch, rank, world):
+    """The contiguous slice of a global ``((users, pos), neg)`` batch that ``rank`` trains on."""
+    (users, pos), neg = batch
+    B = users.shape[0]
+    lo = (B * rank) // world
+    hi = (B * (rank + 1)) // world
+    return (users[lo:hi], pos[lo:hi]), neg[lo:hi]
+
+
+def _resolve_loss(loss, num_negative_samples):
+    """``base_pipeline.py:277-340`` for the implicit losses: adaptive whenever K > 1."""
+    many = num_negative_samples > 1
+    if loss == 'warp':
+        if not many:
+            raise ValueError('Cannot use WARP loss with a single negative sample!')
+        return 'warp'
+    if 'bpr' in loss:
+        return 'adaptive_bpr' if many else 'bpr'
+    if 'hinge' in loss or loss == 'adaptive':
+        return 'adaptive_hinge' if many else 'hinge'
+    raise ValueError('{} is not a valid loss function.'.format(loss))
+
+
+class ShardedMatrixFactorizationModel:
+    """
+    ``MatrixFactorizationModel`` whose four tables are row-sharded over the ranks of ``group``.
+
+    Hyper-parameter names are the reference's (``matrix_factorization.py:73-94``); the optimizers
+    are the sparse ones (``'sparse_adam'``, ``'adagrad'``, ``'sgd'``): dense Adam updates every
+    row every step and stays a single-GPU configuration.
+    """
+
+    def __init__(self, num_users: int, num_items: int, num_negative_samples: int,
+                 embedding_dim: int = 30, lr: float = 1e-3, bias_lr: Optional[float] = 1e-2,
+                 optimizer: str = 'sparse_adam', bias_optimizer: Optional[str] = 'sgd',
+                 loss: str = 'hinge', metadata_for_loss=None, metadata_for_loss_weights=None,
+                 y_range=None, seed: int = 0, device=None, group=None, engine=None,
+                 init: bool = True):
+        self.comm = _Comm(group)
+        G, rank = self.comm.world, self.comm.rank
+        self.device = torch.device(device if device is not None else 'cuda')
+        self.engine = engine if engine is not None else HipEngine(self.device)
+        if bias_optimizer == 'infer' or bias_optimizer is None:
+            bias_optimizer = optimizer
+        if bias_lr == 'infer' or bias_lr is None:
+            bias_lr = lr
+        for algo in (optimizer, bias_optimizer):
+            if algo not in _SPARSE_ALGOS:
+                raise ValueError(f'{algo} is not a valid optimizer for row-sharded tables '
+                                 f'(one of {_SPARSE_ALGOS})')
+        self.hparams = dict(num_users=int(num_users), num_items=int(num_items),
+                            embedding_dim=int(embedding_dim), lr=lr, bias_lr=bias_lr,
+                            optimizer=optimizer, bias_optimizer=bias_optimizer, loss=loss,
+                            sparse=True, y_range=y_range, seed=seed,
+                            num_negative_samples=int(num_negative_samples),
+                            metadata_for_loss_weights=metadata_for_loss_weights)
+        self._loss_kind = _resolve_loss(loss, num_negative_samples)
+        self.U_loc = (num_users - rank + G - 1) // G
+        self.N_loc = (num_items - rank + G - 1) // G
+        D = embedding_dim
+        rows = self.U_loc + self.N_loc
+        dev = self.device
+        self.emb = torch.empty(rows, D, dtype=torch.float32, device=dev)
+        self.bias = torch.zeros(rows, dtype=torch.float32, device=dev)     # ZeroEmbedding
+        if init:                                                           # ScaledEmbedding
+            gu = torch.arange(rank, num_users, G, dtype=torch.int64, device=dev)
+            gi = torch.arange(rank, num_items, G, dtype=torch.int64, device=dev)
+            self.emb[:self.U_loc] = counter_normal(gu, D, seed, 0, 1.0 / (2.5 * D))
+            self.emb[self.U_loc:] = counter_normal(gi, D, seed, 1, 1.0 / (2.5 * D))
+        self.state = {'emb': self._new_state(optimizer, self.emb),
+                      'bias': self._new_state(bias_optimizer, self.bias)}
+        self.steps = 0
+        self._codes, self._weights = loss_mod.metadata_to_codes(
+            metadata_for_loss, metadata_for_loss_weights, dev)
+        self.last_exchange = {}
+
+    @staticmethod
+    def _new_state(algo, table):
+        if algo == 'sparse_adam':
+            return {'exp_avg': torch.zeros_like(table), 'exp_avg_sq': torch.zeros_like(table)}
+        if algo == 'adagrad':
+            return {'sum': torch.zeros_like(table)}
+        return {}
+
+    _HYPER = {'sparse_adam': {'beta1': 0.9, 'beta2': 0.999, 'eps': 1e-8},
+              'adagrad': {'eps': 1e-10, 'lr_decay': 0.0}, 'sgd': {'eps': 0.0}}
+
+    # ---- views in the reference's parameter names (local rows) ---------------------------------
+    @property
+    def user_embeddings(self):
+        return self.emb[:self.U_loc]
+
+    @property
+    def item_embeddings(self):
+        return self.emb[self.U_loc:]
+
+    @property
+    def user_biases(self):
+        return self.bias[:self.U_loc]
+
+    @property
+    def item_biases(self):
+        return self.bias[self.U_loc:]
+
+    # ---- full <-> sharded ------------------------------------------------------------------------
+    def load_full_state_dict(self, state_dict):
+        """Take this rank's rows out of a reference-format (unsharded) ``state_dict``."""
+        G, rank = self.comm.world, self.comm.rank
+        dev = self.device
+        self.emb[:self.U_loc] = state_dict['user_embeddings.weight'][rank::G].to(dev)
+        self.emb[self.U_loc:] = state_dict['item_embeddings.weight'][rank::G].to(dev)
+        self.bias[:self.U_loc] = state_dict['user_biases.weight'][rank::G, 0].to(dev)
+        self.bias[self.U_loc:] = state_dict['item_biases.weight'][rank::G, 0].to(dev)
+
+    @classmethod
+    def from_model(cls, model, num_negative_samples, seed=0, device=None, group=None, engine=None):
+        """Shard a single-GPU ``MatrixFactorizationModel`` (same hyper-parameters, same tables)."""
+        hp = model.hparams
+        self = cls(hp['num_users'], hp['num_items'], num_negative_samples,
+                   embedding_dim=hp['embedding_dim'], lr=hp['lr'], bias_lr=hp['bias_lr'],
+                   optimizer=model.optimizer, bias_optimizer=model.bias_optimizer,
+                   loss=model.loss, metadata_for_loss=hp.get('metadata_for_loss'),
+                   metadata_for_loss_weights=hp.get('metadata_for_loss_weights'),
+                   y_range=hp.get('y_range'), seed=seed, device=device, group=group,
+                   engine=engine, init=False)
+        self.load_full_state_dict(model.state_dict())
+        return self
+
+    def _gather_rows(self, local, n_global):
+        """All ranks' shards of one table, interleaved back into global row order."""
+        G = self.comm.world
+        per = (n_global + G - 1) // G
+        pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        pad[:local.shape[0]] = local
+        parts = self.comm.all_gather(pad)
+        full = torch.empty((n_global,) + tuple(local.shape[1:]), dtype=local.dtype,
+                           device=local.device)
+        for r, part in enumerate(parts):
+            n_r = (n_global - r + G - 1) // G
+            full[r::G] = part[:n_r]
+        return full
+
+    def state_dict(self):
+        """Reference-format ``state_dict`` (full tables on every rank: moderate sizes only)."""
+        U, N = self.hparams['num_users'], self.hparams['num_items']
+        return {
+            'user_biases.weight': self._gather_rows(self.user_biases, U).reshape(U, 1),
+            'item_biases.weight': self._gather_rows(self.item_biases, N).reshape(N, 1),
+            'user_embeddings.weight': self._gather_rows(self.user_embeddings, U),
+            'item_embeddings.weight': self._gather_rows(self.item_embeddings, N),
+        }
+
+    def save_model(self, filename='model.pth'):
+        """``base_pipeline.py:880-900`` file format, written by rank 0 from the gathered tables."""
+        sd = {k: v.cpu() for k, v in self.state_dict().items()}
+        if self.comm.rank == 0:
+            hp = {k: v for k, v in self.hparams.items() if k not in ('seed', 'num_negative_samples')}
+            hp.update(dropout_p=0.0, weight_decay=0.0, metadata_for_loss=None,
+                      load_model_path=None, map_location=None, num_epochs_completed=0,
+                      _is_implicit=True)
+            torch.save({'state_dict': sd, 'hparams': hp}, str(filename))
+
+    # ---- training ----------------------------------------------------------------------------------
+    def _plan(self, users, pos_items, neg_items):
+        """Steps 1-2 of the module docstring: compact numbering + the request exchange."""
+        comm, G = self.comm, self.comm.world
+        dev = users.device
+        B, K = neg_items.shape
+        uu, inv_u = torch.unique(users.long(), return_inverse=True)
+        ui, inv_i = torch.unique(torch.cat([pos_items.long(), neg_items.long().reshape(-1)]),
+                                 return_inverse=True)
+        nu, ni = uu.shape[0], ui.shape[0]
+        n = nu + ni
+        ids = torch.cat([uu, ui])
+        kind = torch.zeros(n, dtype=torch.int64, device=dev)
+        kind[nu:] = 1
+        route = (ids % G) * 2 + kind                     # (owner, kind); ids ascend inside a route
+        order = torch.argsort(route, stable=True)
+        compact = torch.empty(n, dtype=torch.int64, device=dev)
+        compact[order] = torch.arange(n, dtype=torch.int64, device=dev)
+        send_rows = (ids // G)[order]
+        # one small all-to-all: [users, items, B_local, id range flag] per peer
+        meta = torch.zeros(G, 4, dtype=torch.int64, device=dev)
+        meta[:, :2] = torch.bincount(route, minlength=2 * G).reshape(G, 2)
+        meta[:, 2] = B
+        bad = ((uu[0] < 0) | (uu[-1] >= self.hparams['num_users'])
+               | (ui[0] < 0) | (ui[-1] >= self.hparams['num_items']))
+        meta[:, 3] = bad.to(torch.int64)
+        got = comm.all_to_all(meta, [1] * G, [1] * G)
+        meta_h, got_h = torch.stack([meta, got]).cpu().tolist()        # the step's one host sync
+        if any(row[3] for row in got_h) or meta_h[0][3]:
+            raise IndexError('index out of range in self: a user or item id is outside the tables')
+        send_counts = [(r[0], r[1]) for r in meta_h]
+        recv_counts = [(r[0], r[1]) for r in got_h]
+        B_global = sum(r[2] for r in got_h)
+        send_splits = [a + b for a, b in send_counts]
+        recv_splits = [a + b for a, b in recv_counts]
+        req = comm.all_to_all(send_rows, send_splits, recv_splits)
+        # requested row of the combined local table: item rows sit behind the U_loc user rows
+        seg = torch.tensor([c for pair in recv_counts for c in pair], dtype=torch.int64, device=dev)
+        off = torch.tensor([0, self.U_loc] * G, dtype=torch.int64, device=dev)
+        crow = req + torch.repeat_interleave(off, seg)
+        cu = compact[inv_u].to(torch.int32)
+        ci = compact[nu + inv_i].to(torch.int32)
+        plan = dict(n=n, nu=nu, ni=ni, B=B, K=K, B_global=B_global, crow=crow,
+                    send_splits=send_splits, recv_splits=recv_splits,
+                    cu=cu, cp=ci[:B].contiguous(), cn=ci[B:].reshape(B, K).contiguous(),
+                    item_ids=ui, item_compact=compact[nu:])
+        return plan
+
+    def train_step(self, batch) -> torch.Tensor:
+        """
+        ``calculate_loss`` + ``backward`` + both ``optimizer.step()`` calls for this rank's slice
+        ``((users, pos_items), neg_items)`` of the global batch; returns the global-batch loss
+        (0-d tensor, identical on every rank).  Collective: every rank must call it.
+        """
+        (users, pos_items), neg_items = batch
+        if neg_items.dim() == 1:
+            neg_items = neg_items.reshape(-1, 1)
+        comm, eng, dev = self.comm, self.engine, self.device
+        D = self.hparams['embedding_dim']
+        p = self._plan(users, pos_items, neg_items)
+        n, crow = p['n'], p['crow']
+        # 3. owners serve the rows
+        cemb = comm.all_to_all(self.emb.index_select(0, crow), p['recv_splits'], p['send_splits'])
+        cbias = comm.all_to_all(self.bias.index_select(0, crow), p['recv_splits'],
+                                p['send_splits'])
+        # 4. fused forward + segment reduce on the compact tables
+        codes = []
+        for c in self._codes or []:
+            cc = torch.zeros(n, dtype=torch.int32, device=dev)
+            cc[p['item_compact']] = c[p['item_ids']]
+            codes.append(cc)
+        scale = torch.full((1,), p['B'] / p['B_global'], dtype=torch.float32, device=dev)
+        loss, gemb, gbias = eng.train_grads(cemb, cbias, p['cu'], p['cp'], p['cn'],
+                                            self._loss_kind, self.hparams['num_items'], codes,
+                                            self._weights, scale)
+        # 5. gradients home
+        grows = comm.all_to_all(gemb, p['send_splits'], p['recv_splits'])
+        gb = comm.all_to_all(gbias, p['send_splits'], p['recv_splits'])
+        # 6. owners update
+        self.steps += 1
+        hp = self.hparams
+        if crow.shape[0] > 0:
+            eng.rows_update(self.emb, crow, grows, hp['optimizer'], self.steps, hp['lr'],
+                            self.state['emb'], self._HYPER[hp['optimizer']])
+            eng.rows_update(self.bias, crow, gb, hp['bias_optimizer'], self.steps, hp['bias_lr'],
+                            self.state['bias'], self._HYPER[hp['bias_optimizer']])
+        total = comm.all_reduce(loss * scale)
+        self.last_exchange = dict(rows_requested=n, rows_served=int(crow.shape[0]),
+                                  bytes_each_way=n * (D + 1) * 4)
+        return total.reshape(())
+
+    # ---- evaluation --------------------------------------------------------------------------------
+    def _user_tile(self, uids):
+        """Embedding rows + biases of a group of users on every rank (owners fill, sum all-reduce)."""
+        G, rank = self.comm.world, self.comm.rank
+        n = uids.shape[0]
+        tile = torch.zeros(n, self.hparams['embedding_dim'], dtype=torch.float32,
+                           device=self.device)
+        tb = torch.zeros(n, dtype=torch.float32, device=self.device)
+        own = torch.nonzero((uids % G) == rank).reshape(-1)
+        loc = uids[own] // G
+        tile[own] = self.emb.index_select(0, loc)
+        tb[own] = self.bias.index_select(0, loc)
+        self.comm.all_reduce(tile)
+        self.comm.all_reduce(tb)
+        return tile, tb
+
+    def per_user_metrics(self, uids, indptr, indices, k, want):
+        """(ap, rr, auc) per user of one group (device tensors, None where not wanted)."""
+        comm, eng = self.comm, self.engine
+        G, rank = comm.world, comm.rank
+        n = uids.shape[0]
+        N = self.hparams['num_items']
+        y = self.hparams.get('y_range')
+        y = tuple(y) if y is not None else None
+        want_ap, want_rr, want_auc = want
+        utile, ubias = self._user_tile(uids)
+        iemb, ibias = self.item_embeddings, self.item_biases
+        topk_ids = None
+        if want_ap:
+            cap = ops.eval_topk_capacity() if eng.name == 'hip' else 16
+            s, i = eng.shard_topk(utile, ubias, iemb, ibias, G, rank, k)
+            parts_s, parts_i = comm.all_gather(s), comm.all_gather(i.to(torch.int32))
+            cs = torch.full((n, G, cap), float('-inf'), dtype=torch.float32, device=self.device)
+            ci = torch.full((n, G, cap), _I31, dtype=torch.int32, device=self.device)
+            for r in range(G):
+                cs[:, r, :k] = parts_s[r]
+                ci[:, r, :k] = parts_i[r]
+            topk_ids = eng.merge_topk(cs, ci, k)
+        pos = counts = None
+        if want_rr or want_auc:
+            pos = eng.shard_pos_scores(utile, ubias, iemb, ibias, G, rank, indptr, indices)
+            comm.all_reduce(pos)
+            thr = eng.thresholds(utile, ubias, iemb, ibias, indptr, indices, pos, y)
+            counts = eng.shard_rank_counts(utile, ubias, iemb, ibias, G, rank, indptr, thr)
+            comm.all_reduce(counts)
+        return eng.metrics(topk_ids, k, n, N, indptr, indices, pos, counts, y, want)
+
+    def evaluate_in_batches(self, metric_list: Iterable, test_interactions, k: int = 10,
+                            batch_size: int = 20, users_per_launch: int = 8192):
+        """
+        ``collie.metrics.evaluate_in_batches`` (``metrics.py:285-395``) with the catalog sharded
+        over the ranks; every rank returns the same numbers.  ``metric_list`` holds the
+        ``mapk`` / ``mrr`` / ``auc`` callables of ``collie_amd.metrics``.
+        """
+        from collie_amd import metrics as M
+        metric_list = list(metric_list)
+        names = []
+        for m in metric_list:
+            if m not in M._FAST:
+                raise ValueError('the sharded evaluator computes mapk, mrr and auc only')
+            names.append(M._FAST[m])
+        want = ('ap' in names, 'rr' in names, 'auc' in names)
+        n_items = test_interactions.num_items
+        if n_items != self.hparams['num_items']:
+            raise ValueError('test interactions and model disagree on the number of items')
+        if k > n_items:
+            raise ValueError(f'Ensure ``k`` ({k}) is less than the number of items ({n_items}):')
+        if want[0] and (k > 16 or k > self.N_loc):
+            raise ValueError(f'k={k} must not exceed 16 or the smallest item shard ({self.N_loc})')
+        test_users = np.unique(test_interactions.mat.row)
+        targets = test_interactions.mat.tocsr()
+        if len(test_users) < batch_size:
+            batch_size = len(test_users)
+        per_user = {nm: [] for nm in ('ap', 'rr', 'auc')}
+        for s in range(0, len(test_users), users_per_launch):
+            group = test_users[s:s + users_per_launch]
+            uids = torch.from_numpy(group.astype(np.int64)).to(self.device)
+            indptr, indices = M._csr_slice(targets, group, self.device)
+            ap, rr, au = self.per_user_metrics(uids, indptr, indices, k, want)
+            for nm, v in (('ap', ap), ('rr', rr), ('auc', au)):
+                if v is not None:
+                    per_user[nm].append(v)
+        host = {nm: torch.cat(v).cpu().numpy() for nm, v in per_user.items() if v}
+        acc = [0] * len(metric_list)
+        for i in range(int(np.ceil(len(test_users) / batch_size))):
+            sl = slice(i * batch_size, (i + 1) * batch_size)
+            for j, nm in enumerate(names):
+                vals = host[nm][sl]
+                acc[j] += M._batch_mean(nm, vals) * len(vals)
+        scores = [a / len(test_users) for a in acc]
+        return scores[0] if len(scores) == 1 else scores

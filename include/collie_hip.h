@@ -223,6 +223,9 @@ int collie_sparse_rows_update(float* table, int64_t num_rows, int32_t dim, const
  * = whole catalog) and catalog-sharded evaluation (one shard per GPU, results merged).
  * The user's positives are a CSR slice over the batch: indptr [n_users+1], indices [nnz] (item
  * ids, ascending inside a row as scipy's tocsr() gives them, metrics.py:368).
+ * Shards: row r of the local item table is the global item  r * id_stride + id_offset  (single
+ * GPU: stride 1, offset 0; round-robin row sharding over G GPUs: stride G, offset rank).  Ids in
+ * outputs, `indices` and `best_id` are always GLOBAL ids.
  * ------------------------------------------------------------------------------------------- */
 
 /* largest k the register-resident top-k supports */
@@ -233,9 +236,10 @@ size_t collie_mf_eval_workspace_bytes(int64_t n_users, int64_t n_items_shard);
 /* preds.topk(k) (metrics.py:171) over the shard: topk_ids / topk_scores [n_users, k], ordered by
  * descending score, ascending item id on exact ties.  Scores are y_range-transformed if asked. */
 int collie_mf_eval_topk(const collie_mf_tables* t, const int64_t* user_ids, int64_t n_users,
-                        int64_t item_begin, int64_t item_end, int32_t k, int32_t has_y_range,
-                        float y_lo, float y_hi, float* topk_scores, int64_t* topk_ids,
-                        void* workspace, size_t workspace_bytes, collie_stream_t stream);
+                        int64_t item_begin, int64_t item_end, int64_t id_stride,
+                        int64_t id_offset, int32_t k, int32_t has_y_range, float y_lo, float y_hi,
+                        float* topk_scores, int64_t* topk_ids, void* workspace,
+                        size_t workspace_bytes, collie_stream_t stream);
 
 /* Catalog-sharded evaluation: merge per-shard top-k candidate lists (cand_* [n_users, nslots,
  * collie_mf_eval_topk_capacity()], unused entries = (-inf, INT32_MAX)) into the global top-k.
@@ -250,10 +254,14 @@ int collie_mf_eval_merge_topk(const float* cand_scores, const int32_t* cand_ids,
  *   thr_lo/thr_hi [nnz] (optional) the raw-score interval whose fp32 sigmoid(preds) equals the
  *       positive's: AUC ranks sigmoid(preds) (metrics.py:277), which ties distinct raw scores
  *   best_score / best_id [n_users] (optional) the user's best positive = first relevant item of
- *       the descending order (metrics.py:224-238) */
+ *       the descending order (metrics.py:224-238)
+ * compute_scores = 1: pos_scores are computed (entries whose item lives on another shard get 0, so
+ * that a sum all-reduce over the shards completes them); 0: pos_scores are given (already
+ * all-reduced) and only the thresholds / best positives are derived from them. */
 int collie_mf_eval_pos_scores(const collie_mf_tables* t, const int64_t* user_ids, int64_t n_users,
                               const int64_t* indptr, const int64_t* indices, int64_t nnz,
-                              int32_t has_y_range, float y_lo, float y_hi, float* pos_scores,
+                              int32_t has_y_range, float y_lo, float y_hi, int32_t compute_scores,
+                              int64_t id_stride, int64_t id_offset, float* pos_scores,
                               float* thr_lo, float* thr_hi, float* best_score, int64_t* best_id,
                               collie_stream_t stream);
 
@@ -266,7 +274,8 @@ int collie_mf_eval_rank_counts(const collie_mf_tables* t, const int64_t* user_id
                                int64_t n_users, const int64_t* indptr, const float* thr_lo,
                                const float* thr_hi, const float* best_score,
                                const int64_t* best_id, int64_t item_begin, int64_t item_end,
-                               uint64_t* counts, collie_stream_t stream);
+                               int64_t id_stride, int64_t id_offset, uint64_t* counts,
+                               collie_stream_t stream);
 
 /* Per-user AP@k (float64, metrics.py:178-196), reciprocal rank (fp32, :237-238) and tie-averaged
  * AUC of sigmoid(preds) (:266-280) from the top-k ids and the rank counts.  Any of ap / rr / auc
