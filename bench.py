@@ -10,8 +10,15 @@ A "step" is one pass of the hot path over one batch that is already resident in 
 segment-reduce/row-update kernels), all through the product API.  Negative sampling is done on the
 device before the timed region.
 
+N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): the same workload with the four
+tables row-sharded over the ranks (``collie_amd/sharded.py``: all-to-all row lookup, fused forward on
+the compact tables, all-to-all of the gradient rows, owner-side update).  Every rank trains on its
+own batch of ``--batch`` positives per step (weak scaling); ``value`` counts all ranks' interactions.
+
+A second, untimed-by-the-contract leg reports the other half of BASELINE.json's metric, "eval
+users/sec MAP@10", on configs[2]'s shape (1M x 1M, dim 128; a sample of the users) under ``eval``.
+
 Contract: ``python bench.py --gpus N --steps K --warmup W`` prints ONE JSON line on rank 0.
-For N > 1 it is launched by torch.distributed.run, one rank per GPU.
 """
 import argparse
 import json
@@ -112,6 +119,117 @@ def cpu_baseline(seconds=12.0, batch=1024):
                       f'loss/optimizers, torch CPU op sequence of the reference, {dt:.1f} s'}
 
 
+EVAL_USERS, EVAL_ITEMS, EVAL_DIM, EVAL_POS = 1_000_000, 1_000_000, 128, 10
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA (exact fp32 products)
+
+
+def eval_leg(device, n_users, sharded_world=1, group_rank=0):
+    """evaluate_in_batches([mapk], k=10) on configs[2]'s shape for a sample of ``n_users`` users."""
+    from collie_amd import metrics as M
+    from collie_amd.interactions import Interactions
+    rng = np.random.default_rng(0)
+    users = np.repeat(np.sort(rng.choice(EVAL_USERS, n_users, replace=False)), EVAL_POS)
+    items = rng.integers(0, EVAL_ITEMS, users.shape[0])
+    test = Interactions(users=users, items=items, num_users=EVAL_USERS, num_items=EVAL_ITEMS,
+                        allow_missing_ids=True, num_negative_samples=1, check_num_negative_samples_is_valid=False,
+                        max_number_of_samples_to_consider=0, seed=0)
+    if sharded_world == 1:
+        from collie_amd.model import MatrixFactorizationModel
+
+        class Shape:
+            num_users, num_items, num_negative_samples = EVAL_USERS, EVAL_ITEMS, 1
+        torch.manual_seed(0)
+        model = MatrixFactorizationModel(train=Shape(), embedding_dim=EVAL_DIM, sparse=True,
+                                         optimizer='sparse_adam', loss='bpr', lr_scheduler_func=None)
+        with torch.no_grad():
+            model.user_biases.weight.normal_(0, 0.01)
+            model.item_biases.weight.normal_(0, 0.01)
+        model.to(device)
+
+        def run():
+            return M.evaluate_in_batches([M.mapk], test, model, k=10, verbose=False)
+    else:
+        from collie_amd.sharded import ShardedMatrixFactorizationModel
+        model = ShardedMatrixFactorizationModel(EVAL_USERS, EVAL_ITEMS, 1, embedding_dim=EVAL_DIM,
+                                                loss='bpr', device=device, seed=0)
+        model.bias.normal_(0, 0.01)
+
+        def run():
+            return model.evaluate_in_batches([M.mapk], test, k=10)
+    run()                                                      # warm-up (workspace, first launches)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    score = run()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    flops = 2.0 * n_users * EVAL_ITEMS * EVAL_DIM
+    return {'metric': 'eval users/sec MAP@10', 'value': n_users / dt, 'unit': 'users/s',
+            'workload': f'BASELINE configs[2] shape: {EVAL_USERS} users x {EVAL_ITEMS} items, dim '
+                        f'{EVAL_DIM}, {EVAL_POS} test items per user, k=10; sample of {n_users} '
+                        'users through evaluate_in_batches([mapk]) end to end (CSR slicing on the '
+                        'host included)',
+            'seconds': dt, 'map_at_10': float(score),
+            'mfma': {'bound': 'mfma', 'achieved': flops / dt / 1e12, 'peak': MFMA_F32_PEAK_TFLOPS,
+                     'unit': 'TFLOP/s', 'frac': flops / dt / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                     'note': 'end-to-end time, not kernel time: a lower bound on the kernel rate'}}
+
+
+def main_sharded(args, world, rank, device):
+    """N > 1: row-sharded tables, one rank per GPU, RCCL all-to-all each way."""
+    import torch.distributed as dist
+    from collie_amd.sharded import ShardedMatrixFactorizationModel
+    backend = os.environ.get('COLLIE_BENCH_BACKEND', 'nccl')   # 'gloo': rehearsal on one GPU
+    if backend == 'nccl':
+        dist.init_process_group('nccl', device_id=device)
+    else:
+        dist.init_process_group(backend)
+    model = ShardedMatrixFactorizationModel(NUM_USERS, NUM_ITEMS, NUM_NEG, embedding_dim=DIM,
+                                            lr=1e-3, bias_lr=1e-2, optimizer='sparse_adam',
+                                            bias_optimizer='sgd', loss='bpr', device=device, seed=0)
+    n_distinct = min(args.steps + args.warmup, 32)
+    batches = synthetic_batches(n_distinct, args.batch, device, args.dist, seed=1234 + rank)
+    for i in range(args.warmup):
+        model.train_step(batches[i % n_distinct])
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = model.train_step(batches[(args.warmup + i) % n_distinct])
+    dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    ev = None
+    if args.eval_users > 0:
+        ev = eval_leg(device, args.eval_users, world, rank)
+    if rank == 0:
+        per_step = args.batch * (1 + NUM_NEG)
+        result = {
+            'metric': 'train interactions/sec (pos+negs)',
+            'value': world * per_step * args.steps / elapsed, 'unit': 'interactions/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {
+                'workload': 'BASELINE configs[1]: synthetic ML-20M shape 138493 users x 26744 '
+                            'items, MF dim=64, adaptive BPR + 10 negatives, SparseAdam + SGD bias',
+                'batch_per_gpu': args.batch, 'global_batch': args.batch * world,
+                'id_distribution': args.dist,
+                'parallelism': f'tables row-sharded over {world} GPUs (owner = row mod {world}), '
+                               'RCCL all-to-all lookup + gradient exchange',
+                'final_loss': float(loss.item()),
+                'rows_exchanged_per_rank_per_step': model.last_exchange.get('rows_requested'),
+            },
+            'roofline': None,
+        }
+        if ev is not None:
+            result['eval'] = ev
+        print(json.dumps(result))
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -120,6 +238,8 @@ def main():
     ap.add_argument('--batch', type=int, default=65536, help='positives per step per GPU')
     ap.add_argument('--dist', choices=['uniform', 'zipf'], default='uniform')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--eval-users', type=int, default=65536,
+                    help='users in the eval leg (0 = skip it)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -128,12 +248,12 @@ def main():
     if args.gpus > 1 and world == 1:
         raise SystemExit('for --gpus N > 1 launch with: python -m torch.distributed.run '
                          '--nnodes=1 --nproc-per-node N bench.py --gpus N ...')
+    local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
-    dist_on = world > 1
-    if dist_on:
-        import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=device)
+    if world > 1:
+        return main_sharded(args, world, rank, device)
+    dist_on = False
 
     model = build_model(device)
     optimizers = model.configure_optimizers()
@@ -199,7 +319,8 @@ def main():
                 'final_loss': final_loss,
             },
             'roofline': {
-                'kernel': 'mf_train_fwd_kernel<4,16> (fused gather + dot + loss + backward staging)',
+                'kernel': 'mf_train_fwd_fast<4,16,1,false,false> + loss_finalize_kernel '
+                          '(calculate_loss: fused gather + dot + loss + backward staging)',
                 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
                 'algorithmic_bytes_per_launch': alg, 'avg_launch_ms': fwd_ms,
@@ -207,6 +328,10 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             result['cpu_baseline'] = cpu_baseline()
+        if args.eval_users > 0:
+            del model, optimizers, batches
+            torch.cuda.empty_cache()
+            result['eval'] = eval_leg(device, args.eval_users)
         print(json.dumps(result))
     if dist_on:
         dist.destroy_process_group()

@@ -15,6 +15,8 @@
 //     stage_i[b] = g * U[user_b]                    (+ for I[pos], - for I[neg_sel])
 // plus g itself (bias gradients) and one 32-bit code per looked-up id that tells the
 // segment-reduce/optimizer kernels which staged row, with which sign, belongs to that id.
+#include <type_traits>
+
 #include "train_ws.h"
 
 namespace collie {
@@ -578,6 +580,261 @@ __global__ __launch_bounds__(kBlock) void mf_train_fwd_fast(const FwdParams p) {
   }
 }
 
+// ---- K1, LDS-parked variant ------------------------------------------------------------------------
+// One gather pass per sample: 64 / LPR >= 1 + K lane groups, group j owns row j (0 = positive,
+// 1..K = negatives), a lane owns CH 16-byte chunks of its row: chunk c = i * LPR + lig for
+// i < CH (dim == 4 * CH * LPR exactly).  The rows never pass through VGPRs on their way in: every
+// row chunk is fetched by an LDS-DMA load (global_load_lds_dwordx4: per-lane source address,
+// wave-linear LDS destination) into a wave-private parking area, so the gathers in flight cost no
+// registers and the kernel runs at 8 waves per SIMD.  Instruction i of the item gather writes
+// park[i][lane]; each lane reads back exactly the 16 bytes it asked for, and the staging step at
+// the end reads the positive row, the selected negative row and the user row straight out of the
+// parking area (no shuffles).  The selection itself is one wave-wide max + one ballot: groups are
+// laid out in lane order, so the lowest set lane of the ballot is the lowest j (torch.max's first
+// maximum; WARP's first violation).
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+struct LdsParams {
+  const float* user_emb;
+  const float* item_emb;
+  const float* user_bias;
+  const float* item_bias;
+  const int32_t* users;
+  const int32_t* pos_items;
+  const int64_t* neg_items;
+  int64_t neg_stride_b, neg_stride_k;
+  int64_t batch;
+  int32_t num_users, num_items;
+  int32_t num_neg, dim;
+  int32_t* touch_item;
+  uint32_t* ekeys;
+  uint32_t* ecodes;
+  float* gcoef;
+  float* stage_u;
+  float* stage_i;
+  float* loss_partials;
+  int32_t* status;
+  int32_t step_id, need_grad;
+  float inv_b, warp_items;  // warp_items = float(loss.num_items)
+  const int32_t* meta[COLLIE_MAX_META];
+  float meta_weight[COLLIE_MAX_META];
+  int32_t n_meta;
+};
+
+// max over the wave; every lane of a 16-lane row holds the row's max after the DPP steps, the two
+// row broadcasts carry it to lane 63
+template <int LPR>
+__device__ __forceinline__ float wave_max_from_groups(float v) {
+  auto mx = [](float a, int ctrl_result) { return fmaxf(a, __int_as_float(ctrl_result)); };
+  if (LPR <= 1) v = mx(v, __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0xB1, 0xf, 0xf, false));
+  if (LPR <= 2) v = mx(v, __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x4E, 0xf, 0xf, false));
+  if (LPR <= 4) v = mx(v, __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x141, 0xf, 0xf, false));
+  if (LPR <= 8) v = mx(v, __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x140, 0xf, 0xf, false));
+  v = mx(v, __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x142, 0xa, 0xf, false));
+  v = mx(v, __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x143, 0xc, 0xf, false));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// N LDS-DMA loads of 16 bytes per lane: source src + I * SRC_BYTES, destination dst + I * DST_F4
+// float4 slots (+ lane * 16 by the hardware).  The instruction's immediate offset is added to the
+// global address AND to the LDS address, so the LDS base passed for load I is pulled back by it.
+template <int I, int N, int SRC_BYTES, int DST_F4>
+__device__ __forceinline__ void glds_chunks(const float* src, float4* dst) {
+  static_assert(DST_F4 * 16 >= SRC_BYTES, "LDS base would move below the parking area");
+  if constexpr (I < N) {
+    __builtin_amdgcn_global_load_lds(
+        (gptr_t)src, (lptr_t)(reinterpret_cast<char*>(dst) + I * (DST_F4 * 16 - SRC_BYTES)), 16,
+        I * SRC_BYTES, 0);
+    glds_chunks<I + 1, N, SRC_BYTES, DST_F4>(src, dst);
+  }
+}
+
+struct LdsIds {
+  int u, pos;   // wave-uniform
+  int64_t neg;  // per lane group
+};
+
+template <int LPR>
+__device__ __forceinline__ LdsIds load_lds_ids(const LdsParams& p, int64_t b, int64_t neg_lane_off) {
+  LdsIds s;
+  int64_t zero = 0;
+  asm volatile("" : "+v"(zero));  // keep the prefetched ids in VGPRs until they are used
+  const int64_t bv = b + zero;
+  s.u = p.users[bv];
+  s.pos = p.pos_items[bv];
+  s.neg = p.neg_items[bv * p.neg_stride_b + neg_lane_off];
+  return s;
+}
+
+// KIND: 0 = warp, 1 = (adaptive) bpr, 2 = (adaptive) hinge
+template <int CH, int LPR, int KIND, bool META>
+__global__ __launch_bounds__(kBlock, (CH <= 4 ? 8 : 4)) void mf_train_fwd_lds(const LdsParams p) {
+  constexpr int kItemF4 = CH * kWave;  // float4 slots of the item parking area
+  constexpr int kUserF4 = CH * LPR;
+  __shared__ float4 park[kWavesPerBlock][kItemF4 + kUserF4];
+
+  const int lane = lane_id();
+  const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const int grp = lane / LPR;
+  const int lig = lane % LPR;
+  const int K = p.num_neg;
+  const int D = p.dim;
+  const int64_t B = p.batch;
+  const uint32_t key_off = static_cast<uint32_t>(p.num_users);
+  float4* const items_l = &park[wave_in_block][0];
+  float4* const user_l = &park[wave_in_block][kItemF4];
+  const int jn = grp > K ? K : (grp < 1 ? 1 : grp);  // negative read by this lane group (1..K)
+  const int64_t neg_lane_off = static_cast<int64_t>(jn - 1) * p.neg_stride_k;
+  const bool row_lane = grp <= K;
+  const bool neg_lane = grp >= 1 && row_lane;
+
+  float loss1 = 0.0f, loss2 = 0.0f;
+  const int64_t nw = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+  int64_t b = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave_in_block;
+  LdsIds next = {0, 0, 0};
+  if (b < B) next = load_lds_ids<LPR>(p, b, neg_lane_off);
+  for (; b < B; b += nw) {
+    const LdsIds cur = next;
+    const int u = __builtin_amdgcn_readfirstlane(cur.u);
+    const int pos_item = __builtin_amdgcn_readfirstlane(cur.pos);
+    const int64_t item64 = grp == 0 ? static_cast<int64_t>(pos_item) : cur.neg;
+    const bool bad_lane = static_cast<uint64_t>(item64) >= static_cast<uint64_t>(p.num_items);
+    const bool bad = static_cast<uint32_t>(u) >= static_cast<uint32_t>(p.num_users) ||
+                     (__ballot(bad_lane) != 0ull);
+    const int item = static_cast<int>(item64);
+    if (bad) {  // wave-uniform: never touch memory through a bad id
+      if (b + nw < B) next = load_lds_ids<LPR>(p, b + nw, neg_lane_off);
+      if (lane == 0 && p.status) atomicOr(p.status, 1);
+      if (p.need_grad && lane < 3) {
+        const int64_t slot = lane == 0 ? b : B + 2 * b + (lane - 1);
+        p.ekeys[slot] = lane == 0 ? 0u : key_off;
+        p.ecodes[slot] = kCodeNone;
+        if (lane == 0) p.gcoef[b] = 0.0f;
+      }
+      continue;
+    }
+
+    // ---- gathers: LDS-DMA, nothing lands in a VGPR -------------------------------------------
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // last sample's parking reads are done
+    const float* irow = p.item_emb + static_cast<int64_t>(item) * D + lig * 4;
+    glds_chunks<0, CH, LPR * 16, kWave>(irow, items_l);
+    if (grp == 0) {
+      const float* urow = p.user_emb + static_cast<int64_t>(u) * D + lig * 4;
+      glds_chunks<0, CH, LPR * 16, LPR>(urow, user_l);
+    }
+    const float ub = p.user_bias[u];
+    const float ib = p.item_bias[item];
+    if (b + nw < B) next = load_lds_ids<LPR>(p, b + nw, neg_lane_off);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- dot products: chunk order i, then across the LPR lanes of the row ----------------------
+    float dot = 0.0f;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const float4 a = items_l[i * kWave + lane];
+      const float4 c = user_l[i * LPR + lig];
+      dot = fmaf(c.x, a.x, dot);
+      dot = fmaf(c.y, a.y, dot);
+      dot = fmaf(c.z, a.z, dot);
+      dot = fmaf(c.w, a.w, dot);
+    }
+    const float s = (group_sum_dpp<LPR>(dot) + ub) + ib;
+    const float sp = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s)));
+
+    // ---- selection: one max + one ballot ------------------------------------------------------
+    float c = 1.0f;
+    if (META) {
+      float frac = 0.0f;
+      for (int m = 0; m < p.n_meta; ++m)
+        frac += (p.meta[m][pos_item] == p.meta[m][item]) ? p.meta_weight[m] : 0.0f;
+      c = 1.0f - frac;
+    }
+    const float v = KIND == 0 ? (c - sp) + s : s;
+    uint64_t mask;
+    if (KIND == 0) {
+      mask = __ballot(neg_lane & (v > 0.0f));
+    } else {
+      const float vmax = wave_max_from_groups<LPR>(neg_lane ? v : -INFINITY);
+      mask = __ballot(neg_lane & (v == vmax));
+    }
+    const bool none = mask == 0ull;  // warp without a violation (or only NaN scores)
+    const int wl = none ? LPR : static_cast<int>(__builtin_ctzll(mask));
+    const int sel = wl / LPR;
+    const float best_v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), wl));
+    const float best_c = META ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), wl)) : 1.0f;
+    const int best_item = __builtin_amdgcn_readlane(item, wl);
+    float ell = 0.0f, g = 0.0f;
+    if (KIND == 0) {
+      if (!none) {
+        const float w = logf(p.warp_items / static_cast<float>(sel));
+        ell = w * best_v;
+        g = -(w * (1.0f + 2.0f * ell)) * p.inv_b;
+      }
+    } else if (!none) {
+      const float d = sp - best_v;
+      if (KIND == 1) {
+        const float sig = sigmoidf_(d);
+        ell = best_c - sig;
+        g = -(sig * (1.0f - sig)) * (1.0f + 2.0f * ell) * p.inv_b;
+      } else {
+        const float x = best_c - d;
+        ell = fmaxf(x, 0.0f);
+        g = x >= 0.0f ? -(1.0f + 2.0f * ell) * p.inv_b : 0.0f;  // clamp passes grad at the kink
+      }
+    }
+    loss1 += ell;
+    loss2 += ell * ell;
+    if (!p.need_grad) continue;
+
+    // ---- backward staging ---------------------------------------------------------------------
+    const bool live = g != 0.0f;
+    if (lig == 0 && row_lane) p.touch_item[item] = p.step_id;
+    if (lane < 3) {  // lane 0: user entry, lane 1: positive item, lane 2: selected negative
+      const int64_t slot = lane == 0 ? b : B + 2 * b + (lane - 1);
+      const uint32_t key =
+          lane == 0 ? static_cast<uint32_t>(u)
+                    : key_off + static_cast<uint32_t>(lane == 1 ? pos_item : best_item);
+      p.ekeys[slot] = key;
+      p.ecodes[slot] = live ? (static_cast<uint32_t>(b) | (lane == 2 ? kCodeNeg : 0u)) : kCodeNone;
+      if (lane == 0) p.gcoef[b] = g;
+    }
+    if (live && lane < CH * LPR) {  // lane l stages 16-byte chunk l of the two rows
+      const int i = lane / LPR, l2 = lane % LPR;
+      const float4 uu = user_l[lane];
+      const float4 ip = items_l[i * kWave + l2];
+      const float4 is = items_l[i * kWave + sel * LPR + l2];
+      float4 gu, gi;
+      gu.x = g * ip.x - g * is.x;
+      gu.y = g * ip.y - g * is.y;
+      gu.z = g * ip.z - g * is.z;
+      gu.w = g * ip.w - g * is.w;
+      gi.x = g * uu.x;
+      gi.y = g * uu.y;
+      gi.z = g * uu.z;
+      gi.w = g * uu.w;
+      *reinterpret_cast<float4*>(p.stage_u + b * D + lane * 4) = gu;
+      *reinterpret_cast<float4*>(p.stage_i + b * D + lane * 4) = gi;
+    }
+  }
+
+  __shared__ float red[2][kWavesPerBlock];
+  if (lane == 0) {
+    red[0][wave_in_block] = loss1;
+    red[1][wave_in_block] = loss2;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = 0.0f, c2 = 0.0f;
+    for (int w = 0; w < kWavesPerBlock; ++w) {
+      a += red[0][w];
+      c2 += red[1][w];
+    }
+    p.loss_partials[2 * blockIdx.x] = a;
+    p.loss_partials[2 * blockIdx.x + 1] = c2;
+  }
+}
+
 // loss = (sum l + sum l^2) / B   (bpr.py:89, hinge.py:85, warp.py:133); fixed-order reduction
 __global__ __launch_bounds__(kBlock) void loss_finalize_kernel(const float* partials, int nblocks,
                                                                float inv_b, float* loss_out) {
@@ -642,6 +899,77 @@ int launch_fwd_fast(int lpr, int np, dim3 grid, hipStream_t stream, const FwdPar
     default: launch_fast_np<64>(np, std_ids, meta, grid, stream, p); break;
   }
   return check_launch("mf_train_fwd_fast");
+}
+
+template <int CH, int LPR>
+void launch_lds2(int kind3, bool meta, dim3 grid, hipStream_t stream, const LdsParams& q) {
+#define COLLIE_LDS_CASE(KIND_)                                                                    \
+  if (meta)                                                                                       \
+    hipLaunchKernelGGL((mf_train_fwd_lds<CH, LPR, KIND_, true>), grid, dim3(kBlock), 0, stream, q); \
+  else                                                                                            \
+    hipLaunchKernelGGL((mf_train_fwd_lds<CH, LPR, KIND_, false>), grid, dim3(kBlock), 0, stream, q)
+  if (kind3 == 0) { COLLIE_LDS_CASE(0); }
+  else if (kind3 == 1) { COLLIE_LDS_CASE(1); }
+  else { COLLIE_LDS_CASE(2); }
+#undef COLLIE_LDS_CASE
+}
+
+template <int LPR>
+void launch_lds1(int ch, int kind3, bool meta, dim3 grid, hipStream_t stream, const LdsParams& q) {
+  switch (ch) {
+    case 1: launch_lds2<1, LPR>(kind3, meta, grid, stream, q); break;
+    case 2: launch_lds2<2, LPR>(kind3, meta, grid, stream, q); break;
+    case 4: launch_lds2<4, LPR>(kind3, meta, grid, stream, q); break;
+    default: launch_lds2<8, LPR>(kind3, meta, grid, stream, q); break;
+  }
+}
+
+// LDS-parked path.  Conditions (checked by the caller): float4 rows, dim == 16 * ch * lpr bytes
+// exactly, 1 + K <= 64 / lpr, the loaders' id dtypes, no score outputs.
+int launch_fwd_lds(int lpr, int ch, dim3 grid, hipStream_t stream, const FwdParams& p) {
+  LdsParams q;
+  memset(&q, 0, sizeof(q));
+  q.user_emb = p.t.user_emb;
+  q.item_emb = p.t.item_emb;
+  q.user_bias = p.t.user_bias;
+  q.item_bias = p.t.item_bias;
+  q.users = static_cast<const int32_t*>(p.b.users);
+  q.pos_items = static_cast<const int32_t*>(p.b.pos_items);
+  q.neg_items = static_cast<const int64_t*>(p.b.neg_items);
+  q.neg_stride_b = p.b.neg_stride_b;
+  q.neg_stride_k = p.b.neg_stride_k;
+  q.batch = p.b.batch;
+  q.num_users = static_cast<int32_t>(p.t.num_users);
+  q.num_items = static_cast<int32_t>(p.t.num_items);
+  q.num_neg = p.b.num_neg;
+  q.dim = p.t.dim;
+  q.touch_item = p.ws.touch_item;
+  q.ekeys = p.ws.sort.ekeys;
+  q.ecodes = p.ws.sort.ecodes;
+  q.gcoef = p.ws.gcoef;
+  q.stage_u = p.ws.stage_u;
+  q.stage_i = p.ws.stage_i;
+  q.loss_partials = p.ws.loss_partials;
+  q.status = p.status;
+  q.step_id = p.step_id;
+  q.need_grad = p.need_grad;
+  q.inv_b = p.inv_b;
+  q.warp_items = static_cast<float>(p.loss.num_items);
+  q.n_meta = p.loss.n_meta;
+  for (int m = 0; m < COLLIE_MAX_META; ++m) {
+    q.meta[m] = p.loss.meta[m];
+    q.meta_weight[m] = p.loss.meta_weight[m];
+  }
+  const int kind = p.loss.kind;
+  const int kind3 = kind == COLLIE_LOSS_WARP ? 0
+                    : (kind == COLLIE_LOSS_BPR || kind == COLLIE_LOSS_ADAPTIVE_BPR) ? 1 : 2;
+  const bool meta = p.loss.n_meta > 0;
+  switch (lpr) {
+    case 4: launch_lds1<4>(ch, kind3, meta, grid, stream, q); break;
+    case 8: launch_lds1<8>(ch, kind3, meta, grid, stream, q); break;
+    default: launch_lds1<16>(ch, kind3, meta, grid, stream, q); break;
+  }
+  return check_launch("mf_train_fwd_lds");
 }
 
 template <int VEC>
@@ -744,8 +1072,18 @@ extern "C" int collie_mf_train_forward(const collie_mf_tables* t, const collie_m
   int64_t nblocks = (b->batch + kWavesPerBlock - 1) / kWavesPerBlock;
   if (nblocks > kMaxLossBlocks) nblocks = kMaxLossBlocks;
   dim3 grid(static_cast<unsigned>(nblocks));
+  // LDS-parked single pass: the most lanes per row that still leave a lane group for every row
+  int lds_lpr = 16;
+  while (lds_lpr > 4 && kWave / lds_lpr < b->num_neg + 1) lds_lpr /= 2;
+  const int lds_ch = p.nchunks / lds_lpr;
+  const bool lds_ok = vec == 4 && kWave / lds_lpr >= b->num_neg + 1 &&
+                      lds_ch * lds_lpr == p.nchunks &&
+                      (lds_ch == 1 || lds_ch == 2 || lds_ch == 4 || lds_ch == 8) &&
+                      b->users_dtype == COLLIE_I32 && b->pos_dtype == COLLIE_I32 &&
+                      b->neg_dtype == COLLIE_I64 && !s_pos_out && !s_neg_out;
   int rc;
-  if (fast) rc = launch_fwd_fast(lpr, np, grid, stream, p);
+  if (lds_ok) rc = launch_fwd_lds(lds_lpr, lds_ch, grid, stream, p);
+  else if (fast) rc = launch_fwd_fast(lpr, np, grid, stream, p);
   else if (vec == 4) rc = launch_fwd<4>(lpr, grid, stream, p);
   else if (vec == 2) rc = launch_fwd<2>(lpr, grid, stream, p);
   else rc = launch_fwd<1>(lpr, grid, stream, p);

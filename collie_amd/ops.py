@@ -237,6 +237,39 @@ def loss_forward_backward(loss_cfg, s_pos, s_neg_KB, pos_items=None, neg_items_K
 
 
 
+# ---- row-sharded training: requester-side plan ---------------------------------------------------
+class ShardPlanner:
+    """Persistent stamp / slot tables of one sharded model + the per-step plan call."""
+
+    def __init__(self, num_users, num_items, world, device):
+        self.num_users, self.num_items, self.world = int(num_users), int(num_items), int(world)
+        need = int(load().collie_shard_plan_workspace_bytes(num_users, num_items, world))
+        if need == 0:
+            raise _lib.CollieHipError('collie_shard_plan_workspace_bytes: bad sizes')
+        self.buf = torch.zeros(need, dtype=torch.uint8, device=device)
+        self.step = 0
+
+    def plan(self, users, pos_items, neg_items):
+        batch = make_batch(users, pos_items, neg_items)
+        B, K = neg_items.shape
+        dev = users.device
+        self.step += 1
+        if self.step >= 2 ** 31 - 1:
+            self.buf.zero_()
+            self.step = 1
+        cu = torch.empty(B, dtype=torch.int32, device=dev)
+        cp = torch.empty(B, dtype=torch.int32, device=dev)
+        cn = torch.empty(B, K, dtype=torch.int64, device=dev)
+        cap = min((2 + K) * B, self.num_users + self.num_items)
+        send_rows = torch.empty(cap, dtype=torch.int64, device=dev)
+        counts = torch.empty(2 * self.world + 2, dtype=torch.int64, device=dev)
+        check(load().collie_shard_plan(
+            byref(batch), self.num_users, self.num_items, self.world, self.step, ptr(self.buf),
+            self.buf.numel(), ptr(cu), ptr(cp), ptr(cn), ptr(send_rows), cap, ptr(counts),
+            stream_ptr()), 'collie_shard_plan')
+        return cu, cp, cn, send_rows, counts
+
+
 # ---- evaluation -----------------------------------------------------------------------------------
 def eval_topk_capacity():
     return int(load().collie_mf_eval_topk_capacity())

@@ -14,7 +14,8 @@ gather and the owner-side optimizer step is one ``collie_sparse_rows_update`` ca
 Training step on a rank (``train_step``), for its slice of the global batch:
   1. unique user ids and unique item ids of the slice (positives and all K negatives), ordered by
      (owner, kind, id): that order IS the compact row numbering of the step;
-  2. all-to-all of the per-peer counts, then of the requested local row numbers;
+     (``collie_shard_plan``: stamp table + prefix sum, no sort);
+  2. all-to-all of the per-peer counts, then of the requested row numbers;
   3. owners gather the rows; all-to-all of embedding rows and bias values back.  The requester now
      holds compact tables ``[n, D]`` / ``[n]`` in its compact numbering;
   4. the fused forward kernel (``collie_mf_train_forward``) runs on the compact tables and compact
@@ -104,6 +105,14 @@ class HipEngine:
         self._eval_ws = ops.EvalWorkspace(self.device)
         self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
         self._acc = ops.optim_cfg('sgd', 1, -1.0)
+        self._planner = None
+
+    # requester-side plan of one step (collie_shard_plan)
+    def plan(self, model, users, pos_items, neg_items):
+        if self._planner is None:
+            self._planner = ops.ShardPlanner(model.hparams['num_users'], model.hparams['num_items'],
+                                             model.comm.world, self.device)
+        return self._planner.plan(users, pos_items, neg_items)
 
     # compact tables + compact ids -> (loss[1], grad rows [n, D], grad bias [n]), both * scale
     def train_grads(self, cemb, cbias, cu, cp, cn, kind, num_items, codes, weights, scale):
@@ -234,6 +243,39 @@ def shard_batch(batch, rank, world):
     lo = (B * rank) // world
     hi = (B * (rank + 1)) // world
     return (users[lo:hi], pos[lo:hi]), neg[lo:hi]
+
+
+def plan_torch(users, pos_items, neg_items, U, N, G):
+    """
+    Step 1 of the module docstring with torch index ops (any device; what the gloo tests run).
+    Same outputs, bit for bit, as ``collie_shard_plan`` (``HipEngine.plan``).
+    """
+    dev = users.device
+    B, K = neg_items.shape
+    uu, inv_u = torch.unique(users.long(), return_inverse=True)
+    ui, inv_i = torch.unique(torch.cat([pos_items.long(), neg_items.long().reshape(-1)]),
+                             return_inverse=True)
+    bad = (uu[0] < 0) | (uu[-1] >= U) | (ui[0] < 0) | (ui[-1] >= N)
+    uu, ui = uu.clamp(0, U - 1), ui.clamp(0, N - 1)
+    nu = uu.shape[0]
+    n = nu + ui.shape[0]
+    ids = torch.cat([uu, ui])
+    kind = torch.zeros(n, dtype=torch.int64, device=dev)
+    kind[nu:] = 1
+    owner = ids % G
+    route = owner * 2 + kind                     # ids ascend inside a route
+    order = torch.argsort(route, stable=True)
+    compact = torch.empty(n, dtype=torch.int64, device=dev)
+    compact[order] = torch.arange(n, dtype=torch.int64, device=dev)
+    u_loc = (U - owner + G - 1) // G             # the owner's user rows come first
+    send_rows = (ids // G + kind * u_loc)[order]
+    counts = torch.zeros(2 * G + 2, dtype=torch.int64, device=dev)
+    counts[:2 * G] = torch.bincount(route, minlength=2 * G)
+    counts[2 * G] = n
+    counts[2 * G + 1] = bad.to(torch.int64)
+    cu = compact[inv_u].to(torch.int32)
+    ci = compact[nu + inv_i]
+    return (cu, ci[:B].to(torch.int32), ci[B:].reshape(B, K).contiguous(), send_rows, counts)
 
 
 def _resolve_loss(loss, num_negative_samples):
@@ -395,47 +437,30 @@ class ShardedMatrixFactorizationModel:
         comm, G = self.comm, self.comm.world
         dev = users.device
         B, K = neg_items.shape
-        uu, inv_u = torch.unique(users.long(), return_inverse=True)
-        ui, inv_i = torch.unique(torch.cat([pos_items.long(), neg_items.long().reshape(-1)]),
-                                 return_inverse=True)
-        nu, ni = uu.shape[0], ui.shape[0]
-        n = nu + ni
-        ids = torch.cat([uu, ui])
-        kind = torch.zeros(n, dtype=torch.int64, device=dev)
-        kind[nu:] = 1
-        route = (ids % G) * 2 + kind                     # (owner, kind); ids ascend inside a route
-        order = torch.argsort(route, stable=True)
-        compact = torch.empty(n, dtype=torch.int64, device=dev)
-        compact[order] = torch.arange(n, dtype=torch.int64, device=dev)
-        send_rows = (ids // G)[order]
+        planner = getattr(self.engine, 'plan', None)
+        if planner is not None:
+            cu, cp, cn, send_rows, counts = planner(self, users, pos_items, neg_items)
+        else:
+            cu, cp, cn, send_rows, counts = plan_torch(
+                users, pos_items, neg_items, self.hparams['num_users'],
+                self.hparams['num_items'], G)
         # one small all-to-all: [users, items, B_local, id range flag] per peer
-        meta = torch.zeros(G, 4, dtype=torch.int64, device=dev)
-        meta[:, :2] = torch.bincount(route, minlength=2 * G).reshape(G, 2)
+        meta = torch.empty(G, 4, dtype=torch.int64, device=dev)
+        meta[:, :2] = counts[:2 * G].reshape(G, 2)
         meta[:, 2] = B
-        bad = ((uu[0] < 0) | (uu[-1] >= self.hparams['num_users'])
-               | (ui[0] < 0) | (ui[-1] >= self.hparams['num_items']))
-        meta[:, 3] = bad.to(torch.int64)
+        meta[:, 3] = counts[2 * G + 1]
         got = comm.all_to_all(meta, [1] * G, [1] * G)
         meta_h, got_h = torch.stack([meta, got]).cpu().tolist()        # the step's one host sync
-        if any(row[3] for row in got_h) or meta_h[0][3]:
+        if any(row[3] for row in got_h):
             raise IndexError('index out of range in self: a user or item id is outside the tables')
-        send_counts = [(r[0], r[1]) for r in meta_h]
-        recv_counts = [(r[0], r[1]) for r in got_h]
+        send_splits = [r[0] + r[1] for r in meta_h]
+        recv_splits = [r[0] + r[1] for r in got_h]
+        n = sum(send_splits)
         B_global = sum(r[2] for r in got_h)
-        send_splits = [a + b for a, b in send_counts]
-        recv_splits = [a + b for a, b in recv_counts]
-        req = comm.all_to_all(send_rows, send_splits, recv_splits)
-        # requested row of the combined local table: item rows sit behind the U_loc user rows
-        seg = torch.tensor([c for pair in recv_counts for c in pair], dtype=torch.int64, device=dev)
-        off = torch.tensor([0, self.U_loc] * G, dtype=torch.int64, device=dev)
-        crow = req + torch.repeat_interleave(off, seg)
-        cu = compact[inv_u].to(torch.int32)
-        ci = compact[nu + inv_i].to(torch.int32)
-        plan = dict(n=n, nu=nu, ni=ni, B=B, K=K, B_global=B_global, crow=crow,
-                    send_splits=send_splits, recv_splits=recv_splits,
-                    cu=cu, cp=ci[:B].contiguous(), cn=ci[B:].reshape(B, K).contiguous(),
-                    item_ids=ui, item_compact=compact[nu:])
-        return plan
+        # rows of the owner's combined table (user rows first, item rows behind them)
+        crow = comm.all_to_all(send_rows[:n], send_splits, recv_splits)
+        return dict(n=n, B=B, K=K, B_global=B_global, crow=crow, send_splits=send_splits,
+                    recv_splits=recv_splits, cu=cu, cp=cp, cn=cn)
 
     def train_step(self, batch) -> torch.Tensor:
         """
@@ -456,9 +481,10 @@ class ShardedMatrixFactorizationModel:
                                 p['send_splits'])
         # 4. fused forward + segment reduce on the compact tables
         codes = []
-        for c in self._codes or []:
+        for c in self._codes or []:          # category codes of the compact rows (items only)
             cc = torch.zeros(n, dtype=torch.int32, device=dev)
-            cc[p['item_compact']] = c[p['item_ids']]
+            cc[p['cp'].long()] = c[pos_items.long()]
+            cc[p['cn'].reshape(-1).long()] = c[neg_items.reshape(-1).long()]
             codes.append(cc)
         scale = torch.full((1,), p['B'] / p['B_global'], dtype=torch.float32, device=dev)
         loss, gemb, gbias = eng.train_grads(cemb, cbias, p['cu'], p['cp'], p['cn'],

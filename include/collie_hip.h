@@ -214,6 +214,30 @@ int collie_sparse_rows_update(float* table, int64_t num_rows, int32_t dim, const
                               collie_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Row-sharded training, requester side (no counterpart in the reference, which has no multi-GPU
+ * path for the tables: SURVEY.md 8e).  Replaces, for one rank's batch
+ * ((users, pos_items), neg_items) (base_pipeline.py:603-613), the host-side de-duplication a
+ * sharded nn.Embedding lookup would need: finds the distinct user / item rows the batch looks up,
+ * numbers them in (owner = id mod world, kind = user|item, id) order -- the order in which they are
+ * requested from and returned by the owners -- and rewrites the batch in those compact numbers.
+ *   compact_users [B] int32, compact_pos [B] int32, compact_neg [B, K] int64 (row major):
+ *                  compact row numbers, in the id dtypes the loaders use (so that the forward
+ *                  kernel takes the same route as on one GPU)
+ *   send_rows [n]: row to request, as a row of the owner's combined table (its user rows first,
+ *                  then its item rows); send_capacity >= min((2+K)B, num_users+num_items)
+ *   route_counts [2*world + 2] int64: rows per (owner, kind) route; [2*world] = n;
+ *                  [2*world + 1] = 1 if an id was outside the tables (such ids are skipped)
+ * workspace: collie_shard_plan_workspace_bytes() bytes, zero-filled at creation, private to one
+ * model; step_id >= 1 must increase by one per call.  world <= 16.
+ * ------------------------------------------------------------------------------------------- */
+size_t collie_shard_plan_workspace_bytes(int64_t num_users, int64_t num_items, int32_t world);
+int collie_shard_plan(const collie_mf_batch* b, int64_t num_users, int64_t num_items,
+                      int32_t world, int32_t step_id, void* workspace, size_t workspace_bytes,
+                      int32_t* compact_users, int32_t* compact_pos, int64_t* compact_neg,
+                      int64_t* send_rows, int64_t send_capacity, int64_t* route_counts,
+                      collie_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * A13-A17  get_preds + mapk / mrr / auc   collie/metrics.py:77-107,144-282
  *
  * The [users, items] score matrix of get_preds (metrics.py:102-107) is never written.  Scores are

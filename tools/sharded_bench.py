@@ -1,0 +1,35 @@
+"""Time the row-sharded train step at world size 1 (exchange degenerates to local copies): shows
+what the sharded route costs on top of the fused single-GPU step.  python tools/sharded_bench.py B"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from collie_amd.sharded import ShardedMatrixFactorizationModel  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+dev = torch.device('cuda:0')
+m = ShardedMatrixFactorizationModel(bench.NUM_USERS, bench.NUM_ITEMS, bench.NUM_NEG,
+                                    embedding_dim=bench.DIM, loss='bpr', device=dev)
+batches = bench.synthetic_batches(8, B, dev, 'uniform', 1)
+for i in range(5):
+    m.train_step(batches[i % 8])
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for i in range(steps):
+    m.train_step(batches[i % 8])
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / steps
+print(f'B={B}: {dt * 1e3:.3f} ms/step, {B * 11 / dt / 1e9:.3f} G interactions/s, '
+      f'rows/step {m.last_exchange}')
+if os.environ.get('PROFILE'):
+    from torch.profiler import ProfilerActivity, profile
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        for i in range(5):
+            m.train_step(batches[i % 8])
+        torch.cuda.synchronize()
+    print(prof.key_averages().table(sort_by='cuda_time_total', row_limit=25))
