@@ -690,11 +690,48 @@ __global__ __launch_bounds__(kBlock, (CH <= 4 ? 8 : 4)) void mf_train_fwd_lds(co
   const bool neg_lane = grp >= 1 && row_lane;
 
   float loss1 = 0.0f, loss2 = 0.0f;
-  const int64_t nw = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
-  int64_t b = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave_in_block;
+  // A wave owns a contiguous range of samples, so that the per-sample sort entries and gradient
+  // coefficients (wave-uniform values) can be collected one per lane and written 64 samples at a
+  // time as full lines instead of as 3-lane stores every iteration.
+  const int64_t total_waves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+  const int64_t per = (B + total_waves - 1) / total_waves;
+  int64_t b = (static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave_in_block) * per;
+  const int64_t b_end = b + per < B ? b + per : B;
+  uint32_t e_uk = 0, e_uc = 0, e_pk = 0, e_pc = 0, e_nk = 0, e_nc = 0;
+  float e_g = 0.0f;
+  int filled = 0;  // samples collected since the last flush
+  auto flush = [&](int64_t first) {
+    if (lane < filled) {
+      const int64_t bb = first + lane;
+      p.ekeys[bb] = e_uk;
+      p.ecodes[bb] = e_uc;
+      p.gcoef[bb] = e_g;
+      p.ekeys[B + 2 * bb] = e_pk;
+      p.ekeys[B + 2 * bb + 1] = e_nk;
+      p.ecodes[B + 2 * bb] = e_pc;
+      p.ecodes[B + 2 * bb + 1] = e_nc;
+    }
+  };
+  auto collect = [&](int64_t bb, uint32_t uk, uint32_t pk, uint32_t nk, bool live, float g) {
+    if (lane == filled) {
+      const uint32_t code = live ? static_cast<uint32_t>(bb) : kCodeNone;
+      e_uk = uk;
+      e_pk = pk;
+      e_nk = nk;
+      e_uc = code;
+      e_pc = code;
+      e_nc = live ? (code | kCodeNeg) : kCodeNone;
+      e_g = g;
+    }
+    if (++filled == kWave) {
+      flush(bb - (kWave - 1));
+      filled = 0;
+    }
+  };
+
   LdsIds next = {0, 0, 0};
-  if (b < B) next = load_lds_ids<LPR>(p, b, neg_lane_off);
-  for (; b < B; b += nw) {
+  if (b < b_end) next = load_lds_ids<LPR>(p, b, neg_lane_off);
+  for (; b < b_end; ++b) {
     const LdsIds cur = next;
     const int u = __builtin_amdgcn_readfirstlane(cur.u);
     const int pos_item = __builtin_amdgcn_readfirstlane(cur.pos);
@@ -704,14 +741,9 @@ __global__ __launch_bounds__(kBlock, (CH <= 4 ? 8 : 4)) void mf_train_fwd_lds(co
                      (__ballot(bad_lane) != 0ull);
     const int item = static_cast<int>(item64);
     if (bad) {  // wave-uniform: never touch memory through a bad id
-      if (b + nw < B) next = load_lds_ids<LPR>(p, b + nw, neg_lane_off);
+      if (b + 1 < b_end) next = load_lds_ids<LPR>(p, b + 1, neg_lane_off);
       if (lane == 0 && p.status) atomicOr(p.status, 1);
-      if (p.need_grad && lane < 3) {
-        const int64_t slot = lane == 0 ? b : B + 2 * b + (lane - 1);
-        p.ekeys[slot] = lane == 0 ? 0u : key_off;
-        p.ecodes[slot] = kCodeNone;
-        if (lane == 0) p.gcoef[b] = 0.0f;
-      }
+      if (p.need_grad) collect(b, 0u, key_off, key_off, false, 0.0f);
       continue;
     }
 
@@ -725,7 +757,11 @@ __global__ __launch_bounds__(kBlock, (CH <= 4 ? 8 : 4)) void mf_train_fwd_lds(co
     }
     const float ub = p.user_bias[u];
     const float ib = p.item_bias[item];
-    if (b + nw < B) next = load_lds_ids<LPR>(p, b + nw, neg_lane_off);
+    // the item's stamp: most items of a large batch were already stamped by another sample of
+    // this step; a stale read only costs a redundant store
+    int stamp = 0;
+    if (p.need_grad) stamp = p.touch_item[item];
+    if (b + 1 < b_end) next = load_lds_ids<LPR>(p, b + 1, neg_lane_off);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // ---- dot products: chunk order i, then across the LPR lanes of the row ----------------------
@@ -789,16 +825,7 @@ __global__ __launch_bounds__(kBlock, (CH <= 4 ? 8 : 4)) void mf_train_fwd_lds(co
 
     // ---- backward staging ---------------------------------------------------------------------
     const bool live = g != 0.0f;
-    if (lig == 0 && row_lane) p.touch_item[item] = p.step_id;
-    if (lane < 3) {  // lane 0: user entry, lane 1: positive item, lane 2: selected negative
-      const int64_t slot = lane == 0 ? b : B + 2 * b + (lane - 1);
-      const uint32_t key =
-          lane == 0 ? static_cast<uint32_t>(u)
-                    : key_off + static_cast<uint32_t>(lane == 1 ? pos_item : best_item);
-      p.ekeys[slot] = key;
-      p.ecodes[slot] = live ? (static_cast<uint32_t>(b) | (lane == 2 ? kCodeNeg : 0u)) : kCodeNone;
-      if (lane == 0) p.gcoef[b] = g;
-    }
+    if (lig == 0 && row_lane && stamp != p.step_id) p.touch_item[item] = p.step_id;
     if (live && lane < CH * LPR) {  // lane l stages 16-byte chunk l of the two rows
       const int i = lane / LPR, l2 = lane % LPR;
       const float4 uu = user_l[lane];
@@ -816,7 +843,10 @@ __global__ __launch_bounds__(kBlock, (CH <= 4 ? 8 : 4)) void mf_train_fwd_lds(co
       *reinterpret_cast<float4*>(p.stage_u + b * D + lane * 4) = gu;
       *reinterpret_cast<float4*>(p.stage_i + b * D + lane * 4) = gi;
     }
+    collect(b, static_cast<uint32_t>(u), key_off + static_cast<uint32_t>(pos_item),
+            key_off + static_cast<uint32_t>(best_item), live, g);
   }
+  if (p.need_grad && filled > 0) flush(b_end - filled);
 
   __shared__ float red[2][kWavesPerBlock];
   if (lane == 0) {

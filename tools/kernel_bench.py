@@ -16,14 +16,14 @@ from collie_amd import _lib, ops  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('what', choices=['fwd', 'step', 'eval'])
+    ap.add_argument('what', choices=['fwd', 'fwd_nograd', 'step', 'eval'])
     ap.add_argument('--batch', type=int, default=1048576)
     ap.add_argument('--iters', type=int, default=10)
     ap.add_argument('--users', type=int, default=16384)
     args = ap.parse_args()
     dev = torch.device('cuda:0')
     model = bench.build_model(dev)
-    if args.what in ('fwd', 'step'):
+    if args.what in ('fwd', 'fwd_nograd', 'step'):
         batches = bench.synthetic_batches(4, args.batch, dev, 'uniform', 1)
         opts = model.configure_optimizers()
         for i in range(3):
@@ -31,9 +31,10 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(args.iters):
-            if args.what == 'fwd':
+            if args.what == 'fwd_nograd':
                 with torch.no_grad():
-                    pass
+                    model.calculate_loss(batches[i % 4])
+            elif args.what == 'fwd':
                 for o in opts:
                     o.zero_grad()
                 model.calculate_loss(batches[i % 4])
