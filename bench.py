@@ -61,11 +61,13 @@ def synthetic_batches(n, batch, device, dist, seed):
     out = []
     for _ in range(n):
         if dist == 'zipf':
-            # Zipf(1.05) popularity over a random permutation of ids (inverse-CDF on a power law)
+            # Zipf(1.05) popularity over ranks 1..rows: P(r) ~ r^-1.05, by inverting the CDF of the
+            # continuous power law on [1, rows + 1) (id = rank - 1: hot ids are the low ones)
             def zipf(rows):
-                u = torch.rand(batch, device=device, generator=g)
-                r = (torch.pow(u, -1.0 / 0.05) - 1.0).clamp_(0, rows - 1)
-                return r.to(torch.int32)
+                a = 0.05                                        # s - 1
+                u = torch.rand(batch, device=device, generator=g, dtype=torch.float64)
+                r = torch.pow(1.0 - u * (1.0 - (rows + 1.0) ** -a), -1.0 / a)
+                return (r.floor().clamp_(1, rows) - 1).to(torch.int32)
             users, pos = zipf(NUM_USERS), zipf(NUM_ITEMS)
         else:
             users = torch.randint(0, NUM_USERS, (batch,), device=device, generator=g, dtype=torch.int32)
@@ -90,6 +92,23 @@ def fwd_algorithmic_bytes(batch):
     idx = batch * (4 + 4) + batch * NUM_NEG * 8
     rows = (batch + (1 + NUM_NEG) * batch) * (DIM + 1) * 4
     return idx + rows
+
+
+def pmc_traffic(batch):
+    """
+    HBM-side bytes per launch of the forward kernel, from the committed rocprofv3 --pmc passes of
+    this same command (profiles/r01_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in
+    separate runs, KiB -> bytes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).
+    A PMC pass cannot run inside the timed benchmark, so the number is read, not measured live;
+    None when no pass was recorded for this batch size.
+    """
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+    try:
+        with open(path) as f:
+            rec = json.load(f).get(str(batch))
+    except (OSError, ValueError):
+        return None
+    return rec['traffic_bytes'] if rec else None
 
 
 def cpu_baseline(seconds=12.0, batch=1024):
@@ -235,7 +254,8 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--batch', type=int, default=65536, help='positives per step per GPU')
+    ap.add_argument('--batch', type=int, default=1048576,
+                    help='positives per step per GPU (SURVEY.md 8d lists 1024, 65536, 1048576)')
     ap.add_argument('--dist', choices=['uniform', 'zipf'], default='uniform')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--eval-users', type=int, default=65536,
@@ -319,10 +339,10 @@ def main():
                 'final_loss': final_loss,
             },
             'roofline': {
-                'kernel': 'mf_train_fwd_fast<4,16,1,false,false> + loss_finalize_kernel '
-                          '(calculate_loss: fused gather + dot + loss + backward staging)',
+                'kernel': 'mf_train_fwd_lds<4,4,1,false> (+ loss_finalize_kernel, 5 us): calculate_loss = '
+                          'fused gather + dot + loss + backward staging',
                 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic(args.batch),
                 'algorithmic_bytes_per_launch': alg, 'avg_launch_ms': fwd_ms,
             },
         }

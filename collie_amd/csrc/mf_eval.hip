@@ -185,34 +185,52 @@ __global__ __launch_bounds__(kBlock) void eval_gemm_kernel(const EvalParams p) {
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], ufrag[q][3], acc, 0, 0, 0);
       }
       // ---- epilogue: this lane's user x 16 items (rows (r&3) + 8(r>>2) + 4h of the tile) ------
+      if (MODE == 0) {
+        // scores first (rows past the shard end become -inf), one test for the whole sub-tile:
+        // after warm-up almost no sub-tile holds a score that enters the list
+        float smax = -INFINITY;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const int64_t item = base + row;
-        const float s = finish_score(acc[r], ub, tile_bias[row]);
-        const bool in = item < chunk_end;
-        if (MODE == 0) {
-          if (in && s > top_s[kCap - 1]) {
-            // insertion into the sorted list (rare after warm-up; divergent lanes wait)
-            float cs = s;
-            int ci = static_cast<int>(item * p.id_stride + p.id_offset);
+        for (int r = 0; r < 16; ++r) {
+          const int row = sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const float s = finish_score(acc[r], ub, tile_bias[row]);
+          acc[r] = base + row < chunk_end ? s : -INFINITY;
+          smax = fmaxf(smax, acc[r]);
+        }
+        if (smax > top_s[kCap - 1]) {
 #pragma unroll
-            for (int i = 0; i < kCap; ++i) {
-              const bool better = cs > top_s[i];
-              const float ts = top_s[i];
-              const int ti = top_i[i];
-              top_s[i] = better ? cs : ts;
-              top_i[i] = better ? ci : ti;
-              cs = better ? ts : cs;
-              ci = better ? ti : ci;
+          for (int r = 0; r < 16; ++r) {
+            if (acc[r] > top_s[kCap - 1]) {
+              // insertion into the sorted list (items arrive in ascending id order inside a lane,
+              // so the strict '>' keeps ties in id order)
+              const int row = sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+              float cs = acc[r];
+              int ci = static_cast<int>((base + row) * p.id_stride + p.id_offset);
+#pragma unroll
+              for (int i = 0; i < kCap; ++i) {
+                const bool better = cs > top_s[i];
+                const float ts = top_s[i];
+                const int ti = top_i[i];
+                top_s[i] = better ? cs : ts;
+                top_i[i] = better ? ci : ti;
+                cs = better ? ts : cs;
+                ci = better ? ti : ci;
+              }
             }
           }
-        } else if (in && user_ok) {
-          const int64_t gid = item * p.id_stride + p.id_offset;
-          c_above += (s > bscore || (s == bscore && gid < bid)) ? 1ull : 0ull;
-          for (int64_t e = e_begin; e < e_end; ++e) {
-            c_lt += s < p.thr_lo[e] ? 1ull : 0ull;
-            c_le += s <= p.thr_hi[e] ? 1ull : 0ull;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const int64_t item = base + row;
+          const float s = finish_score(acc[r], ub, tile_bias[row]);
+          if (item < chunk_end && user_ok) {
+            const int64_t gid = item * p.id_stride + p.id_offset;
+            c_above += (s > bscore || (s == bscore && gid < bid)) ? 1ull : 0ull;
+            for (int64_t e = e_begin; e < e_end; ++e) {
+              c_lt += s < p.thr_lo[e] ? 1ull : 0ull;
+              c_le += s <= p.thr_hi[e] ? 1ull : 0ull;
+            }
           }
         }
       }
