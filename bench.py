@@ -35,6 +35,8 @@ sys.path.insert(0, ROOT)
 NUM_USERS, NUM_ITEMS, NUM_INTERACTIONS = 138_493, 26_744, 20_000_263
 DIM, NUM_NEG = 64, 10
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+WORKLOAD = ('BASELINE configs[1]: synthetic ML-20M shape 138493 users x 26744 items, MF dim=64, '
+            'adaptive BPR + 10 negatives, SparseAdam + SGD bias')
 
 
 class _Shape:
@@ -46,9 +48,10 @@ class _Shape:
 def build_model(device):
     from collie_amd.model import MatrixFactorizationModel
     torch.manual_seed(0)
-    model = MatrixFactorizationModel(train=_Shape(), embedding_dim=DIM, sparse=True, lr=1e-3,
-                                     bias_lr=1e-2, optimizer='sparse_adam', bias_optimizer='sgd',
-                                     loss='bpr', lr_scheduler_func=None)
+    with torch.device(device):                 # tables are created (and initialised) in HBM
+        model = MatrixFactorizationModel(train=_Shape(), embedding_dim=DIM, sparse=True, lr=1e-3,
+                                         bias_lr=1e-2, optimizer='sparse_adam', bias_optimizer='sgd',
+                                         loss='bpr', lr_scheduler_func=None)
     model.to(device)
     model.train()
     return model
@@ -92,6 +95,21 @@ def fwd_algorithmic_bytes(batch):
     idx = batch * (4 + 4) + batch * NUM_NEG * 8
     rows = (batch + (1 + NUM_NEG) * batch) * (DIM + 1) * 4
     return idx + rows
+
+
+def step_algorithmic_bytes(batch_tensors):
+    """
+    SURVEY.md §8d whole-step figure for one batch: ``idx + fwd + opt`` with
+    ``opt = (u* + i*) * D * 4 * 6`` (SparseAdam reads and writes p, m, v of every looked-up row,
+    zero-gradient rows included) ``+ (u* + i*) * 4 * 2`` (bias SGD), u* / i* = unique user / item
+    rows of the step (items: positives and all K negatives).
+    """
+    (users, pos), neg = batch_tensors
+    B = users.shape[0]
+    u_star = int(torch.unique(users).numel())
+    i_star = int(torch.unique(torch.cat([pos.long(), neg.reshape(-1)])).numel())
+    opt = (u_star + i_star) * DIM * 4 * 6 + (u_star + i_star) * 4 * 2
+    return fwd_algorithmic_bytes(B) + opt, u_star, i_star
 
 
 def pmc_traffic(batch):
@@ -232,8 +250,7 @@ def main_sharded(args, world, rank, device):
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {
-                'workload': 'BASELINE configs[1]: synthetic ML-20M shape 138493 users x 26744 '
-                            'items, MF dim=64, adaptive BPR + 10 negatives, SparseAdam + SGD bias',
+                'workload': WORKLOAD,
                 'batch_per_gpu': args.batch, 'global_batch': args.batch * world,
                 'id_distribution': args.dist,
                 'parallelism': f'tables row-sharded over {world} GPUs (owner = row mod {world}), '
@@ -257,11 +274,20 @@ def main():
     ap.add_argument('--batch', type=int, default=1048576,
                     help='positives per step per GPU (SURVEY.md 8d lists 1024, 65536, 1048576)')
     ap.add_argument('--dist', choices=['uniform', 'zipf'], default='uniform')
+    ap.add_argument('--shape', choices=['c2', 'c4'], default='c2',
+                    help="c2 = BASELINE configs[1] (the headline line); c4 = configs[3]'s tables "
+                         '(100M users x 10M items, dim 128) on ONE GPU: the shape no cache holds')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--eval-users', type=int, default=65536,
                     help='users in the eval leg (0 = skip it)')
     args = ap.parse_args()
 
+    if args.shape == 'c4':
+        global NUM_USERS, NUM_ITEMS, NUM_INTERACTIONS, DIM, WORKLOAD
+        NUM_USERS, NUM_ITEMS, NUM_INTERACTIONS, DIM = 100_000_000, 10_000_000, 0, 128
+        _Shape.num_users, _Shape.num_items = NUM_USERS, NUM_ITEMS
+        WORKLOAD = ('BASELINE configs[3] tables on one GPU: synthetic 100M users x 10M items, MF '
+                    'dim=128, adaptive BPR + 10 negatives, SparseAdam + SGD bias')
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -312,6 +338,7 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
+        step_bytes, u_star, i_star = step_algorithmic_bytes(batches[0])
         fwd_ms = float(np.mean([a.elapsed_time(b) for a, b in fwd_events]))
         per_step = args.batch * (1 + NUM_NEG)
         value = world * per_step * args.steps / elapsed
@@ -331,19 +358,28 @@ def main():
             'dtype': 'f32',
             'data': 'synthetic',
             'config': {
-                'workload': 'BASELINE configs[1]: synthetic ML-20M shape 138493 users x 26744 '
-                            'items, MF dim=64, adaptive BPR + 10 negatives, SparseAdam + SGD bias',
+                'workload': WORKLOAD,
                 'batch_per_gpu': args.batch, 'global_batch': args.batch * world,
                 'id_distribution': args.dist,
                 'parallelism': 'single GPU' if world == 1 else f'{world} independent replicas',
                 'final_loss': final_loss,
             },
             'roofline': {
-                'kernel': 'mf_train_fwd_lds<4,4,1,false> (+ loss_finalize_kernel, 5 us): calculate_loss = '
+                'kernel': ('mf_train_fwd_lds<4,4,1,false>' if DIM == 64 else
+                           'mf_train_fwd_lds<8,4,1,false>') +
+                          ' (+ loss_finalize_kernel, 5 us): calculate_loss = '
                           'fused gather + dot + loss + backward staging',
                 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic(args.batch),
+                'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic(args.batch) if args.shape == 'c2' else None,
                 'algorithmic_bytes_per_launch': alg, 'avg_launch_ms': fwd_ms,
+                'whole_step': {
+                    'note': 'all kernels of the step (forward + coalesce + optimizer row updates): '
+                            'SURVEY.md 8d bytes_step = idx + fwd + opt over wall time per step',
+                    'algorithmic_bytes_per_step': step_bytes, 'unique_user_rows': u_star,
+                    'unique_item_rows': i_star,
+                    'achieved': step_bytes / (elapsed / args.steps) / 1e9, 'unit': 'GB/s',
+                    'frac': step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+                },
             },
         }
         if not args.no_cpu_baseline and world == 1:

@@ -325,6 +325,72 @@ __global__ __launch_bounds__(kBlock) void touched_sweep_kernel(float* __restrict
   }
 }
 
+// Row-granular variant of the sweep for float4-aligned rows: a wave scans 64 consecutive stamps
+// with one coalesced load, compacts the rows that need the zero-gradient update into a wave-private
+// LDS list, and then LPR lanes own one such row (64 / LPR rows in flight per wave, every lane with
+// up to 4 chunks x (p, m, v) 16-byte loads outstanding before the first use).
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void touched_rows_kernel(float* __restrict__ table,
+                                                              float* __restrict__ s1p,
+                                                              float* __restrict__ s2p,
+                                                              const int32_t* __restrict__ touch,
+                                                              const int32_t* __restrict__ seg,
+                                                              int64_t rows, int D, int step,
+                                                              const Hyper h) {
+  constexpr int GPW = kWave / LPR;
+  __shared__ int list[kWavesPerBlock][kWave];
+  const int lane = lane_id();
+  const int wave = threadIdx.x / kWave;
+  const int grp = lane / LPR;
+  const int lig = lane % LPR;
+  const int nchunks = D / 4;
+  const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+  for (int64_t base = (static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave) * kWave;
+       base < rows; base += nwaves * kWave) {
+    const int64_t r = base + lane;
+    const bool need = r < rows && touch[r] == step && seg[r] != step;
+    const unsigned long long mask = __ballot(need);
+    if (mask == 0ull) continue;
+    const int n = __popcll(mask);
+    if (need) list[wave][__popcll(mask & ((1ull << lane) - 1ull))] = lane;
+    __builtin_amdgcn_wave_barrier();
+    for (int i0 = 0; i0 < n; i0 += GPW) {
+      const int i = i0 + grp;
+      const bool on_row = i < n;
+      const int64_t row = base + list[wave][on_row ? i : 0];
+      for (int c0 = 0; c0 < nchunks; c0 += 4 * LPR) {
+        float4 pv[4], m[4], v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c = c0 + q * LPR + lig;
+          if (on_row && c < nchunks) {
+            const int64_t off = row * D + c * 4;
+            pv[q] = *reinterpret_cast<const float4*>(table + off);
+            m[q] = *reinterpret_cast<const float4*>(s1p + off);
+            v[q] = *reinterpret_cast<const float4*>(s2p + off);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c = c0 + q * LPR + lig;
+          if (on_row && c < nchunks) {
+            const int64_t off = row * D + c * 4;
+            float4 np;
+            np.x = apply_update(h, pv[q].x, 0.0f, m[q].x, v[q].x);
+            np.y = apply_update(h, pv[q].y, 0.0f, m[q].y, v[q].y);
+            np.z = apply_update(h, pv[q].z, 0.0f, m[q].z, v[q].z);
+            np.w = apply_update(h, pv[q].w, 0.0f, m[q].w, v[q].w);
+            *reinterpret_cast<float4*>(table + off) = np;
+            *reinterpret_cast<float4*>(s1p + off) = m[q];
+            *reinterpret_cast<float4*>(s2p + off) = v[q];
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void export_touched_kernel(const int32_t* __restrict__ touch,
                                                                 int64_t rows, int step,
                                                                 uint8_t* __restrict__ out) {
@@ -549,9 +615,25 @@ extern "C" int collie_mf_train_update(const collie_mf_tables* t, const collie_mf
       if (check_launch("dense_sweep_kernel")) return -2;
     }
     if (touched[side]) {
-      hipLaunchKernelGGL(touched_sweep_kernel, dim3(sweep_grid(rows * p.D)), dim3(kBlock), 0,
-                         stream, d.table, d.s1, d.s2, ws.touch_item, ws.seg_item, rows, p.D, p.step,
-                         d.h);
+      auto al16 = [](const void* q) { return reinterpret_cast<uintptr_t>(q) % 16 == 0; };
+      if (p.D % 4 == 0 && al16(d.table) && al16(d.s1) && al16(d.s2)) {
+        // rows of 16-byte chunks: 4, 8 or 16 lanes per row (at most 4 chunks per lane and pass)
+        const int nchunks = p.D / 4;
+        const unsigned grid = sweep_grid(rows * 4);
+        if (nchunks <= 16)
+          hipLaunchKernelGGL(touched_rows_kernel<4>, dim3(grid), dim3(kBlock), 0, stream, d.table,
+                             d.s1, d.s2, ws.touch_item, ws.seg_item, rows, p.D, p.step, d.h);
+        else if (nchunks <= 32)
+          hipLaunchKernelGGL(touched_rows_kernel<8>, dim3(grid), dim3(kBlock), 0, stream, d.table,
+                             d.s1, d.s2, ws.touch_item, ws.seg_item, rows, p.D, p.step, d.h);
+        else
+          hipLaunchKernelGGL(touched_rows_kernel<16>, dim3(grid), dim3(kBlock), 0, stream, d.table,
+                             d.s1, d.s2, ws.touch_item, ws.seg_item, rows, p.D, p.step, d.h);
+      } else {
+        hipLaunchKernelGGL(touched_sweep_kernel, dim3(sweep_grid(rows * p.D)), dim3(kBlock), 0,
+                           stream, d.table, d.s1, d.s2, ws.touch_item, ws.seg_item, rows, p.D,
+                           p.step, d.h);
+      }
       if (check_launch("touched_sweep_kernel")) return -2;
     }
   }
