@@ -183,16 +183,16 @@ def eval_leg(device, n_users, sharded_world=1, group_rank=0):
             model.item_biases.weight.normal_(0, 0.01)
         model.to(device)
 
-        def run():
-            return M.evaluate_in_batches([M.mapk], test, model, k=10, verbose=False)
+        def run(metrics=(M.mapk,)):
+            return M.evaluate_in_batches(list(metrics), test, model, k=10, verbose=False)
     else:
         from collie_amd.sharded import ShardedMatrixFactorizationModel
         model = ShardedMatrixFactorizationModel(EVAL_USERS, EVAL_ITEMS, 1, embedding_dim=EVAL_DIM,
                                                 loss='bpr', device=device, seed=0)
         model.bias.normal_(0, 0.01)
 
-        def run():
-            return model.evaluate_in_batches([M.mapk], test, k=10)
+        def run(metrics=(M.mapk,)):
+            return model.evaluate_in_batches(list(metrics), test, k=10)
     run()                                                      # warm-up (workspace, first launches)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -200,12 +200,19 @@ def eval_leg(device, n_users, sharded_world=1, group_rank=0):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     flops = 2.0 * n_users * EVAL_ITEMS * EVAL_DIM
+    # the same users with all three metrics (one more scoring pass for the MRR / AUC rank counts)
+    t0 = time.perf_counter()
+    all3 = run((M.mapk, M.mrr, M.auc))
+    torch.cuda.synchronize()
+    dt3 = time.perf_counter() - t0
     return {'metric': 'eval users/sec MAP@10', 'value': n_users / dt, 'unit': 'users/s',
             'workload': f'BASELINE configs[2] shape: {EVAL_USERS} users x {EVAL_ITEMS} items, dim '
                         f'{EVAL_DIM}, {EVAL_POS} test items per user, k=10; sample of {n_users} '
                         'users through evaluate_in_batches([mapk]) end to end (CSR slicing on the '
                         'host included)',
             'seconds': dt, 'map_at_10': float(score),
+            'mapk_mrr_auc': {'value': n_users / dt3, 'unit': 'users/s', 'seconds': dt3,
+                             'scores': [float(x) for x in all3]},
             'mfma': {'bound': 'mfma', 'achieved': flops / dt / 1e12, 'peak': MFMA_F32_PEAK_TFLOPS,
                      'unit': 'TFLOP/s', 'frac': flops / dt / 1e12 / MFMA_F32_PEAK_TFLOPS,
                      'note': 'end-to-end time, not kernel time: a lower bound on the kernel rate'}}

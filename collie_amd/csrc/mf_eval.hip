@@ -253,6 +253,270 @@ __global__ __launch_bounds__(kBlock) void eval_gemm_kernel(const EvalParams p) {
   }
 }
 
+// ---- K6, LDS-DMA variant (embedding_dim 32 / 64 / 128, float4-aligned tables) ----------------------
+// Same MFMA mapping, same k order (so chain_dot() still reproduces every score bit for bit), but
+//   * 8 waves = 256 users share each 64-item tile (half the L2 -> LDS traffic per flop);
+//   * the tile never passes through VGPRs: global_load_lds_dwordx4 writes it straight into one of
+//     two LDS buffers, so tile t+1 is in flight during all of tile t's MFMAs (one barrier per tile);
+//   * an LDS-DMA destination is wave-linear, so rows cannot be padded; the bank-conflict-free image
+//     is an XOR swizzle applied on the per-lane SOURCE address instead: 16-byte chunk c of tile row
+//     r lives at slot r * CPR + (c ^ (r % S)), S = min(16, CPR), and the A-fragment reads apply the
+//     same XOR.
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int kBlockDma = 512;
+constexpr int kWavesDma = kBlockDma / kWave;
+constexpr int kUsersPerBlockDma = 32 * kWavesDma;  // 256
+
+// t_lt += #{e < N: s < lo_e}, t_le += #{e < N: s <= hi_e} over register-resident thresholds
+template <int N>
+__device__ __forceinline__ void count_thr(float s, const float (&lo)[kCap], const int (&hi)[kCap],
+                                          uint32_t& t_lt, uint32_t& t_le) {
+#pragma unroll
+  for (int e = 0; e < N; ++e) {
+    t_lt += s < lo[e] ? 1u : 0u;
+    t_le += s <= __int_as_float(hi[e]) ? 1u : 0u;
+  }
+}
+
+// rank counters of one lane's 16 scores of a sub-tile; N = threshold registers in use (one fully
+// unrolled, statically indexed instance per wave-uniform tier)
+template <int N>
+__device__ __forceinline__ void rank_subtile(const f32x16& acc, const float (&lo)[kCap],
+                                             const int (&hi)[kCap], float bscore, int bid,
+                                             int64_t gid0, int64_t id_stride, uint32_t& t_above,
+                                             uint32_t& t_lt, uint32_t& t_le) {
+#pragma unroll
+  for (int rr = 0; rr < 16; ++rr) {
+    const float s = acc[rr];
+    const int64_t gid = gid0 + ((rr & 3) + 8 * (rr >> 2)) * id_stride;
+    t_above += (s > bscore || (s == bscore && gid < bid)) ? 1u : 0u;
+    count_thr<N>(s, lo, hi, t_lt, t_le);
+  }
+}
+
+template <int D8, int MODE>
+__global__ __launch_bounds__(kBlockDma) void eval_gemm_dma_kernel(const EvalParams p) {
+  constexpr int D = D8 * 8;
+  constexpr int CPR = D / 4;                     // 16-byte chunks per row
+  constexpr int S = CPR < 16 ? CPR : 16;         // swizzle span
+  constexpr int kTileF4 = kTileItems * CPR;      // float4 slots per tile
+  constexpr int kPerWave = CPR / kWavesDma;      // DMA instructions per wave per tile
+  constexpr int kBufF4 = kTileF4 + kTileItems / 4;  // tile + its 64 item biases
+  static_assert(kPerWave >= 1, "embedding_dim >= 32");
+  __shared__ float4 smem[2 * kBufF4];            // ONE array: both tiles and both bias vectors
+
+  const int lane = lane_id();
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const int col = lane & 31;
+  const int h = lane >> 5;
+
+  const int64_t uslot = static_cast<int64_t>(blockIdx.x) * kUsersPerBlockDma + wave * 32 + col;
+  const bool user_ok = uslot < p.n_users;
+  int64_t uid = p.user_ids[user_ok ? uslot : p.n_users - 1];
+  if (uid < 0) uid = 0;
+  if (uid >= p.t.num_users) uid = p.t.num_users - 1;
+  const float* urow = p.t.user_emb + uid * D;
+  const float ub = p.t.user_bias[uid];
+  f32x4 ufrag[D8];
+#pragma unroll
+  for (int q = 0; q < D8; ++q) ufrag[q] = *reinterpret_cast<const f32x4*>(urow + 8 * q + 4 * h);
+
+  float top_s[kCap];
+  int top_i[kCap];
+  unsigned long long c_above = 0, c_lt = 0, c_le = 0, c_below_all = 0;
+  int64_t e_begin = 0, e_end = 0;
+  float bscore = 0.0f, lo_min = INFINITY, hi_max = -INFINITY;
+  int bid = 0;
+  if (MODE == 0) {
+#pragma unroll
+    for (int i = 0; i < kCap; ++i) {
+      top_s[i] = -INFINITY;
+      top_i[i] = 0x7fffffff;
+    }
+  } else {
+    // the first kThr (lo, hi) threshold pairs of the user's positives live in registers (they take
+    // the place of the top-k list); unused slots hold -inf, which no score is below.  The rare
+    // user with more positives walks the rest of its CSR row per score (lo_min / hi_max bound the
+    // scores that can differ from "below all" / "above all" of that remainder).
+#pragma unroll
+    for (int i = 0; i < kCap; ++i) {
+      top_s[i] = -INFINITY;
+      top_i[i] = __float_as_int(-INFINITY);
+    }
+    if (user_ok) {
+      e_begin = p.indptr[uslot];
+      e_end = p.indptr[uslot + 1];
+      bscore = p.best_score[uslot];
+      bid = static_cast<int>(p.best_id[uslot]);
+#pragma unroll
+      for (int i = 0; i < kCap; ++i) {
+        if (e_begin + i < e_end) {
+          top_s[i] = p.thr_lo[e_begin + i];
+          top_i[i] = __float_as_int(p.thr_hi[e_begin + i]);
+        }
+      }
+      for (int64_t e = e_begin + kCap; e < e_end; ++e) {
+        lo_min = fminf(lo_min, p.thr_lo[e]);
+        hi_max = fmaxf(hi_max, p.thr_hi[e]);
+      }
+    }
+  }
+  // wave-uniform number of register-resident threshold pairs in use (the rest are skipped)
+  int npos_here = static_cast<int>(e_end - e_begin);
+  if (npos_here > kCap) npos_here = kCap;
+  int n_thr = npos_here;
+#pragma unroll
+  for (int o = kWave / 2; o > 0; o >>= 1) n_thr = max(n_thr, __shfl_xor(n_thr, o, kWave));
+  n_thr = __builtin_amdgcn_readfirstlane(n_thr);
+  const bool any_long = __ballot(e_end - e_begin > kCap) != 0ull;
+  const int k = p.k;
+
+  const int64_t chunk_items = static_cast<int64_t>(p.tiles_per_chunk) * kTileItems;
+  const int64_t chunk_begin = p.item_begin + static_cast<int64_t>(blockIdx.y) * chunk_items;
+  int64_t chunk_end = chunk_begin + chunk_items;
+  if (chunk_end > p.item_end) chunk_end = p.item_end;
+  const int64_t last_row = p.item_end - 1;       // rows past the shard end re-read this one (masked)
+
+  // per-lane constants of the DMA: slot i = I * 64 + lane of the tile, I = wave * kPerWave + n
+  auto issue = [&](int64_t base, int buf) {
+    float4* dst = smem + buf * kBufF4;
+#pragma unroll
+    for (int n = 0; n < kPerWave; ++n) {
+      const int I = wave * kPerWave + n;
+      const int i = I * kWave + lane;
+      const int r = i / CPR;
+      const int c = (i % CPR) ^ (r & (S - 1));
+      int64_t item = base + r;
+      if (item > last_row) item = last_row;
+      __builtin_amdgcn_global_load_lds((gptr_t)(p.t.item_emb + item * D + c * 4),
+                                       (lptr_t)(dst + I * kWave), 16, 0, 0);
+    }
+    if (wave == 0) {
+      int64_t item = base + lane;
+      if (item > last_row) item = last_row;
+      __builtin_amdgcn_global_load_lds((gptr_t)(p.t.item_bias + item), (lptr_t)(dst + kTileF4), 4,
+                                       0, 0);
+    }
+  };
+
+  int buf = 0;
+  if (chunk_begin < chunk_end) issue(chunk_begin, 0);
+  for (int64_t base = chunk_begin; base < chunk_end; base += kTileItems) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's part of tile `base` has landed
+    __syncthreads();                                  // everyone's has; buffer buf ^ 1 is free
+    if (base + kTileItems < chunk_end) issue(base + kTileItems, buf ^ 1);
+    const float4* tile = smem + buf * kBufF4;
+    const float* tile_bias = reinterpret_cast<const float*>(tile + kTileF4);
+    const bool full = base + kTileItems <= chunk_end;
+
+    // MODE 1 keeps one sub-tile live at a time (its epilogue holds 32 threshold registers)
+#pragma unroll MODE == 0 ? 2 : 1
+    for (int sub = 0; sub < kTileItems / 32; ++sub) {
+      f32x16 acc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+      const int r = sub * 32 + col;
+      const float4* arow = tile + r * CPR;
+      const int sw = r & (S - 1);
+#pragma unroll
+      for (int q = 0; q < D8; ++q) {
+        const float4 a = arow[(2 * q + h) ^ sw];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, ufrag[q][0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, ufrag[q][1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, ufrag[q][2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, ufrag[q][3], acc, 0, 0, 0);
+      }
+      // ---- epilogue: this lane's user x 16 items (rows (r&3) + 8(r>>2) + 4h of the sub-tile) ----
+      float smax = -INFINITY;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 b4 = *reinterpret_cast<const float4*>(tile_bias + sub * 32 + 8 * g + 4 * h);
+        acc[4 * g + 0] = finish_score(acc[4 * g + 0], ub, b4.x);
+        acc[4 * g + 1] = finish_score(acc[4 * g + 1], ub, b4.y);
+        acc[4 * g + 2] = finish_score(acc[4 * g + 2], ub, b4.z);
+        acc[4 * g + 3] = finish_score(acc[4 * g + 3], ub, b4.w);
+      }
+      if (!full) {
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+          const int row = sub * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
+          // masked rows: -inf never enters a top-k list; NaN fails every rank-count comparison
+          if (base + row >= chunk_end) acc[rr] = MODE == 0 ? -INFINITY : __builtin_nanf("");
+        }
+      }
+      if (MODE == 0) {
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) smax = fmaxf(smax, acc[rr]);
+        if (smax > top_s[kCap - 1]) {
+#pragma unroll
+          for (int rr = 0; rr < 16; ++rr) {
+            if (acc[rr] > top_s[kCap - 1]) {
+              const int row = sub * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
+              float cs = acc[rr];
+              int ci = static_cast<int>((base + row) * p.id_stride + p.id_offset);
+#pragma unroll
+              for (int i = 0; i < kCap; ++i) {
+                const bool better = cs > top_s[i];
+                const float ts = top_s[i];
+                const int ti = top_i[i];
+                top_s[i] = better ? cs : ts;
+                top_i[i] = better ? ci : ti;
+                cs = better ? ts : cs;
+                ci = better ? ti : ci;
+              }
+            }
+          }
+        }
+      } else {
+        // 32-bit counters per sub-tile (at most 16 * kCap increments), folded into the 64-bit ones
+        uint32_t t_above = 0, t_lt = 0, t_le = 0;
+        const int64_t gid0 = (base + sub * 32 + 4 * h) * p.id_stride + p.id_offset;
+        if (n_thr <= 4) rank_subtile<4>(acc, top_s, top_i, bscore, bid, gid0, p.id_stride, t_above, t_lt, t_le);
+        else if (n_thr <= 8) rank_subtile<8>(acc, top_s, top_i, bscore, bid, gid0, p.id_stride, t_above, t_lt, t_le);
+        else if (n_thr <= 12) rank_subtile<12>(acc, top_s, top_i, bscore, bid, gid0, p.id_stride, t_above, t_lt, t_le);
+        else rank_subtile<kCap>(acc, top_s, top_i, bscore, bid, gid0, p.id_stride, t_above, t_lt, t_le);
+        c_above += t_above;
+        c_lt += t_lt;
+        c_le += t_le;
+        if (any_long) {
+#pragma unroll 1
+          for (int rr = 0; rr < 16; ++rr) {
+            const float s = acc[rr];
+            if (s < lo_min) {
+              c_below_all += 1ull;                     // below every remaining positive
+            } else if (s <= hi_max) {
+              for (int64_t e = e_begin + kCap; e < e_end; ++e) {
+                c_lt += s < p.thr_lo[e] ? 1ull : 0ull;
+                c_le += s <= p.thr_hi[e] ? 1ull : 0ull;
+              }
+            }
+          }
+        }
+      }
+    }
+    buf ^= 1;
+  }
+
+  if (!user_ok) return;
+  if (MODE == 0) {
+    const int nslots = p.nchunks * 2;
+    const int64_t slot = uslot * nslots + blockIdx.y * 2 + h;
+#pragma unroll
+    for (int i = 0; i < kCap; ++i) {
+      p.cand_scores[slot * kCap + i] = i < k ? top_s[i] : -INFINITY;
+      p.cand_ids[slot * kCap + i] = i < k ? top_i[i] : 0x7fffffff;
+    }
+  } else {
+    const unsigned long long npos =
+        e_end - e_begin > kCap ? static_cast<unsigned long long>(e_end - e_begin - kCap) : 0ull;
+    atomicAdd(&p.counts[uslot * 3 + 0], c_above);
+    atomicAdd(&p.counts[uslot * 3 + 1], c_lt + c_below_all * npos);
+    atomicAdd(&p.counts[uslot * 3 + 2], c_le + c_below_all * npos);
+  }
+}
+
 // one wave per user: k rounds of "best remaining candidate" over nslots * kCap candidates
 __global__ __launch_bounds__(kBlock) void merge_topk_kernel(const float* __restrict__ cand_scores,
                                                             const int32_t* __restrict__ cand_ids,
@@ -437,39 +701,76 @@ int d8_bucket(int dim) {
   return b;
 }
 
-struct EvalWs {
-  float* cand_scores;
-  int32_t* cand_ids;
-  size_t bytes;
+struct EvalGeom {
   int nchunks;
   int tiles_per_chunk;
 };
 
-EvalWs carve_eval_ws(void* base, int64_t n_users, int64_t n_items_shard) {
-  EvalWs w;
+// item chunks per user block: enough workgroups to fill 256 CUs a few times over, at most 64
+EvalGeom eval_geom(int64_t n_users, int64_t n_items_shard, int users_per_block) {
+  EvalGeom g;
   const int64_t ntiles = (n_items_shard + kTileItems - 1) / kTileItems;
-  const int64_t user_blocks = (n_users + kUsersPerBlock - 1) / kUsersPerBlock;
-  // enough workgroups to fill 256 CUs a few times over, at most 64 chunks
+  const int64_t user_blocks = (n_users + users_per_block - 1) / users_per_block;
   int64_t want = (2048 + user_blocks - 1) / user_blocks;
-  if (want < 1) want = 1;
   if (want > 64) want = 64;
   if (want > ntiles) want = ntiles;
   if (want < 1) want = 1;
-  w.tiles_per_chunk = static_cast<int>((ntiles + want - 1) / want);
-  if (w.tiles_per_chunk < 1) w.tiles_per_chunk = 1;
-  w.nchunks = static_cast<int>((ntiles + w.tiles_per_chunk - 1) / w.tiles_per_chunk);
-  if (w.nchunks < 1) w.nchunks = 1;
+  g.tiles_per_chunk = static_cast<int>((ntiles + want - 1) / want);
+  if (g.tiles_per_chunk < 1) g.tiles_per_chunk = 1;
+  g.nchunks = static_cast<int>((ntiles + g.tiles_per_chunk - 1) / g.tiles_per_chunk);
+  if (g.nchunks < 1) g.nchunks = 1;
+  return g;
+}
+
+// the LDS-DMA kernel: exact power-of-two depth 32..128, 16-byte aligned rows
+bool dma_ok(const collie_mf_tables* t) {
+  auto al16 = [](const void* q) { return reinterpret_cast<uintptr_t>(q) % 16 == 0; };
+  return (t->dim == 32 || t->dim == 64 || t->dim == 128) && al16(t->user_emb) && al16(t->item_emb);
+}
+
+struct EvalWs {
+  float* cand_scores;
+  int32_t* cand_ids;
+  size_t bytes;
+};
+
+// candidate lists [n_users, nslots, kCap]; sized for whichever kernel geometry needs more slots
+EvalWs carve_eval_ws(void* base, int64_t n_users, int64_t n_items_shard) {
+  EvalWs w;
+  const int a = eval_geom(n_users, n_items_shard, kUsersPerBlock).nchunks;
+  const int b = eval_geom(n_users, n_items_shard, kUsersPerBlockDma).nchunks;
   Carver c(base);
-  const size_t n = static_cast<size_t>(n_users) * w.nchunks * 2 * kCap;
+  const size_t n = static_cast<size_t>(n_users) * (a > b ? a : b) * 2 * kCap;
   w.cand_scores = c.take<float>(n);
   w.cand_ids = c.take<int32_t>(n);
   w.bytes = align_up(c.off, 256);
   return w;
 }
 
+// fills p.nchunks / p.tiles_per_chunk / p.D8 and launches the scoring kernel
 template <int MODE>
-int launch_gemm(int d8, dim3 grid, hipStream_t stream, const EvalParams& p) {
-  switch (d8) {
+int launch_gemm(hipStream_t stream, EvalParams& p) {
+  const int64_t n_items = p.item_end - p.item_begin;
+  p.D8 = d8_bucket(p.t.dim);
+  if (dma_ok(&p.t)) {
+    const EvalGeom g = eval_geom(p.n_users, n_items, kUsersPerBlockDma);
+    p.nchunks = g.nchunks;
+    p.tiles_per_chunk = g.tiles_per_chunk;
+    dim3 grid(static_cast<unsigned>((p.n_users + kUsersPerBlockDma - 1) / kUsersPerBlockDma),
+              static_cast<unsigned>(g.nchunks));
+    switch (p.D8) {
+      case 4: hipLaunchKernelGGL((eval_gemm_dma_kernel<4, MODE>), grid, dim3(kBlockDma), 0, stream, p); break;
+      case 8: hipLaunchKernelGGL((eval_gemm_dma_kernel<8, MODE>), grid, dim3(kBlockDma), 0, stream, p); break;
+      default: hipLaunchKernelGGL((eval_gemm_dma_kernel<16, MODE>), grid, dim3(kBlockDma), 0, stream, p); break;
+    }
+    return check_launch("eval_gemm_dma_kernel");
+  }
+  const EvalGeom g = eval_geom(p.n_users, n_items, kUsersPerBlock);
+  p.nchunks = g.nchunks;
+  p.tiles_per_chunk = g.tiles_per_chunk;
+  dim3 grid(static_cast<unsigned>((p.n_users + kUsersPerBlock - 1) / kUsersPerBlock),
+            static_cast<unsigned>(g.nchunks));
+  switch (p.D8) {
     case 1: hipLaunchKernelGGL((eval_gemm_kernel<1, MODE>), grid, dim3(kBlock), 0, stream, p); break;
     case 2: hipLaunchKernelGGL((eval_gemm_kernel<2, MODE>), grid, dim3(kBlock), 0, stream, p); break;
     case 4: hipLaunchKernelGGL((eval_gemm_kernel<4, MODE>), grid, dim3(kBlock), 0, stream, p); break;
@@ -530,17 +831,12 @@ extern "C" int collie_mf_eval_topk(const collie_mf_tables* t, const int64_t* use
   p.item_end = item_end;
   p.id_stride = id_stride;
   p.id_offset = id_offset;
-  p.tiles_per_chunk = ws.tiles_per_chunk;
-  p.nchunks = ws.nchunks;
   p.k = k;
-  p.D8 = d8_bucket(t->dim);
   p.cand_scores = ws.cand_scores;
   p.cand_ids = ws.cand_ids;
-  dim3 grid(static_cast<unsigned>((n_users + kUsersPerBlock - 1) / kUsersPerBlock),
-            static_cast<unsigned>(ws.nchunks));
-  if (launch_gemm<0>(p.D8, grid, stream, p)) return -1;
+  if (launch_gemm<0>(stream, p)) return -1;
   hipLaunchKernelGGL(merge_topk_kernel, dim3(static_cast<unsigned>((n_users + kWaves - 1) / kWaves)),
-                     dim3(kBlock), 0, stream, ws.cand_scores, ws.cand_ids, n_users, ws.nchunks * 2,
+                     dim3(kBlock), 0, stream, ws.cand_scores, ws.cand_ids, n_users, p.nchunks * 2,
                      k, has_y_range, y_lo, y_hi, topk_scores, topk_ids);
   return check_launch("merge_topk_kernel");
 }
@@ -600,7 +896,6 @@ extern "C" int collie_mf_eval_rank_counts(const collie_mf_tables* t, const int64
   if (validate_tables(t) || check_range(t, n_users, item_begin, item_end)) return -1;
   COLLIE_REQUIRE(user_ids && indptr && thr_lo && thr_hi && best_score && best_id && counts,
                  "eval_rank_counts: NULL pointer");
-  EvalWs ws = carve_eval_ws(nullptr, n_users, item_end - item_begin);
   EvalParams p;
   memset(&p, 0, sizeof(p));
   p.t = *t;
@@ -610,19 +905,14 @@ extern "C" int collie_mf_eval_rank_counts(const collie_mf_tables* t, const int64
   p.item_end = item_end;
   p.id_stride = id_stride;
   p.id_offset = id_offset;
-  p.tiles_per_chunk = ws.tiles_per_chunk;
-  p.nchunks = ws.nchunks;
   p.k = 1;
-  p.D8 = d8_bucket(t->dim);
   p.indptr = indptr;
   p.thr_lo = thr_lo;
   p.thr_hi = thr_hi;
   p.best_score = best_score;
   p.best_id = best_id;
   p.counts = reinterpret_cast<unsigned long long*>(counts);
-  dim3 grid(static_cast<unsigned>((n_users + kUsersPerBlock - 1) / kUsersPerBlock),
-            static_cast<unsigned>(ws.nchunks));
-  return launch_gemm<1>(p.D8, grid, stream, p);
+  return launch_gemm<1>(stream, p);
 }
 
 extern "C" int collie_mf_eval_metrics(const int64_t* topk_ids, int32_t k, int64_t n_users,

@@ -120,7 +120,8 @@ def test_eval_case_with_engineered_ties(golden_dir, dev):
 
 
 @pytest.mark.parametrize('D,N,U,k', [(64, 5003, 300, 10), (10, 1682, 943, 10), (128, 2048, 70, 16),
-                                     (30, 777, 129, 1), (256, 300, 40, 5), (8, 50000, 33, 10)])
+                                     (30, 777, 129, 1), (256, 300, 40, 5), (8, 50000, 33, 10),
+                                     (32, 4100, 700, 7), (128, 70001, 520, 10)])
 def test_topk_ids_exact_on_exactly_representable_scores(dev, D, N, U, k):
     """Embeddings on a coarse grid: every dot product is exact in fp32 in any order, so the ids
     must equal the oracle's (score desc, id asc) order bit for bit, ties included."""
@@ -133,7 +134,7 @@ def test_topk_ids_exact_on_exactly_representable_scores(dev, D, N, U, k):
               'item_biases': (rng.integers(-8, 9, (N, 1)) / 16).astype(np.float32)}
     model = make_model(tables, dev)
     t = model._tables()
-    users = np.sort(rng.choice(U, min(U, 200), replace=False))
+    users = np.sort(rng.choice(U, min(U, 600), replace=False))
     preds = O.get_preds(tables, users, N)
     ws = ops.EvalWorkspace(dev)
     slots = torch.tensor(users, dtype=torch.int64, device=dev)
