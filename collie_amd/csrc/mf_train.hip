@@ -15,6 +15,7 @@
 //     stage_i[b] = g * U[user_b]                    (+ for I[pos], - for I[neg_sel])
 // plus g itself (bias gradients) and one 32-bit code per looked-up id that tells the
 // segment-reduce/optimizer kernels which staged row, with which sign, belongs to that id.
+#include <cstdlib>
 #include <type_traits>
 
 #include "train_ws.h"
@@ -650,27 +651,35 @@ __device__ __forceinline__ void glds_chunks(const float* src, float4* dst) {
   }
 }
 
+template <int NP>
 struct LdsIds {
-  int u, pos;   // wave-uniform
-  int64_t neg;  // per lane group
+  int u, pos;        // wave-uniform
+  int64_t neg[NP];   // per lane group and pass
 };
 
-template <int LPR>
-__device__ __forceinline__ LdsIds load_lds_ids(const LdsParams& p, int64_t b, int64_t neg_lane_off) {
-  LdsIds s;
+template <int NP>
+__device__ __forceinline__ LdsIds<NP> load_lds_ids(const LdsParams& p, int64_t b,
+                                                   const int64_t (&neg_lane_off)[NP]) {
+  LdsIds<NP> s;
   int64_t zero = 0;
   asm volatile("" : "+v"(zero));  // keep the prefetched ids in VGPRs until they are used
   const int64_t bv = b + zero;
   s.u = p.users[bv];
   s.pos = p.pos_items[bv];
-  s.neg = p.neg_items[bv * p.neg_stride_b + neg_lane_off];
+#pragma unroll
+  for (int q = 0; q < NP; ++q) s.neg[q] = p.neg_items[bv * p.neg_stride_b + neg_lane_off[q]];
   return s;
 }
 
-// KIND: 0 = warp, 1 = (adaptive) bpr, 2 = (adaptive) hinge
-template <int CH, int LPR, int KIND, bool META>
-__global__ __launch_bounds__(kBlock, (CH <= 4 ? 8 : 4)) void mf_train_fwd_lds(const LdsParams p) {
-  constexpr int kItemF4 = CH * kWave;  // float4 slots of the item parking area
+// KIND: 0 = warp, 1 = (adaptive) bpr, 2 = (adaptive) hinge.
+// NP passes of G = 64 / LPR rows: row j = q * G + grp (q = pass) belongs to lane group grp; with
+// NP = 2 the lane groups are wider (LPR = 8 at K = 10), so every wave-instruction of the gather
+// reads 128 contiguous bytes of each row (a full cache line) instead of 64.
+template <int CH, int LPR, int NP, int KIND, bool META>
+__global__ __launch_bounds__(kBlock, (CH * NP <= 4 ? 8 : 4)) void mf_train_fwd_lds(const LdsParams p) {
+  constexpr int G = kWave / LPR;
+  constexpr int kPassF4 = CH * kWave;      // float4 slots of one pass of the item parking area
+  constexpr int kItemF4 = NP * kPassF4;
   constexpr int kUserF4 = CH * LPR;
   __shared__ float4 park[kWavesPerBlock][kItemF4 + kUserF4];
 
@@ -684,10 +693,16 @@ __global__ __launch_bounds__(kBlock, (CH <= 4 ? 8 : 4)) void mf_train_fwd_lds(co
   const uint32_t key_off = static_cast<uint32_t>(p.num_users);
   float4* const items_l = &park[wave_in_block][0];
   float4* const user_l = &park[wave_in_block][kItemF4];
-  const int jn = grp > K ? K : (grp < 1 ? 1 : grp);  // negative read by this lane group (1..K)
-  const int64_t neg_lane_off = static_cast<int64_t>(jn - 1) * p.neg_stride_k;
-  const bool row_lane = grp <= K;
-  const bool neg_lane = grp >= 1 && row_lane;
+  bool row_lane[NP], neg_lane[NP];
+  int64_t neg_lane_off[NP];
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {
+    const int j = q * G + grp;
+    const int jn = j > K ? K : (j < 1 ? 1 : j);  // negative read for this row slot (1..K)
+    neg_lane_off[q] = static_cast<int64_t>(jn - 1) * p.neg_stride_k;
+    row_lane[q] = j <= K;
+    neg_lane[q] = j >= 1 && j <= K;
+  }
 
   float loss1 = 0.0f, loss2 = 0.0f;
   // A wave owns a contiguous range of samples, so that the per-sample sort entries and gradient
@@ -729,19 +744,27 @@ __global__ __launch_bounds__(kBlock, (CH <= 4 ? 8 : 4)) void mf_train_fwd_lds(co
     }
   };
 
-  LdsIds next = {0, 0, 0};
-  if (b < b_end) next = load_lds_ids<LPR>(p, b, neg_lane_off);
+  LdsIds<NP> next;
+  next.u = next.pos = 0;
+#pragma unroll
+  for (int q = 0; q < NP; ++q) next.neg[q] = 0;
+  if (b < b_end) next = load_lds_ids<NP>(p, b, neg_lane_off);
   for (; b < b_end; ++b) {
-    const LdsIds cur = next;
+    const LdsIds<NP> cur = next;
     const int u = __builtin_amdgcn_readfirstlane(cur.u);
     const int pos_item = __builtin_amdgcn_readfirstlane(cur.pos);
-    const int64_t item64 = grp == 0 ? static_cast<int64_t>(pos_item) : cur.neg;
-    const bool bad_lane = static_cast<uint64_t>(item64) >= static_cast<uint64_t>(p.num_items);
+    int item[NP];
+    bool bad_lane = false;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const int64_t item64 = (q == 0 && grp == 0) ? static_cast<int64_t>(pos_item) : cur.neg[q];
+      bad_lane |= static_cast<uint64_t>(item64) >= static_cast<uint64_t>(p.num_items);
+      item[q] = static_cast<int>(item64);
+    }
     const bool bad = static_cast<uint32_t>(u) >= static_cast<uint32_t>(p.num_users) ||
                      (__ballot(bad_lane) != 0ull);
-    const int item = static_cast<int>(item64);
     if (bad) {  // wave-uniform: never touch memory through a bad id
-      if (b + 1 < b_end) next = load_lds_ids<LPR>(p, b + 1, neg_lane_off);
+      if (b + 1 < b_end) next = load_lds_ids<NP>(p, b + 1, neg_lane_off);
       if (lane == 0 && p.status) atomicOr(p.status, 1);
       if (p.need_grad) collect(b, 0u, key_off, key_off, false, 0.0f);
       continue;
@@ -749,57 +772,89 @@ __global__ __launch_bounds__(kBlock, (CH <= 4 ? 8 : 4)) void mf_train_fwd_lds(co
 
     // ---- gathers: LDS-DMA, nothing lands in a VGPR -------------------------------------------
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // last sample's parking reads are done
-    const float* irow = p.item_emb + static_cast<int64_t>(item) * D + lig * 4;
-    glds_chunks<0, CH, LPR * 16, kWave>(irow, items_l);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const float* irow = p.item_emb + static_cast<int64_t>(item[q]) * D + lig * 4;
+      glds_chunks<0, CH, LPR * 16, kWave>(irow, items_l + q * kPassF4);
+    }
     if (grp == 0) {
       const float* urow = p.user_emb + static_cast<int64_t>(u) * D + lig * 4;
       glds_chunks<0, CH, LPR * 16, LPR>(urow, user_l);
     }
     const float ub = p.user_bias[u];
-    const float ib = p.item_bias[item];
-    // the item's stamp: most items of a large batch were already stamped by another sample of
-    // this step; a stale read only costs a redundant store
-    int stamp = 0;
-    if (p.need_grad) stamp = p.touch_item[item];
-    if (b + 1 < b_end) next = load_lds_ids<LPR>(p, b + 1, neg_lane_off);
+    float ib[NP];
+    int stamp[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      ib[q] = p.item_bias[item[q]];
+      // the item's stamp: most items of a large batch were already stamped by another sample of
+      // this step; a stale read only costs a redundant store
+      stamp[q] = 0;
+      if (p.need_grad) stamp[q] = p.touch_item[item[q]];
+    }
+    if (b + 1 < b_end) next = load_lds_ids<NP>(p, b + 1, neg_lane_off);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // ---- dot products: chunk order i, then across the LPR lanes of the row ----------------------
-    float dot = 0.0f;
+    float s[NP];
 #pragma unroll
-    for (int i = 0; i < CH; ++i) {
-      const float4 a = items_l[i * kWave + lane];
-      const float4 c = user_l[i * LPR + lig];
-      dot = fmaf(c.x, a.x, dot);
-      dot = fmaf(c.y, a.y, dot);
-      dot = fmaf(c.z, a.z, dot);
-      dot = fmaf(c.w, a.w, dot);
+    for (int q = 0; q < NP; ++q) {
+      float dot = 0.0f;
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const float4 a = items_l[q * kPassF4 + i * kWave + lane];
+        const float4 c = user_l[i * LPR + lig];
+        dot = fmaf(c.x, a.x, dot);
+        dot = fmaf(c.y, a.y, dot);
+        dot = fmaf(c.z, a.z, dot);
+        dot = fmaf(c.w, a.w, dot);
+      }
+      s[q] = (group_sum_dpp<LPR>(dot) + ub) + ib[q];
     }
-    const float s = (group_sum_dpp<LPR>(dot) + ub) + ib;
-    const float sp = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s)));
+    const float sp = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s[0])));
 
-    // ---- selection: one max + one ballot ------------------------------------------------------
-    float c = 1.0f;
-    if (META) {
-      float frac = 0.0f;
-      for (int m = 0; m < p.n_meta; ++m)
-        frac += (p.meta[m][pos_item] == p.meta[m][item]) ? p.meta_weight[m] : 0.0f;
-      c = 1.0f - frac;
+    // ---- selection: one max + one ballot per pass (rows of pass 0 come before rows of pass 1) ---
+    float c[NP], v[NP];
+    uint64_t mask[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      c[q] = 1.0f;
+      if (META) {
+        float frac = 0.0f;
+        for (int m = 0; m < p.n_meta; ++m)
+          frac += (p.meta[m][pos_item] == p.meta[m][item[q]]) ? p.meta_weight[m] : 0.0f;
+        c[q] = 1.0f - frac;
+      }
+      v[q] = KIND == 0 ? (c[q] - sp) + s[q] : s[q];
     }
-    const float v = KIND == 0 ? (c - sp) + s : s;
-    uint64_t mask;
     if (KIND == 0) {
-      mask = __ballot(neg_lane & (v > 0.0f));
+#pragma unroll
+      for (int q = 0; q < NP; ++q) mask[q] = __ballot(neg_lane[q] & (v[q] > 0.0f));
     } else {
-      const float vmax = wave_max_from_groups<LPR>(neg_lane ? v : -INFINITY);
-      mask = __ballot(neg_lane & (v == vmax));
+      float m = -INFINITY;
+#pragma unroll
+      for (int q = 0; q < NP; ++q) m = fmaxf(m, neg_lane[q] ? v[q] : -INFINITY);
+      const float vmax = wave_max_from_groups<LPR>(m);
+#pragma unroll
+      for (int q = 0; q < NP; ++q) mask[q] = __ballot(neg_lane[q] & (v[q] == vmax));
     }
-    const bool none = mask == 0ull;  // warp without a violation (or only NaN scores)
-    const int wl = none ? LPR : static_cast<int>(__builtin_ctzll(mask));
-    const int sel = wl / LPR;
-    const float best_v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), wl));
-    const float best_c = META ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), wl)) : 1.0f;
-    const int best_item = __builtin_amdgcn_readlane(item, wl);
+    int qs = 0;  // pass of the selected row (wave-uniform)
+    uint64_t msel = mask[0];
+    if (NP > 1 && msel == 0ull) {
+      qs = 1;
+      msel = mask[NP - 1];
+    }
+    const bool none = msel == 0ull;  // warp without a violation (or only NaN scores)
+    if (none) qs = 0;
+    const int wl = none ? LPR : static_cast<int>(__builtin_ctzll(msel));
+    const int sel_grp = wl / LPR;
+    const int sel = qs * G + sel_grp;  // 1-based index of the selected negative
+    const float v_q = qs == 0 ? v[0] : v[NP - 1];
+    const float c_q = qs == 0 ? c[0] : c[NP - 1];
+    const int item_q = qs == 0 ? item[0] : item[NP - 1];
+    const float best_v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v_q), wl));
+    const float best_c = META ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c_q), wl)) : 1.0f;
+    const int best_item = __builtin_amdgcn_readlane(item_q, wl);
     float ell = 0.0f, g = 0.0f;
     if (KIND == 0) {
       if (!none) {
@@ -825,12 +880,14 @@ __global__ __launch_bounds__(kBlock, (CH <= 4 ? 8 : 4)) void mf_train_fwd_lds(co
 
     // ---- backward staging ---------------------------------------------------------------------
     const bool live = g != 0.0f;
-    if (lig == 0 && row_lane && stamp != p.step_id) p.touch_item[item] = p.step_id;
+#pragma unroll
+    for (int q = 0; q < NP; ++q)
+      if (lig == 0 && row_lane[q] && stamp[q] != p.step_id) p.touch_item[item[q]] = p.step_id;
     if (live && lane < CH * LPR) {  // lane l stages 16-byte chunk l of the two rows
       const int i = lane / LPR, l2 = lane % LPR;
       const float4 uu = user_l[lane];
       const float4 ip = items_l[i * kWave + l2];
-      const float4 is = items_l[i * kWave + sel * LPR + l2];
+      const float4 is = items_l[qs * kPassF4 + i * kWave + sel_grp * LPR + l2];
       float4 gu, gi;
       gu.x = g * ip.x - g * is.x;
       gu.y = g * ip.y - g * is.y;
@@ -931,32 +988,39 @@ int launch_fwd_fast(int lpr, int np, dim3 grid, hipStream_t stream, const FwdPar
   return check_launch("mf_train_fwd_fast");
 }
 
-template <int CH, int LPR>
-void launch_lds2(int kind3, bool meta, dim3 grid, hipStream_t stream, const LdsParams& q) {
-#define COLLIE_LDS_CASE(KIND_)                                                                    \
-  if (meta)                                                                                       \
-    hipLaunchKernelGGL((mf_train_fwd_lds<CH, LPR, KIND_, true>), grid, dim3(kBlock), 0, stream, q); \
-  else                                                                                            \
-    hipLaunchKernelGGL((mf_train_fwd_lds<CH, LPR, KIND_, false>), grid, dim3(kBlock), 0, stream, q)
+template <int CH, int LPR, int NP>
+void launch_lds3(int kind3, bool meta, dim3 grid, hipStream_t stream, const LdsParams& q) {
+#define COLLIE_LDS_CASE(KIND_)                                                                        \
+  if (meta)                                                                                           \
+    hipLaunchKernelGGL((mf_train_fwd_lds<CH, LPR, NP, KIND_, true>), grid, dim3(kBlock), 0, stream, q); \
+  else                                                                                                \
+    hipLaunchKernelGGL((mf_train_fwd_lds<CH, LPR, NP, KIND_, false>), grid, dim3(kBlock), 0, stream, q)
   if (kind3 == 0) { COLLIE_LDS_CASE(0); }
   else if (kind3 == 1) { COLLIE_LDS_CASE(1); }
   else { COLLIE_LDS_CASE(2); }
 #undef COLLIE_LDS_CASE
 }
 
+template <int CH, int LPR>
+void launch_lds2(int np, int kind3, bool meta, dim3 grid, hipStream_t stream, const LdsParams& q) {
+  if (np == 1) launch_lds3<CH, LPR, 1>(kind3, meta, grid, stream, q);
+  else launch_lds3<CH, LPR, 2>(kind3, meta, grid, stream, q);
+}
+
 template <int LPR>
-void launch_lds1(int ch, int kind3, bool meta, dim3 grid, hipStream_t stream, const LdsParams& q) {
+void launch_lds1(int ch, int np, int kind3, bool meta, dim3 grid, hipStream_t stream,
+                 const LdsParams& q) {
   switch (ch) {
-    case 1: launch_lds2<1, LPR>(kind3, meta, grid, stream, q); break;
-    case 2: launch_lds2<2, LPR>(kind3, meta, grid, stream, q); break;
-    case 4: launch_lds2<4, LPR>(kind3, meta, grid, stream, q); break;
-    default: launch_lds2<8, LPR>(kind3, meta, grid, stream, q); break;
+    case 1: launch_lds2<1, LPR>(np, kind3, meta, grid, stream, q); break;
+    case 2: launch_lds2<2, LPR>(np, kind3, meta, grid, stream, q); break;
+    case 4: launch_lds2<4, LPR>(np, kind3, meta, grid, stream, q); break;
+    default: launch_lds2<8, LPR>(np, kind3, meta, grid, stream, q); break;
   }
 }
 
 // LDS-parked path.  Conditions (checked by the caller): float4 rows, dim == 16 * ch * lpr bytes
-// exactly, 1 + K <= 64 / lpr, the loaders' id dtypes, no score outputs.
-int launch_fwd_lds(int lpr, int ch, dim3 grid, hipStream_t stream, const FwdParams& p) {
+// exactly, 1 + K <= np * 64 / lpr, the loaders' id dtypes, no score outputs.
+int launch_fwd_lds(int lpr, int ch, int np, dim3 grid, hipStream_t stream, const FwdParams& p) {
   LdsParams q;
   memset(&q, 0, sizeof(q));
   q.user_emb = p.t.user_emb;
@@ -995,9 +1059,9 @@ int launch_fwd_lds(int lpr, int ch, dim3 grid, hipStream_t stream, const FwdPara
                     : (kind == COLLIE_LOSS_BPR || kind == COLLIE_LOSS_ADAPTIVE_BPR) ? 1 : 2;
   const bool meta = p.loss.n_meta > 0;
   switch (lpr) {
-    case 4: launch_lds1<4>(ch, kind3, meta, grid, stream, q); break;
-    case 8: launch_lds1<8>(ch, kind3, meta, grid, stream, q); break;
-    default: launch_lds1<16>(ch, kind3, meta, grid, stream, q); break;
+    case 4: launch_lds1<4>(ch, np, kind3, meta, grid, stream, q); break;
+    case 8: launch_lds1<8>(ch, np, kind3, meta, grid, stream, q); break;
+    default: launch_lds1<16>(ch, np, kind3, meta, grid, stream, q); break;
   }
   return check_launch("mf_train_fwd_lds");
 }
@@ -1102,17 +1166,24 @@ extern "C" int collie_mf_train_forward(const collie_mf_tables* t, const collie_m
   int64_t nblocks = (b->batch + kWavesPerBlock - 1) / kWavesPerBlock;
   if (nblocks > kMaxLossBlocks) nblocks = kMaxLossBlocks;
   dim3 grid(static_cast<unsigned>(nblocks));
-  // LDS-parked single pass: the most lanes per row that still leave a lane group for every row
+  // LDS-parked variant: the widest lane groups that give every row of the sample its own group in
+  // ONE pass (measured: at K = 10 one pass of 4-lane groups beats two passes of 8-lane groups by 15 %
+  // on cache-resident tables and ties on HBM-resident ones); two passes only when K needs them
   int lds_lpr = 16;
-  while (lds_lpr > 4 && kWave / lds_lpr < b->num_neg + 1) lds_lpr /= 2;
+  while (lds_lpr > 4 && (lds_lpr > p.nchunks || kWave / lds_lpr < b->num_neg + 1)) lds_lpr /= 2;
+  const int lds_groups = kWave / lds_lpr;
+  const int lds_np = (b->num_neg + 1 + lds_groups - 1) / lds_groups;
   const int lds_ch = p.nchunks / lds_lpr;
-  const bool lds_ok = vec == 4 && kWave / lds_lpr >= b->num_neg + 1 &&
+  const bool lds_ok = vec == 4 && lds_np <= 2 && lds_groups >= 2 && lds_ch >= 1 &&
                       lds_ch * lds_lpr == p.nchunks &&
                       (lds_ch == 1 || lds_ch == 2 || lds_ch == 4 || lds_ch == 8) &&
                       b->users_dtype == COLLIE_I32 && b->pos_dtype == COLLIE_I32 &&
                       b->neg_dtype == COLLIE_I64 && !s_pos_out && !s_neg_out;
+  // tuning knob for A/B profiling only: COLLIE_K1_VARIANT=regs keeps the rows in VGPRs
+  static const char* const variant = getenv("COLLIE_K1_VARIANT");
+  const bool lds_pick = lds_ok && !(variant && variant[0] == 'r');
   int rc;
-  if (lds_ok) rc = launch_fwd_lds(lds_lpr, lds_ch, grid, stream, p);
+  if (lds_pick) rc = launch_fwd_lds(lds_lpr, lds_ch, lds_np, grid, stream, p);
   else if (fast) rc = launch_fwd_fast(lpr, np, grid, stream, p);
   else if (vec == 4) rc = launch_fwd<4>(lpr, grid, stream, p);
   else if (vec == 2) rc = launch_fwd<2>(lpr, grid, stream, p);

@@ -96,7 +96,7 @@ class Fused:
     """One fused forward on a fresh (zeroed) workspace, kept for the following update calls."""
 
     def __init__(self, td, users, pos, neg, kind, dev, codes=None, weights=None, need_grad=True,
-                 ws=None):
+                 ws=None, want_scores=True):
         from collie_amd import ops
         self.t = tables_struct(td)
         self.batch = ops.make_batch(users, pos, neg)
@@ -106,8 +106,9 @@ class Fused:
         self.step_id = self.ws.next_step()
         cfg = ops.make_loss_cfg(kind, self.t.num_items, codes, weights)
         self.loss = torch.empty(1, device=dev)
-        self.s_pos = torch.empty(B, device=dev)
-        self.s_neg = torch.empty(K, B, device=dev)
+        # without score outputs the dispatcher may pick the LDS-parked kernel variant
+        self.s_pos = torch.empty(B, device=dev) if want_scores else None
+        self.s_neg = torch.empty(K, B, device=dev) if want_scores else None
         self.status = torch.zeros(1, dtype=torch.int32, device=dev)
         ops.train_forward(self.t, self.batch, cfg, self.buf, need_grad, self.step_id, self.loss,
                           self.s_pos, self.s_neg, self.status)
@@ -260,6 +261,53 @@ def test_fused_step_vs_oracle_seeded(dev, B, K, D, U, N):
             if 'bias' not in n:
                 close(m[n].cpu().numpy(), st.state[n]['m'], rtol=5e-5)
                 close(v[n].cpu().numpy(), st.state[n]['v'], rtol=5e-5)
+
+
+@pytest.mark.parametrize('B,K,D,kind', [(3000, 10, 64, 'adaptive_bpr'), (3000, 20, 64, 'adaptive_hinge'),
+                                        (2000, 10, 128, 'warp'), (1500, 1, 64, 'hinge'),
+                                        (1500, 5, 32, 'warp'), (1000, 30, 128, 'adaptive_bpr'),
+                                        (1200, 17, 256, 'warp'), (900, 3, 16, 'adaptive_hinge')])
+def test_fused_step_lds_parked_variants_vs_oracle(dev, B, K, D, kind):
+    """The LDS-parked forward variants (one and two gather passes; picked when no score outputs
+    are requested): loss, coalesced gradients and the updated tables vs the numpy oracle."""
+    from oracle import mf_oracle as O
+    from collie_amd import _lib, ops
+    rng = np.random.default_rng(B + K + D)
+    U, N = 700, 900
+    tables = O.init_tables(U, N, D, rng)
+    tables['user_embeddings'] *= np.float32(4 * np.sqrt(D))
+    tables['item_embeddings'] *= np.float32(4 * np.sqrt(D))
+    tables['item_biases'] = rng.normal(0, 0.05, (N, 1)).astype(np.float32)
+    st = O.TrainState(tables, 'sparse_adam', 'sgd', lr=1e-2, bias_lr=1e-1, sparse=True)
+    td = to_dev(tables, dev)
+    m = {n: torch.zeros_like(td[n]) for n in NAMES}
+    v = {n: torch.zeros_like(td[n]) for n in NAMES}
+    ws = ops.TrainWorkspace(dev)
+    for step in range(2):
+        users = (rng.zipf(1.3, B) % U).astype(np.int32)
+        pos = (rng.zipf(1.2, B) % N).astype(np.int32)
+        neg = rng.integers(0, N, (B, K)).astype(np.int64)
+        out = st.step(users, pos, neg, kind)
+        f = Fused(td, torch.tensor(users, device=dev), torch.tensor(pos, device=dev),
+                  torch.tensor(neg, device=dev), kind, dev, ws=ws, want_scores=False)
+        close(f.loss.item(), out['loss'])
+        assert int(f.status.item()) == 0
+        per_side = {}
+        for n in ('user_embeddings', 'item_embeddings'):
+            side = _lib.SIDE_USER if n.startswith('user') else _lib.SIDE_ITEM
+            rows, vals = f.export(side, False)
+            np.testing.assert_array_equal(rows.cpu().numpy(), out['grads'][n][0])
+            close(vals.cpu().numpy(), out['grads'][n][1], rtol=5e-5)
+            per_side[side] = (ops.optim_cfg('sparse_adam', step + 1, 1e-2), m[n], v[n], None)
+        f.update(False, False, per_side)
+        sgd = ops.optim_cfg('sgd', step + 1, 1e-1)
+        f.update(True, False, {_lib.SIDE_USER: (sgd, None, None, None),
+                               _lib.SIDE_ITEM: (sgd, None, None, None)})
+        # SparseAdam's first steps are sign-like (m / sqrt(v)): an element whose gradient is pure
+        # rounding residue moves by O(lr) either way, hence the wider bar on the updated tables
+        # (the gradients themselves were held to 5e-5 above)
+        for n in ('user_embeddings', 'item_embeddings', 'item_biases'):
+            close(td[n].cpu().numpy(), st.t[n], rtol=2e-4)
 
 
 def test_fused_step_is_deterministic(dev):

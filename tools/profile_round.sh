@@ -1,6 +1,7 @@
 #!/bin/bash
-# Collect the round's rocprofv3 evidence on the GPU box: kernel-trace stats of bench.py (two batch
-# sizes) and the HBM-traffic counters of the same command in separate --pmc passes.
+# Collect the round's rocprofv3 evidence on the GPU box: kernel-trace stats of bench.py (C2 at two
+# batch sizes, the C4 tables on one GPU, the eval leg) and the HBM-traffic counters of the same
+# commands in separate --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit one pass).
 # usage: tools/profile_round.sh TAG      -> gpurun_out/prof_TAG/...
 set -e
 TAG=${1:-r01}
@@ -9,9 +10,15 @@ REPO=$PWD
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 ARGS="--no-cpu-baseline --eval-users 0 --steps 30 --warmup 5"
-timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_B65536 -o bench -- python3 $REPO/bench.py $ARGS --batch 65536 > $OUT/stats_B65536.log 2>&1
-timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_B1048576 -o bench -- python3 $REPO/bench.py $ARGS --batch 1048576 > $OUT/stats_B1048576.log 2>&1
-timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_B1048576 -o bench -- python3 $REPO/bench.py $ARGS --batch 1048576 > $OUT/pmc_fetch.log 2>&1
-timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_B1048576 -o bench -- python3 $REPO/bench.py $ARGS --batch 1048576 > $OUT/pmc_write.log 2>&1
-timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_eval -o bench -- python3 $REPO/bench.py --no-cpu-baseline --steps 2 --warmup 1 --eval-users 65536 > $OUT/stats_eval.log 2>&1
-ls -R $OUT | head -60
+C4="--no-cpu-baseline --eval-users 0 --steps 10 --warmup 3 --shape c4"
+stats() { timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$1 -o bench -- python3 $REPO/bench.py ${@:2} > $OUT/$1.log 2>&1; }
+pmc() { timeout -s KILL 300 rocprofv3 --pmc $2 --output-format csv -d $OUT/$1 -o bench -- python3 $REPO/bench.py ${@:3} > $OUT/$1.log 2>&1; }
+stats stats_B65536 $ARGS --batch 65536
+stats stats_B1048576 $ARGS --batch 1048576
+stats stats_c4 $C4
+stats stats_eval --no-cpu-baseline --steps 2 --warmup 1 --eval-users 65536
+pmc pmc_fetch_B1048576 FETCH_SIZE $ARGS --batch 1048576
+pmc pmc_write_B1048576 WRITE_SIZE $ARGS --batch 1048576
+pmc pmc_fetch_c4 FETCH_SIZE $C4
+pmc pmc_write_c4 WRITE_SIZE $C4
+ls $OUT
