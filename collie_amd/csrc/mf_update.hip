@@ -82,6 +82,10 @@ struct UpdParams {
   const uint32_t* vals;
   const uint32_t* seg_start;
   const uint32_t* nseg;
+  const uint32_t* long_base;    // per segment: first piece of a long segment, or kNoPiece
+  const uint32_t* piece_start;
+  const uint32_t* piece_end;
+  float* partial;               // [pieces, D] piece sums
   const float* grad_scale;
   int64_t* rows_out;   // export mode
   float* vals_out;
@@ -120,6 +124,82 @@ __device__ __forceinline__ void rstore(float* p, const RVec<VEC>& r) {
   }
 }
 
+// Piece sums of the long segments (embedding rows): LPR lanes own one piece and add its staged rows
+// in entry order, four loads in flight; pieces of tables this call does not own are skipped.
+template <bool EXPORT, int VEC, int LPR>
+__global__ __launch_bounds__(kBlock) void piece_rows_kernel(const UpdParams p) {
+  constexpr int GPW = kWave / LPR;
+  const int lane = lane_id();
+  const int grp = lane / LPR;
+  const int lig = lane % LPR;
+  const uint32_t npieces = p.nseg[2];
+  const int D = p.D;
+  const int nchunks = (D + VEC - 1) / VEC;
+  const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+  for (int64_t pc0 = (static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + threadIdx.x / kWave) * GPW;
+       pc0 < npieces; pc0 += nwaves * GPW) {
+    const int64_t pc = pc0 + grp;
+    if (pc >= npieces) continue;
+    const uint32_t start = p.piece_start[pc], end = p.piece_end[pc];
+    const int side = p.keys[start] >= p.split ? 1 : 0;
+    const TableDesc& t = p.d[side];
+    if (EXPORT ? side != p.export_side : t.table == nullptr) continue;
+    const float* stage = t.stage;
+    for (int chunk = lig; chunk < nchunks; chunk += LPR) {
+      RVec<VEC> acc;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc.v[i] = 0.0f;
+      for (uint32_t e0 = start; e0 < end; e0 += 4) {
+        RVec<VEC> x[4];
+        float sg[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const uint32_t c = e0 + q < end ? p.vals[e0 + q] : kCodeNone;
+          const bool live = c != kCodeNone && stage != nullptr;
+          sg[q] = live ? ((c & kCodeNeg) ? -1.0f : 1.0f) : 0.0f;
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) x[q].v[i] = 0.0f;
+          if (live) x[q] = rload<VEC>(stage + static_cast<int64_t>(c & kCodeMask) * D + chunk * VEC);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (sg[q] != 0.0f) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc.v[i] += sg[q] * x[q].v[i];
+          }
+      }
+      rstore<VEC>(p.partial + pc * D + chunk * VEC, acc);
+    }
+  }
+}
+
+// Piece sums for a bias table: one wave per piece, lanes stride the entries, fixed butterfly.
+template <bool EXPORT>
+__global__ __launch_bounds__(kBlock) void piece_bias_kernel(const UpdParams p) {
+  const int lane = lane_id();
+  const uint32_t npieces = p.nseg[2];
+  const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+  for (int64_t pc = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + threadIdx.x / kWave;
+       pc < npieces; pc += nwaves) {
+    const uint32_t start = p.piece_start[pc], end = p.piece_end[pc];
+    const int side = p.keys[start] >= p.split ? 1 : 0;
+    const TableDesc& t = p.d[side];
+    if (EXPORT ? side != p.export_side : t.table == nullptr) continue;
+    float acc = 0.0f;
+    if (t.stage) {
+      for (uint32_t e = start + lane; e < end; e += kWave) {
+        const uint32_t c = p.vals[e];
+        if (c != kCodeNone) {
+          const float gv = t.stage[c & kCodeMask];
+          acc += (c & kCodeNeg) ? -gv : gv;
+        }
+      }
+    }
+    acc = group_sum<kWave>(acc);
+    if (lane == 0) p.partial[pc] = acc;
+  }
+}
+
 // EXPORT = true writes the coalesced gradient of one side instead of updating the tables.
 // LPR lanes own one segment (VEC floats per lane per chunk), so 64 / LPR segments are reduced and
 // updated concurrently by a wave: independent rows keep 64 / LPR times more loads in flight than
@@ -152,6 +232,10 @@ __global__ __launch_bounds__(kBlock) void emb_rows_kernel(const UpdParams p) {
     const TableDesc& t = p.d[side];
     if (EXPORT ? side != p.export_side : t.table == nullptr) active = false;
     if (!active) end = start;
+    // a long segment was summed piecewise (piece_rows_kernel): combine its pieces in order
+    const uint32_t lbase = active ? p.long_base[seg] : kNoPiece;
+    const uint32_t npc = lbase != kNoPiece ? (end - start + kPieceLen - 1) / kPieceLen : 0u;
+    if (lbase != kNoPiece) end = start;
     const int64_t row = side ? key - p.split : key;
     const int64_t oseg = EXPORT ? (side ? seg - first1 : seg) : 0;
     if (EXPORT && active && lig == 0) p.rows_out[oseg] = row;
@@ -195,6 +279,24 @@ __global__ __launch_bounds__(kBlock) void emb_rows_kernel(const UpdParams p) {
             }
         }
         e0 += LPR;
+      }
+      if (on) {
+        for (uint32_t i0 = 0; i0 < npc; i0 += 4) {
+          RVec<VEC> x[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) x[q].v[i] = 0.0f;
+            if (i0 + q < npc)
+              x[q] = rload<VEC>(p.partial + static_cast<int64_t>(lbase + i0 + q) * D + chunk * VEC);
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (i0 + q < npc) {
+#pragma unroll
+              for (int i = 0; i < VEC; ++i) acc.v[i] += x[q].v[i];
+            }
+        }
       }
       if (on) {
         RVec<VEC> g;
@@ -251,7 +353,13 @@ __global__ __launch_bounds__(kBlock) void bias_rows_kernel(const UpdParams p) {
     if (EXPORT ? side != p.export_side : t.table == nullptr) active = false;
     const int64_t row = side ? key - p.split : key;
     float acc = 0.0f;
-    if (active && t.stage) {
+    const uint32_t lbase = active ? p.long_base[seg] : kNoPiece;
+    if (lbase != kNoPiece) {
+      if (t.stage) {
+        const uint32_t npc = (end - start + kPieceLen - 1) / kPieceLen;
+        for (uint32_t i = lig; i < npc; i += LPS) acc += p.partial[lbase + i];
+      }
+    } else if (active && t.stage) {
       for (uint32_t e = start + lig; e < end; e += LPS) {
         const uint32_t c = p.vals[e];
         if (c != kCodeNone) {
@@ -503,6 +611,19 @@ int rows_vec(const UpdParams& p) {
 }
 
 template <bool EXPORT, int VEC>
+void launch_piece_lpr(int lpr, unsigned grid, hipStream_t stream, const UpdParams& p) {
+  switch (lpr) {
+    case 1: hipLaunchKernelGGL((piece_rows_kernel<EXPORT, VEC, 1>), dim3(grid), dim3(kBlock), 0, stream, p); break;
+    case 2: hipLaunchKernelGGL((piece_rows_kernel<EXPORT, VEC, 2>), dim3(grid), dim3(kBlock), 0, stream, p); break;
+    case 4: hipLaunchKernelGGL((piece_rows_kernel<EXPORT, VEC, 4>), dim3(grid), dim3(kBlock), 0, stream, p); break;
+    case 8: hipLaunchKernelGGL((piece_rows_kernel<EXPORT, VEC, 8>), dim3(grid), dim3(kBlock), 0, stream, p); break;
+    case 16: hipLaunchKernelGGL((piece_rows_kernel<EXPORT, VEC, 16>), dim3(grid), dim3(kBlock), 0, stream, p); break;
+    case 32: hipLaunchKernelGGL((piece_rows_kernel<EXPORT, VEC, 32>), dim3(grid), dim3(kBlock), 0, stream, p); break;
+    default: hipLaunchKernelGGL((piece_rows_kernel<EXPORT, VEC, 64>), dim3(grid), dim3(kBlock), 0, stream, p); break;
+  }
+}
+
+template <bool EXPORT, int VEC>
 void launch_emb_lpr(int lpr, unsigned grid, hipStream_t stream, const UpdParams& p) {
   switch (lpr) {
     case 1: hipLaunchKernelGGL((emb_rows_kernel<EXPORT, VEC, 1>), dim3(grid), dim3(kBlock), 0, stream, p); break;
@@ -527,6 +648,14 @@ int launch_emb(const UpdParams& p, int64_t segs, hipStream_t stream) {
   if (blocks > 4 * kUpdateBlocks) blocks = 4 * kUpdateBlocks;
   if (blocks < 1) blocks = 1;
   const unsigned grid = static_cast<unsigned>(blocks);
+  // long segments first: at most max_pieces_for(3B) pieces, usually none (the grid-stride loop
+  // reads the piece count on the device)
+  int64_t pblocks = (max_pieces_for(segs) + gpw * kWavesPerBlock - 1) / (gpw * kWavesPerBlock);
+  if (pblocks > 2048) pblocks = 2048;
+  const unsigned pgrid = static_cast<unsigned>(pblocks);
+  if (vec == 4) launch_piece_lpr<EXPORT, 4>(lpr, pgrid, stream, p);
+  else if (vec == 2) launch_piece_lpr<EXPORT, 2>(lpr, pgrid, stream, p);
+  else launch_piece_lpr<EXPORT, 1>(lpr, pgrid, stream, p);
   if (vec == 4) launch_emb_lpr<EXPORT, 4>(lpr, grid, stream, p);
   else if (vec == 2) launch_emb_lpr<EXPORT, 2>(lpr, grid, stream, p);
   else launch_emb_lpr<EXPORT, 1>(lpr, grid, stream, p);
@@ -540,11 +669,21 @@ unsigned bias_grid(int64_t segs) {
   return static_cast<unsigned>(blocks);
 }
 
+unsigned piece_bias_grid(int64_t entries) {
+  int64_t blocks = (max_pieces_for(entries) + kWavesPerBlock - 1) / kWavesPerBlock;
+  if (blocks > 2048) blocks = 2048;
+  return static_cast<unsigned>(blocks);
+}
+
 void fill_sorted(UpdParams& p, const SortWs& s, int64_t nkeys, uint32_t split) {
   p.keys = sorted_keys(s, nkeys);
   p.vals = sorted_vals(s, nkeys);
   p.seg_start = s.seg_start;
   p.nseg = s.nseg;
+  p.long_base = s.long_base;
+  p.piece_start = s.piece_start;
+  p.piece_end = s.piece_end;
+  p.partial = s.partial;
   p.split = split;
 }
 
@@ -600,6 +739,8 @@ extern "C" int collie_mf_train_update(const collie_mf_tables* t, const collie_mf
     if (touched[side]) d.seg_stamp = ws.seg_item;
   }
   if (is_bias) {
+    hipLaunchKernelGGL(piece_bias_kernel<false>, dim3(piece_bias_grid(3 * b->batch)), dim3(kBlock),
+                       0, stream, p);
     hipLaunchKernelGGL(bias_rows_kernel<false>, dim3(bias_grid(3 * b->batch)), dim3(kBlock), 0,
                        stream, p);
     if (check_launch("bias_rows_kernel")) return -2;
@@ -668,6 +809,8 @@ extern "C" int collie_mf_train_export_grad(const collie_mf_tables* t, const coll
     p.d[1].stage = ws.stage_i;
   }
   if (is_bias) {
+    hipLaunchKernelGGL(piece_bias_kernel<true>, dim3(piece_bias_grid(3 * b->batch)), dim3(kBlock),
+                       0, stream, p);
     hipLaunchKernelGGL(bias_rows_kernel<true>, dim3(bias_grid(3 * b->batch)), dim3(kBlock), 0,
                        stream, p);
     if (check_launch("export_grad")) return -2;
@@ -683,11 +826,11 @@ extern "C" int collie_mf_train_export_grad(const collie_mf_tables* t, const coll
   return 0;
 }
 
-extern "C" size_t collie_sparse_rows_workspace_bytes(int64_t m) {
-  if (m < 1) return 0;
+extern "C" size_t collie_sparse_rows_workspace_bytes(int64_t m, int32_t dim) {
+  if (m < 1 || dim < 1) return 0;
   Carver c(nullptr);
   SortWs s;
-  carve_sort_ws(c, s, m);
+  carve_sort_ws(c, s, m, dim);
   return align_up(c.off, 256);
 }
 
@@ -703,7 +846,7 @@ extern "C" int collie_sparse_rows_update(float* table, int64_t num_rows, int32_t
   COLLIE_REQUIRE(m >= 1 && m < (int64_t{1} << 30), "sparse_rows_update: bad entry count");
   Carver c(workspace);
   SortWs s;
-  carve_sort_ws(c, s, m);
+  carve_sort_ws(c, s, m, dim);
   COLLIE_REQUIRE(workspace && workspace_bytes >= align_up(c.off, 256),
                  "workspace too small: need %zu bytes, got %zu", align_up(c.off, 256),
                  workspace_bytes);
@@ -726,6 +869,8 @@ extern "C" int collie_sparse_rows_update(float* table, int64_t num_rows, int32_t
                  "Adam does not support sparse gradients, please consider SparseAdam instead");
   if (make_hyper(d.h, cfg, 0, true, d.s1, d.s2)) return -1;
   if (dim == 1) {
+    hipLaunchKernelGGL(piece_bias_kernel<false>, dim3(piece_bias_grid(m)), dim3(kBlock), 0, stream,
+                       p);
     hipLaunchKernelGGL(bias_rows_kernel<false>, dim3(bias_grid(m)), dim3(kBlock), 0, stream, p);
     return check_launch("sparse_rows_update");
   }

@@ -196,6 +196,7 @@ __global__ __launch_bounds__(kBlock) void seg_scan_kernel(uint32_t* __restrict__
   if (tid == 0) {
     nseg[0] = carry;
     nseg[1] = carry;  // overwritten by seg_write_kernel if a key >= split exists
+    nseg[2] = 0;      // pieces of long segments (piece_plan_kernel)
     seg_start[carry] = static_cast<uint32_t>(m);
   }
 }
@@ -235,6 +236,35 @@ __global__ __launch_bounds__(kBlock) void seg_write_kernel(const uint32_t* __res
       seg_start[pos] = static_cast<uint32_t>(idx);
       // the first segment of the second table (keys are sorted: exactly one such head)
       if (keys[idx] >= split && (idx == 0 || keys[idx - 1] < split)) nseg[1] = pos;
+    }
+  }
+}
+
+// one thread per segment: segments longer than kPieceLen get ceil(len / kPieceLen) consecutive
+// pieces.  The piece numbers come from an integer atomic (their values vary run to run); what a
+// piece sums and the order in which a segment's pieces are combined do not.
+__global__ __launch_bounds__(kBlock) void piece_plan_kernel(const uint32_t* __restrict__ seg_start,
+                                                            uint32_t* __restrict__ nseg,
+                                                            uint32_t* __restrict__ long_base,
+                                                            uint32_t* __restrict__ piece_start,
+                                                            uint32_t* __restrict__ piece_end) {
+  const uint32_t n = nseg[0];
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t seg = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; seg < n;
+       seg += stride) {
+    const uint32_t start = seg_start[seg], end = seg_start[seg + 1];
+    const uint32_t len = end - start;
+    if (len <= kPieceLen) {
+      long_base[seg] = kNoPiece;
+      continue;
+    }
+    const uint32_t np = (len + kPieceLen - 1) / kPieceLen;
+    const uint32_t base = atomicAdd(&nseg[2], np);
+    long_base[seg] = base;
+    for (uint32_t i = 0; i < np; ++i) {
+      piece_start[base + i] = start + i * kPieceLen;
+      const uint32_t pe = start + (i + 1) * kPieceLen;
+      piece_end[base + i] = pe < end ? pe : end;
     }
   }
 }
@@ -279,6 +309,10 @@ int sort_and_segment(const SortWs& s, int64_t nkeys, uint32_t split, hipStream_t
                      s.nseg, s.seg_start);
   hipLaunchKernelGGL(seg_write_kernel, grid, dim3(kBlock), 0, stream, sorted, s.m, split,
                      s.blk_heads, s.seg_start, s.nseg);
+  int64_t pblocks = (s.m + kBlock - 1) / kBlock;
+  if (pblocks > 1024) pblocks = 1024;
+  hipLaunchKernelGGL(piece_plan_kernel, dim3(static_cast<unsigned>(pblocks)), dim3(kBlock), 0,
+                     stream, s.seg_start, s.nseg, s.long_base, s.piece_start, s.piece_end);
   return check_launch("segment heads");
 }
 

@@ -28,10 +28,23 @@ struct SortWs {
   uint32_t* totals;     // [4 * 2^kMaxRadixBits]
   uint32_t* seg_start;  // [m + 1]
   uint32_t* blk_heads;  // [ntiles + 1]
-  uint32_t* nseg;       // [0] number of segments, [1] index of the first segment with key >= split
+  uint32_t* nseg;       // [0] number of segments, [1] index of the first segment with key >= split,
+                        // [2] number of pieces of long segments
+  // Long segments (a hot row under skewed ids: one row can own a large share of the batch) are cut
+  // into pieces of kPieceLen entries that are summed in parallel, then combined in piece order.
+  uint32_t* long_base;    // [m] per segment: first piece, or kNoPiece
+  uint32_t* piece_start;  // [max_pieces] first entry of the piece
+  uint32_t* piece_end;    // [max_pieces]
+  float* partial;         // [max_pieces, D] piece sums (bias updates use the first max_pieces floats)
+  int64_t max_pieces;
 };
 
-inline void carve_sort_ws(Carver& c, SortWs& s, int64_t m) {
+constexpr int kPieceLen = 256;
+constexpr uint32_t kNoPiece = 0xffffffffu;
+// every piece but the last of a segment is full, and only segments longer than one piece have any
+inline int64_t max_pieces_for(int64_t m) { return 2 * (m / kPieceLen) + 2; }
+
+inline void carve_sort_ws(Carver& c, SortWs& s, int64_t m, int D) {
   s.m = m;
   s.ntiles = (m + kSortTile - 1) / kSortTile;
   s.ekeys = c.take<uint32_t>(m);
@@ -45,6 +58,11 @@ inline void carve_sort_ws(Carver& c, SortWs& s, int64_t m) {
   s.seg_start = c.take<uint32_t>(m + 1);
   s.blk_heads = c.take<uint32_t>(s.ntiles + 1);
   s.nseg = c.take<uint32_t>(64);
+  s.long_base = c.take<uint32_t>(m);
+  s.max_pieces = max_pieces_for(m);
+  s.piece_start = c.take<uint32_t>(s.max_pieces);
+  s.piece_end = c.take<uint32_t>(s.max_pieces);
+  s.partial = c.take<float>(static_cast<size_t>(s.max_pieces) * D);
 }
 
 // radix plan for keys in [0, nkeys)
@@ -88,7 +106,7 @@ inline TrainWs carve_train_ws(void* base, int64_t B, int K, int D, int64_t num_u
   w.stage_i = c.take<float>(static_cast<size_t>(B) * D);
   w.gcoef = c.take<float>(B);
   w.loss_partials = c.take<float>(2 * kMaxLossBlocks);
-  carve_sort_ws(c, w.sort, 3 * B);
+  carve_sort_ws(c, w.sort, 3 * B, D);
   w.bytes = align_up(c.off, 256);
   return w;
 }

@@ -161,10 +161,10 @@ def sparse_rows_update(table, rows, vals, cfg, state1=None, state2=None, status=
     m = rows.shape[0]
     if m == 0:
         return workspace
-    need = int(load().collie_sparse_rows_workspace_bytes(m))
+    dim = table.shape[1] if table.dim() == 2 else 1
+    need = int(load().collie_sparse_rows_workspace_bytes(m, dim))
     if workspace is None or workspace.numel() < need:
         workspace = torch.empty(need, dtype=torch.uint8, device=table.device)
-    dim = table.shape[1] if table.dim() == 2 else 1
     check(load().collie_sparse_rows_update(
         ptr(table), table.shape[0], dim, ptr(rows), idx_dtype(rows), ptr(vals), m, byref(cfg),
         ptr(state1), ptr(state2), ptr(workspace), workspace.numel(), ptr(status), stream_ptr()),

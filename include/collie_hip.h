@@ -205,8 +205,8 @@ int collie_mf_train_export_grad(const collie_mf_tables* t, const collie_mf_batch
  * (torch/optim/_functional.py:41-84): rows [m] (int32/int64) with values vals [m, dim].  Sorts,
  * sums duplicates in input order (deterministic) and updates the rows in place.  Used by the
  * row-sharded multi-GPU step (owners apply the gradient rows they receive) and by the generic
- * route.  workspace: collie_sparse_rows_workspace_bytes(m) bytes (need not be zeroed). */
-size_t collie_sparse_rows_workspace_bytes(int64_t m);
+ * route.  workspace: collie_sparse_rows_workspace_bytes(m, dim) bytes (need not be zeroed). */
+size_t collie_sparse_rows_workspace_bytes(int64_t m, int32_t dim);
 int collie_sparse_rows_update(float* table, int64_t num_rows, int32_t dim, const void* rows,
                               int32_t rows_dtype, const float* vals, int64_t m,
                               const collie_optim_cfg* cfg, float* state1, float* state2,

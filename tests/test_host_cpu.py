@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
     # size queries are pure host functions
     assert lib.collie_mf_train_workspace_bytes(1024, 10, 64, 1000, 500) > 1024 * 64 * 4 * 2
     assert lib.collie_mf_train_workspace_bytes(0, 10, 64, 1000, 500) == 0
-    assert lib.collie_sparse_rows_workspace_bytes(1000) > 1000 * 4 * 6
+    assert lib.collie_sparse_rows_workspace_bytes(1000, 64) > 1000 * 4 * 6
     assert lib.collie_mf_eval_topk_capacity() >= 10
 
 
