@@ -175,3 +175,54 @@ class ApproximateNegativeSamplingInteractionsDataLoader(_BaseLoader):
         else:
             interactions.max_number_of_samples_to_consider = 0
         super().__init__(interactions, batch_size, shuffle)
+
+
+class DeviceInteractionsDataLoader(_BaseLoader):
+    """
+    The loaders above with the data resident in HBM and every batch assembled on the device
+    (``collie_sample_batch``): same constructor arguments, same batch format
+    ``((users int32 [B], pos int32 [B]), neg int64 [B, K])``, same sampling rules
+    (``max_number_of_samples_to_consider == 0``: approximate, ``datasets.py:427-443``; otherwise the
+    exact rejection rule of ``datasets.py:399-426`` against the user's positives), but the tensors
+    it yields already live on ``device``, so a training epoch never waits for the host: shuffling is
+    one device permutation per epoch (``samplers.py:43-44``) and the negatives come from a
+    counter-based Philox stream keyed by ``interactions.seed``.
+    There is no CPU fallback: ``device`` must be a HIP device.
+    """
+
+    def __init__(self, interactions=None, mat=None, users=None, items=None, ratings=None,
+                 batch_size: int = 1024, shuffle: bool = False, device='cuda', **kwargs):
+        if interactions is None:
+            interactions = Interactions(mat=mat, users=users, items=items, ratings=ratings, **kwargs)
+        super().__init__(interactions, batch_size, shuffle)
+        from collie_amd import _lib
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise _lib.CollieHipError('DeviceInteractionsDataLoader samples on a HIP device only')
+        mat = interactions.mat
+        self._rows = torch.from_numpy(np.ascontiguousarray(mat.row, dtype=np.int32)).to(self.device)
+        self._cols = torch.from_numpy(np.ascontiguousarray(mat.col, dtype=np.int32)).to(self.device)
+        self._indptr = self._indices = None
+        if interactions.max_number_of_samples_to_consider > 0:
+            csr = mat.tocsr()
+            csr.sort_indices()
+            self._indptr = torch.from_numpy(csr.indptr.astype(np.int64)).to(self.device)
+            self._indices = torch.from_numpy(csr.indices.astype(np.int32)).to(self.device)
+        self._gen = torch.Generator(device=self.device)
+        self._gen.manual_seed(int(interactions.seed))
+        self.epoch = 0
+
+    def __iter__(self):
+        from collie_amd import ops
+        it = self.interactions
+        n = len(it)
+        order = None
+        if self.shuffle:
+            order = torch.randperm(n, device=self.device, generator=self._gen)
+        base = self.epoch * n
+        self.epoch += 1
+        for start in range(0, n, self.batch_size):
+            b = min(self.batch_size, n - start)
+            yield ops.sample_batch(self._rows, self._cols, order, start, b, self._indptr,
+                                   self._indices, it.num_items, it.num_negative_samples,
+                                   it.max_number_of_samples_to_consider, it.seed, base)

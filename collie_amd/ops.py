@@ -237,6 +237,24 @@ def loss_forward_backward(loss_cfg, s_pos, s_neg_KB, pos_items=None, neg_items_K
 
 
 
+# ---- device-side batch assembly + negative sampling ------------------------------------------------
+def sample_batch(rows, cols, order, start, batch, indptr, indices, num_items, num_neg, max_tries,
+                 seed, position_base):
+    """((users int32 [B], pos int32 [B]), neg int64 [B, K]) for dataset entries
+    order[start:start + batch], produced on the device (``collie_sample_batch``)."""
+    require_hip(rows, 'rows')
+    dev = rows.device
+    users = torch.empty(batch, dtype=torch.int32, device=dev)
+    pos = torch.empty(batch, dtype=torch.int32, device=dev)
+    neg = torch.empty(batch, num_neg, dtype=torch.int64, device=dev)
+    check(load().collie_sample_batch(
+        ptr(rows), ptr(cols), rows.shape[0], ptr(order), start, batch, ptr(indptr), ptr(indices),
+        num_items, num_neg, max_tries, seed & 0xFFFFFFFFFFFFFFFF,
+        position_base & 0xFFFFFFFFFFFFFFFF, ptr(users), ptr(pos), ptr(neg), stream_ptr()),
+        'collie_sample_batch')
+    return (users, pos), neg
+
+
 # ---- row-sharded training: requester-side plan ---------------------------------------------------
 class ShardPlanner:
     """Persistent stamp / slot tables of one sharded model + the per-step plan call."""

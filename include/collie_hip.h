@@ -309,6 +309,26 @@ int collie_mf_eval_metrics(const int64_t* topk_ids, int32_t k, int64_t n_users, 
                            const uint64_t* counts, int32_t has_y_range, float y_lo, float y_hi,
                            double* ap, float* rr, double* auc, collie_stream_t stream);
 
+/* ---- device-side batch assembly + negative sampling ---------------------
+ * Replaces Interactions.__getitem__ / _negative_sample (collie/interactions/datasets.py:375-445)
+ * and the index shuffling of the samplers (collie/interactions/samplers.py:43-60) for one batch:
+ * sample t is dataset entry order[start + t] (order == NULL: dataset order) of the COO arrays
+ * rows / cols [nnz]; outputs are the loaders' batch format, users int32 [batch], pos int32
+ * [batch], neg int64 [batch, num_neg] (datasets.py:382-388), written in HBM.
+ *   indptr / indices: CSR of the positives (column ids ascending inside a row), or both NULL for
+ *       approximate sampling (max_number_of_samples_to_consider == 0, datasets.py:427-443);
+ *   max_tries: max_number_of_samples_to_consider (rejections per sample, datasets.py:411);
+ *   seed, position_base: the draws of sample t come from Philox4x32-10 with key = seed and counter
+ *       = (position_base + start + t, draw number): pass position_base = epoch * nnz so that every
+ *       epoch draws fresh negatives.  (The reference's stream is CPython random / numpy global
+ *       state: only the distribution and the rejection rule are reproduced.) */
+int collie_sample_batch(const int32_t* rows, const int32_t* cols, int64_t nnz,
+                        const int64_t* order, int64_t start, int64_t batch,
+                        const int64_t* indptr, const int32_t* indices, int64_t num_items,
+                        int32_t num_neg, int32_t max_tries, uint64_t seed, uint64_t position_base,
+                        int32_t* users_out, int32_t* pos_out, int64_t* neg_out,
+                        collie_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
