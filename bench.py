@@ -112,21 +112,24 @@ def step_algorithmic_bytes(batch_tensors):
     return fwd_algorithmic_bytes(B) + opt, u_star, i_star
 
 
-def pmc_traffic(batch):
+def pmc_traffic(shape, batch):
     """
     HBM-side bytes per launch of the forward kernel, from the committed rocprofv3 --pmc passes of
-    this same command (profiles/r01_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in
-    separate runs, KiB -> bytes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).
-    A PMC pass cannot run inside the timed benchmark, so the number is read, not measured live;
-    None when no pass was recorded for this batch size.
+    this same command (profiles/r01_pmc_traffic.json, written by tools/summarize_profiles.py:
+    FETCH_SIZE and WRITE_SIZE collected in separate runs, KiB -> bytes, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  A PMC pass cannot run inside the timed benchmark,
+    so the number is read, not measured live; None when no pass was recorded for this workload.
     """
     path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
     try:
         with open(path) as f:
-            rec = json.load(f).get(str(batch))
+            per_kernel = json.load(f).get(f'{shape}_B{batch}', {})
     except (OSError, ValueError):
         return None
-    return rec['traffic_bytes'] if rec else None
+    for name, rec in per_kernel.items():
+        if name.startswith('mf_train_fwd_lds'):
+            return rec['hbm_bytes_per_launch']
+    return None
 
 
 def cpu_baseline(seconds=12.0, batch=1024):
@@ -372,12 +375,12 @@ def main():
                 'final_loss': final_loss,
             },
             'roofline': {
-                'kernel': ('mf_train_fwd_lds<4,4,1,false>' if DIM == 64 else
-                           'mf_train_fwd_lds<8,4,1,false>') +
+                'kernel': ('mf_train_fwd_lds<CH=4,LPR=4,NP=1,KIND=bpr,META=0>' if DIM == 64 else
+                           'mf_train_fwd_lds<CH=8,LPR=4,NP=1,KIND=bpr,META=0>') +
                           ' (+ loss_finalize_kernel, 5 us): calculate_loss = '
                           'fused gather + dot + loss + backward staging',
                 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic(args.batch) if args.shape == 'c2' else None,
+                'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic(args.shape, args.batch),
                 'algorithmic_bytes_per_launch': alg, 'avg_launch_ms': fwd_ms,
                 'whole_step': {
                     'note': 'all kernels of the step (forward + coalesce + optimizer row updates): '

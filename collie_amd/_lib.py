@@ -159,7 +159,12 @@ def ptr(t):
 
 
 def stream_ptr():
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+    """torch's current HIP stream of the current device as a raw handle (the private accessor is
+    ~30x cheaper than building a ``torch.cuda.Stream`` object per launch)."""
+    try:
+        return c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
+    except AttributeError:                       # accessor renamed: the public route still works
+        return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 def idx_dtype(t):

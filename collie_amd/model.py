@@ -275,12 +275,15 @@ class MatrixFactorizationModel(nn.Module):
             self.hparams.metadata_for_loss = {k: torch.as_tensor(v).to(self.device)
                                               for k, v in md.items()}
         self._meta_codes = None
+        self._loss_cfg = None
 
     def _apply(self, fn, *args, **kwargs):
         out = super()._apply(fn, *args, **kwargs)
         self._workspace = None
         self._status = None
         self._meta_codes = None
+        self._loss_cfg = None
+        self._tables_cache = None
         self._staged_step = None
         return out
 
@@ -378,8 +381,15 @@ class MatrixFactorizationModel(nn.Module):
 
     # ------------------------------------------------------------------------------- arithmetic
     def _tables(self):
-        return _lib.make_tables(self.user_embeddings.weight.data, self.item_embeddings.weight.data,
-                                self.user_biases.weight.data, self.item_biases.weight.data)
+        """The four tables as the C struct; rebuilt only when a parameter's storage moved."""
+        ws = (self.user_embeddings.weight, self.item_embeddings.weight, self.user_biases.weight,
+              self.item_biases.weight)
+        key = tuple(w.data_ptr() for w in ws)
+        cached = getattr(self, '_tables_cache', None)
+        if cached is None or cached[0] != key:
+            cached = (key, _lib.make_tables(*(w.data for w in ws)))
+            self._tables_cache = cached
+        return cached[1]
 
     def _table_slot(self, param):
         for name, slot in _SLOTS.items():
@@ -472,7 +482,11 @@ class MatrixFactorizationModel(nn.Module):
         codes, weights = self._meta_codes
         tables = self._tables()
         hbatch = ops.make_batch(users, pos_items, neg_items)
-        cfg = ops.make_loss_cfg(self._loss_kind, self.hparams.num_items, codes, weights)
+        cfg = getattr(self, '_loss_cfg', None)
+        if cfg is None or cfg._key != (self._loss_kind, self.hparams.num_items, id(codes)):
+            cfg = ops.make_loss_cfg(self._loss_kind, self.hparams.num_items, codes, weights)
+            cfg._key = (self._loss_kind, self.hparams.num_items, id(codes))
+            self._loss_cfg = cfg
         loss_value = torch.empty(1, dtype=torch.float32, device=dev)
         step_id = self._workspace.next_step() if need_grad else max(self._workspace.step_id, 1)
         ops.train_forward(tables, hbatch, cfg, buf, need_grad, step_id, loss_value, None, None,

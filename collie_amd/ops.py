@@ -67,7 +67,11 @@ class TrainWorkspace:
         self.step_id = 0
 
     def ensure(self, batch_size, num_neg, dim, num_users, num_items):
-        need = train_workspace_bytes(batch_size, num_neg, dim, num_users, num_items)
+        key = (batch_size, num_neg, dim, num_users, num_items)
+        if key != getattr(self, '_key', None):
+            self._need = train_workspace_bytes(*key)
+            self._key = key
+        need = self._need
         if need == 0:
             raise ValueError('empty batch')
         if self.buf is None or self.buf.numel() < need:

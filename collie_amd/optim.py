@@ -28,7 +28,12 @@ class _FusedMixin:
         model = getattr(self, '_collie_model', None)
         if model is not None:
             model._drop_staged_step()
-        return super().zero_grad(set_to_none=set_to_none)
+        # the fused route never materialises ``.grad``: nothing to clear in the usual case
+        for group in self.param_groups:
+            for p in group['params']:
+                if p.grad is not None:
+                    return super().zero_grad(set_to_none=set_to_none)
+        return None
 
     def _staged(self):
         model = getattr(self, '_collie_model', None)
@@ -37,11 +42,13 @@ class _FusedMixin:
         st = model._staged_step
         return st if (st is not None and st.armed) else None
 
-    @torch.no_grad()
     def step(self, closure=None):
         staged = self._staged()
-        if staged is None:
-            return super().step(closure)
+        if staged is None or self._optimizer_step_pre_hooks or self._optimizer_step_post_hooks:
+            return self._torch_step(closure)
+        return self._fused_step(staged, closure)
+
+    def _fused_step(self, staged, closure=None):
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -64,6 +71,28 @@ class _FusedMixin:
             if per_side:
                 staged.update(is_bias, dense, per_side)
         return loss
+
+    # torch wraps ``step`` of every Optimizer class with profiler / hook plumbing (~45 us per call,
+    # more than the launches of a small batch); a step marked ``hooked`` is left alone, and the
+    # wrapped form is still used whenever hooks are registered or no fused step is staged.
+    step.hooked = True
+
+    def _torch_step(self, closure=None):
+        base = next(c for c in type(self).__mro__
+                    if c.__module__.startswith('torch.optim') and 'step' in c.__dict__)
+        staged = self._staged()
+        if staged is None:
+            return base.step(self, closure)
+        # hooks registered: run them around the fused update as torch's wrapper would
+        from torch.optim.optimizer import _global_optimizer_pre_hooks, _global_optimizer_post_hooks
+        for hook in list(_global_optimizer_pre_hooks.values()) + list(
+                self._optimizer_step_pre_hooks.values()):
+            hook(self, (closure,) if closure is not None else (), {})
+        out = self._fused_step(staged, closure)
+        for hook in list(self._optimizer_step_post_hooks.values()) + list(
+                _global_optimizer_post_hooks.values()):
+            hook(self, (closure,) if closure is not None else (), {})
+        return out
 
     @staticmethod
     def _stamp(state, p):
