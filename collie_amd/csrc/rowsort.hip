@@ -269,6 +269,139 @@ __global__ __launch_bounds__(kBlock) void piece_plan_kernel(const uint32_t* __re
   }
 }
 
+// ---- small batches: the whole coalesce in ONE workgroup ---------------------------------------------
+// Up to kSmallMax entries (B <= 1365 at 3 entries per sample, i.e. the reference's default batch
+// size of 1,024): the ~11 launches of the general path cost more than their work.  Entries live in
+// LDS; the sort is a stable LSD radix sort one bit at a time (a block-wide prefix count of the
+// zero-bit entries gives every entry its place: zeros keep their order in front, ones behind), then
+// segment heads, the split index and the long-segment pieces, all written in the general layout.
+constexpr int kSmallBlock = 1024;
+constexpr int kSmallPer = 4;
+constexpr int kSmallMax = kSmallBlock * kSmallPer;  // 4096 entries
+
+// exclusive prefix sum of one value per thread over the workgroup; total to every thread
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* wave_tot, uint32_t& total) {
+  const int lane = lane_id();
+  const int w = threadIdx.x / kWave;
+  uint32_t inc = v;
+#pragma unroll
+  for (int o = 1; o < kWave; o <<= 1) {
+    const uint32_t up = __shfl_up(inc, o, kWave);
+    if (lane >= o) inc += up;
+  }
+  __syncthreads();  // wave_tot from the previous call has been read by everyone
+  if (lane == kWave - 1) wave_tot[w] = inc;
+  __syncthreads();
+  uint32_t before = 0, all = 0;
+#pragma unroll
+  for (int i = 0; i < kSmallBlock / kWave; ++i) {
+    const uint32_t t = wave_tot[i];
+    before += i < w ? t : 0u;
+    all += t;
+  }
+  total = all;
+  return before + inc - v;
+}
+
+__global__ __launch_bounds__(kSmallBlock) void small_sort_segment_kernel(
+    const uint32_t* __restrict__ ekeys, const uint32_t* __restrict__ ecodes, int m, int nbits,
+    uint32_t split, uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+    uint32_t* __restrict__ seg_start, uint32_t* __restrict__ nseg, uint32_t* __restrict__ long_base,
+    uint32_t* __restrict__ piece_start, uint32_t* __restrict__ piece_end) {
+  __shared__ uint32_t kbuf[2][kSmallMax];
+  __shared__ uint32_t vbuf[2][kSmallMax];
+  __shared__ uint32_t heads[kSmallMax + 1];
+  __shared__ uint32_t wave_tot[kSmallBlock / kWave];
+  __shared__ uint32_t npieces;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < kSmallMax; i += kSmallBlock) {
+    kbuf[0][i] = i < m ? ekeys[i] : 0xffffffffu;  // padding sorts last and keeps its place
+    vbuf[0][i] = i < m ? ecodes[i] : 0u;
+  }
+  if (tid == 0) npieces = 0;
+  __syncthreads();
+  int cur = 0;
+  for (int bit = 0; bit < nbits; ++bit) {
+    // thread t owns entries 4t .. 4t+3 of the current order
+    uint32_t k[kSmallPer], v[kSmallPer];
+    uint32_t zeros = 0;
+#pragma unroll
+    for (int j = 0; j < kSmallPer; ++j) {
+      k[j] = kbuf[cur][tid * kSmallPer + j];
+      v[j] = vbuf[cur][tid * kSmallPer + j];
+      zeros += ((k[j] >> bit) & 1u) ^ 1u;
+    }
+    uint32_t total_zeros;
+    uint32_t zbefore = block_excl_scan(zeros, wave_tot, total_zeros);
+#pragma unroll
+    for (int j = 0; j < kSmallPer; ++j) {
+      const uint32_t idx = tid * kSmallPer + j;
+      const bool one = (k[j] >> bit) & 1u;
+      const uint32_t pos = one ? total_zeros + (idx - zbefore) : zbefore;
+      kbuf[cur ^ 1][pos] = k[j];
+      vbuf[cur ^ 1][pos] = v[j];
+      zbefore += one ? 0u : 1u;
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  // ---- sorted entries out + segment heads ----------------------------------------------------------
+  uint32_t nh = 0;
+  bool head[kSmallPer];
+#pragma unroll
+  for (int j = 0; j < kSmallPer; ++j) {
+    const int idx = tid * kSmallPer + j;
+    const uint32_t key = kbuf[cur][idx];
+    if (idx < m) {
+      keys_out[idx] = key;
+      vals_out[idx] = vbuf[cur][idx];
+    }
+    head[j] = idx < m && (idx == 0 || key != kbuf[cur][idx - 1]);
+    nh += head[j] ? 1u : 0u;
+  }
+  uint32_t total_heads;
+  uint32_t hbefore = block_excl_scan(nh, wave_tot, total_heads);
+  uint32_t first_split = 0xffffffffu;
+#pragma unroll
+  for (int j = 0; j < kSmallPer; ++j) {
+    const int idx = tid * kSmallPer + j;
+    if (head[j]) {
+      heads[hbefore] = idx;
+      seg_start[hbefore] = idx;
+      const uint32_t key = kbuf[cur][idx];
+      if (key >= split && (idx == 0 || kbuf[cur][idx - 1] < split)) first_split = hbefore;
+      ++hbefore;
+    }
+  }
+  if (tid == 0) {
+    heads[total_heads] = m;
+    seg_start[total_heads] = m;
+    nseg[0] = total_heads;
+    nseg[1] = total_heads;  // overwritten below if a key >= split exists
+  }
+  __syncthreads();
+  if (first_split != 0xffffffffu) nseg[1] = first_split;  // exactly one thread
+  // ---- long segments -> pieces ---------------------------------------------------------------------
+  for (uint32_t seg = tid; seg < total_heads; seg += kSmallBlock) {
+    const uint32_t start = heads[seg], end = heads[seg + 1];
+    const uint32_t len = end - start;
+    if (len <= kPieceLen) {
+      long_base[seg] = kNoPiece;
+      continue;
+    }
+    const uint32_t np = (len + kPieceLen - 1) / kPieceLen;
+    const uint32_t base = atomicAdd(&npieces, np);
+    long_base[seg] = base;
+    for (uint32_t i = 0; i < np; ++i) {
+      piece_start[base + i] = start + i * kPieceLen;
+      const uint32_t pe = start + (i + 1) * kPieceLen;
+      piece_end[base + i] = pe < end ? pe : end;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) nseg[2] = npieces;
+}
+
 template <int BITS>
 int run_pass(const SortWs& s, const uint32_t* kin, const uint32_t* vin, uint32_t* kout,
              uint32_t* vout, int shift, uint32_t* totals, hipStream_t stream) {
@@ -287,6 +420,15 @@ int run_pass(const SortWs& s, const uint32_t* kin, const uint32_t* vin, uint32_t
 int sort_and_segment(const SortWs& s, int64_t nkeys, uint32_t split, hipStream_t stream) {
   const RadixPlan plan = radix_plan(nkeys);
   COLLIE_REQUIRE(plan.passes <= 4, "key range too large for the radix plan");
+  if (s.m <= kSmallMax) {
+    int nbits = 1;
+    while ((int64_t{1} << nbits) < nkeys) ++nbits;
+    const int out = (plan.passes - 1) & 1;  // where sorted_keys() / sorted_vals() look
+    hipLaunchKernelGGL(small_sort_segment_kernel, dim3(1), dim3(kSmallBlock), 0, stream, s.ekeys,
+                       s.ecodes, static_cast<int>(s.m), nbits, split, s.keys[out], s.vals[out],
+                       s.seg_start, s.nseg, s.long_base, s.piece_start, s.piece_end);
+    return check_launch("small_sort_segment_kernel");
+  }
   COLLIE_CHECK_HIP(hipMemsetAsync(s.totals, 0, 4 * (size_t{1} << kMaxRadixBits) * sizeof(uint32_t),
                                   stream));
   for (int pass = 0; pass < plan.passes; ++pass) {
