@@ -372,6 +372,7 @@ __global__ __launch_bounds__(kBlockDma) void eval_gemm_dma_kernel(const EvalPara
   n_thr = __builtin_amdgcn_readfirstlane(n_thr);
   const bool any_long = __ballot(e_end - e_begin > kCap) != 0ull;
   const int k = p.k;
+  float thr = -INFINITY;  // MODE 0: score of the k-th best candidate so far
 
   const int64_t chunk_items = static_cast<int64_t>(p.tiles_per_chunk) * kTileItems;
   const int64_t chunk_begin = p.item_begin + static_cast<int64_t>(blockIdx.y) * chunk_items;
@@ -449,10 +450,10 @@ __global__ __launch_bounds__(kBlockDma) void eval_gemm_dma_kernel(const EvalPara
       if (MODE == 0) {
 #pragma unroll
         for (int rr = 0; rr < 16; ++rr) smax = fmaxf(smax, acc[rr]);
-        if (smax > top_s[kCap - 1]) {
+        if (smax > thr) {
 #pragma unroll
           for (int rr = 0; rr < 16; ++rr) {
-            if (acc[rr] > top_s[kCap - 1]) {
+            if (acc[rr] > thr) {
               const int row = sub * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
               float cs = acc[rr];
               int ci = static_cast<int>((base + row) * p.id_stride + p.id_offset);
@@ -466,6 +467,9 @@ __global__ __launch_bounds__(kBlockDma) void eval_gemm_dma_kernel(const EvalPara
                 cs = better ? ts : cs;
                 ci = better ? ti : ci;
               }
+              // entry threshold = the k-th best so far (k is uniform: a chain of scalar selects)
+#pragma unroll
+              for (int i = 0; i < kCap; ++i) thr = i == k - 1 ? top_s[i] : thr;
             }
           }
         }

@@ -25,7 +25,9 @@ from scipy.sparse import csr_matrix
 from collie_amd import _lib, ops
 from collie_amd.interactions import Interactions
 
-USERS_PER_LAUNCH = 8192
+# users scored per launch: 256 user blocks of the MFMA kernel, so that few item chunks per block are
+# needed to fill the chip (long item streams per block = rare top-k insertions, few candidate lists)
+USERS_PER_LAUNCH = 65536
 
 
 def _get_user_item_pairs(user_ids, n_items: int, device):
@@ -44,6 +46,14 @@ def get_preds(model, user_ids, n_items: int, device) -> torch.Tensor:
     with torch.no_grad():
         predicted_scores = model(user, item)
     return predicted_scores.view(-1, n_items)
+
+
+def _unique_users(test_interactions):
+    """``np.unique(test_interactions.mat.row)`` (metrics.py:367) by counting instead of sorting."""
+    rows = test_interactions.mat.row
+    if len(rows) == 0:
+        return np.unique(rows)
+    return np.flatnonzero(np.bincount(rows, minlength=test_interactions.num_users)).astype(rows.dtype)
 
 
 def _csr_slice(targets: csr_matrix, user_ids, device):
@@ -165,7 +175,7 @@ def evaluate_in_batches(
     model.to(device)
     model._move_any_external_data_to_device()
 
-    test_users = np.unique(test_interactions.mat.row)
+    test_users = _unique_users(test_interactions)
     targets = test_interactions.mat.tocsr()
     n_items = test_interactions.num_items
     if len(test_users) < batch_size:

@@ -554,7 +554,7 @@ class ShardedMatrixFactorizationModel:
         return eng.metrics(topk_ids, k, n, N, indptr, indices, pos, counts, y, want)
 
     def evaluate_in_batches(self, metric_list: Iterable, test_interactions, k: int = 10,
-                            batch_size: int = 20, users_per_launch: int = 8192):
+                            batch_size: int = 20, users_per_launch: int = 65536):
         """
         ``collie.metrics.evaluate_in_batches`` (``metrics.py:285-395``) with the catalog sharded
         over the ranks; every rank returns the same numbers.  ``metric_list`` holds the
@@ -575,7 +575,7 @@ class ShardedMatrixFactorizationModel:
             raise ValueError(f'Ensure ``k`` ({k}) is less than the number of items ({n_items}):')
         if want[0] and (k > 16 or k > self.N_loc):
             raise ValueError(f'k={k} must not exceed 16 or the smallest item shard ({self.N_loc})')
-        test_users = np.unique(test_interactions.mat.row)
+        test_users = M._unique_users(test_interactions)
         targets = test_interactions.mat.tocsr()
         if len(test_users) < batch_size:
             batch_size = len(test_users)
