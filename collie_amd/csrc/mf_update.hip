@@ -717,7 +717,8 @@ extern "C" int collie_mf_train_update(const collie_mf_tables* t, const collie_mf
     TableDesc& d = p.d[side];
     if (is_bias) {
       d.table = side == COLLIE_SIDE_USER ? t->user_bias : t->item_bias;
-      d.stage = side == COLLIE_SIDE_USER ? nullptr : ws.gcoef;
+      // pairwise losses: d loss / d user_bias == 0 exactly; explicit losses (is_bias == 2): g
+      d.stage = (side == COLLIE_SIDE_USER && is_bias != 2) ? nullptr : ws.gcoef;
     } else {
       d.table = side == COLLIE_SIDE_USER ? t->user_emb : t->item_emb;
       d.stage = side == COLLIE_SIDE_USER ? ws.stage_u : ws.stage_i;

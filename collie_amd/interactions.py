@@ -124,10 +124,66 @@ class Interactions:
                 f'{self.num_negative_samples} negative samples per interaction.')
 
 
+class ExplicitInteractions:
+    """Explicit user-item ratings (``datasets.py:448-562``): ``__getitem__`` returns the non-nested
+    ``(user ids, item ids, ratings)`` tuple that marks a batch as explicit."""
+
+    def __init__(self, mat=None, users=None, items=None, ratings=None,
+                 allow_missing_ids: bool = False, remove_duplicate_user_item_pairs: bool = True,
+                 num_users='infer', num_items='infer'):
+        if mat is None and ratings is None:
+            raise ValueError('Ratings must be provided to ``ExplicitInteractions`` with ``mat`` or '
+                             '``ratings`` - both cannot be ``None``!')
+        if mat is None:
+            users, items, ratings = np.asarray(users), np.asarray(items), np.asarray(ratings)
+            if len(users) != len(items) or len(users) != len(ratings):
+                raise ValueError('Lengths of ``users``, ``items`` and ``ratings`` must be equal')
+            if num_users == 'infer':
+                num_users = int(users.max()) + 1
+            if num_items == 'infer':
+                num_items = int(items.max()) + 1
+            if not allow_missing_ids:
+                if len(np.unique(users)) != num_users or len(np.unique(items)) != num_items:
+                    raise ValueError('``users`` / ``items`` are missing ids; pass '
+                                     '``allow_missing_ids=True`` to allow this')
+            mat = coo_matrix((ratings, (users, items)), shape=(num_users, num_items))
+        else:
+            mat = coo_matrix(mat)
+        if remove_duplicate_user_item_pairs:
+            key = mat.row.astype(np.int64) * mat.shape[1] + mat.col
+            _, first = np.unique(key, return_index=True)
+            if len(first) != len(key):
+                first.sort()
+                mat = coo_matrix((mat.data[first], (mat.row[first], mat.col[first])), shape=mat.shape)
+        self.mat = coo_matrix((mat.data, (mat.row.astype(np.int32), mat.col.astype(np.int32))),
+                              shape=mat.shape)
+        self.num_users, self.num_items = self.mat.shape
+        self.num_interactions = self.mat.nnz
+        self.min_rating = self.mat.data.min() if self.mat.nnz else None
+        self.max_rating = self.mat.data.max() if self.mat.nnz else None
+        self.seed = 0
+
+    @property
+    def num_negative_samples(self):
+        raise AttributeError('``num_negative_samples`` does not exist for explicit datasets.')
+
+    def __len__(self):
+        return self.num_interactions
+
+    def __getitem__(self, index):
+        return self.mat.row[index], self.mat.col[index], self.mat.data[index]
+
+    def __repr__(self):
+        return (f'ExplicitInteractions object with {self.num_interactions} interactions between '
+                f'{self.num_users} users and {self.num_items} items, with minimum rating of '
+                f'{self.min_rating} and maximum rating of {self.max_rating}.')
+
+
 class _BaseLoader:
     def __init__(self, interactions, batch_size, shuffle):
-        if not isinstance(interactions, Interactions):
-            raise ValueError('``interactions`` must be an ``Interactions`` object')
+        if not isinstance(interactions, (Interactions, ExplicitInteractions)):
+            raise ValueError('``interactions`` must be an ``Interactions`` or '
+                             '``ExplicitInteractions`` object')
         self.interactions = interactions
         self.batch_size = batch_size
         self.shuffle = shuffle
@@ -136,6 +192,7 @@ class _BaseLoader:
 
     num_users = property(lambda self: self.interactions.num_users)
     num_items = property(lambda self: self.interactions.num_items)
+    # AttributeError for explicit data, so that ``hasattr(loader, 'num_negative_samples')`` is False
     num_negative_samples = property(lambda self: self.interactions.num_negative_samples)
     num_interactions = property(lambda self: self.interactions.num_interactions)
     mat = property(lambda self: self.interactions.mat)
@@ -148,6 +205,12 @@ class _BaseLoader:
             self._rng.shuffle(self._order)
         for start in range(0, len(self.interactions), self.batch_size):
             idxs = self._order[start:start + self.batch_size]
+            if isinstance(self.interactions, ExplicitInteractions):
+                users, items, ratings = self.interactions[idxs]
+                yield (torch.from_numpy(np.ascontiguousarray(users)),
+                       torch.from_numpy(np.ascontiguousarray(items)),
+                       torch.from_numpy(np.ascontiguousarray(ratings)))
+                continue
             (users, items), neg = self.interactions[idxs]
             yield ((torch.from_numpy(np.ascontiguousarray(users)),
                     torch.from_numpy(np.ascontiguousarray(items))),
@@ -196,6 +259,7 @@ class DeviceInteractionsDataLoader(_BaseLoader):
             interactions = Interactions(mat=mat, users=users, items=items, ratings=ratings, **kwargs)
         super().__init__(interactions, batch_size, shuffle)
         from collie_amd import _lib
+        self.explicit = isinstance(interactions, ExplicitInteractions)
         self.device = torch.device(device)
         if self.device.type != 'cuda':
             raise _lib.CollieHipError('DeviceInteractionsDataLoader samples on a HIP device only')
@@ -203,7 +267,9 @@ class DeviceInteractionsDataLoader(_BaseLoader):
         self._rows = torch.from_numpy(np.ascontiguousarray(mat.row, dtype=np.int32)).to(self.device)
         self._cols = torch.from_numpy(np.ascontiguousarray(mat.col, dtype=np.int32)).to(self.device)
         self._indptr = self._indices = None
-        if interactions.max_number_of_samples_to_consider > 0:
+        if self.explicit:
+            self._ratings = torch.from_numpy(np.ascontiguousarray(mat.data)).to(self.device)
+        elif interactions.max_number_of_samples_to_consider > 0:
             csr = mat.tocsr()
             csr.sort_indices()
             self._indptr = torch.from_numpy(csr.indptr.astype(np.int64)).to(self.device)
@@ -223,6 +289,10 @@ class DeviceInteractionsDataLoader(_BaseLoader):
         self.epoch += 1
         for start in range(0, n, self.batch_size):
             b = min(self.batch_size, n - start)
+            if self.explicit:      # no sampling: index plumbing only
+                sl = slice(start, start + b) if order is None else order[start:start + b]
+                yield self._rows[sl], self._cols[sl], self._ratings[sl]
+                continue
             yield ops.sample_batch(self._rows, self._cols, order, start, b, self._indptr,
                                    self._indices, it.num_items, it.num_negative_samples,
                                    it.max_number_of_samples_to_consider, it.seed, base)

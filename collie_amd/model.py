@@ -80,9 +80,10 @@ class _MFScore(torch.autograd.Function):
 class _FusedStep:
     """One staged backward: batch, workspace, step id and whether the segments exist yet."""
 
-    def __init__(self, model, tables, batch, buf, step_id):
+    def __init__(self, model, tables, batch, buf, step_id, explicit=False):
         self.model, self.tables, self.batch, self.buf = model, tables, batch, buf
         self.step_id = step_id
+        self.explicit = explicit      # explicit losses: the user-bias gradient is not zero
         self.armed = False
         self.grad_scale = None
         self.segments = False
@@ -96,8 +97,9 @@ class _FusedStep:
         if not self.segments:
             ops.train_build_segments(self.tables, self.batch, self.buf)
             self.segments = True
-        ops.train_update(self.tables, self.batch, self.buf, is_bias, dense, self.step_id, per_side,
-                         self.grad_scale)
+        ops.train_update(self.tables, self.batch, self.buf,
+                         (2 if self.explicit else 1) if is_bias else 0, dense, self.step_id,
+                         per_side, self.grad_scale)
         self.done.update((s, is_bias) for s in per_side)
 
 
@@ -457,6 +459,9 @@ class MatrixFactorizationModel(nn.Module):
             if self.hparams.get('_is_implicit') is True:
                 raise ValueError('Implicit loss with explicit data is invalid!')
             (users, items, ratings) = batch
+            if (isinstance(self.loss, str) and self.loss in ops.EXPLICIT_LOSSES
+                    and not (self.training and self.hparams.dropout_p > 0)):
+                return self._fused_explicit_loss(users, items, ratings)
             preds = self(users.long(), items.long())
             return self.loss_function(preds, ratings.float())
         else:
@@ -494,6 +499,40 @@ class MatrixFactorizationModel(nn.Module):
         if not need_grad:
             return loss_value.reshape(())
         staged = _FusedStep(self, tables, hbatch, buf, step_id)
+        self._staged_step = staged
+        weights_ = [getattr(self, n).weight for n in _TABLES]
+        return _FusedLoss.apply(self, staged, loss_value, *weights_)
+
+    def _fused_explicit_loss(self, users, items, ratings):
+        """``base_pipeline.py:635-650`` with ``loss='mse' | 'mae'``: one fused HIP kernel."""
+        dev = self.device
+        _lib.require_hip(self.user_embeddings.weight, 'MatrixFactorizationModel')
+        for t in (users, items, ratings):
+            _lib.require_hip(t, 'batch')
+        users = users.contiguous()
+        items = items.contiguous()
+        ratings = ratings.float().contiguous()
+        need_grad = torch.is_grad_enabled() and any(
+            getattr(self, n).weight.requires_grad for n in _TABLES)
+        if self._workspace is None:
+            self._workspace = ops.TrainWorkspace(dev)
+        self._staged_step = None
+        B = users.shape[0]
+        buf = self._workspace.ensure(B, 1, self.hparams.embedding_dim, self.hparams.num_users,
+                                     self.hparams.num_items)
+        tables = self._tables()
+        y = self.hparams.get('y_range')
+        loss_value = torch.empty(1, dtype=torch.float32, device=dev)
+        step_id = self._workspace.next_step() if need_grad else max(self._workspace.step_id, 1)
+        ops.explicit_forward(tables, users, items, ratings, self.loss,
+                             tuple(y) if y is not None else None, buf, need_grad, loss_value, None,
+                             self._status_flag())
+        if not need_grad:
+            return loss_value.reshape(())
+        col = items.reshape(-1, 1)
+        hbatch = ops.make_batch(users, items, col)
+        hbatch._keepalive = (users, items, col, ratings)
+        staged = _FusedStep(self, tables, hbatch, buf, step_id, explicit=True)
         self._staged_step = staged
         weights_ = [getattr(self, n).weight for n in _TABLES]
         return _FusedLoss.apply(self, staged, loss_value, *weights_)

@@ -95,6 +95,21 @@ def train_forward(tables, batch, loss_cfg, ws_buf, need_grad, step_id, loss_out,
         ptr(status), stream_ptr()), 'collie_mf_train_forward')
 
 
+EXPLICIT_LOSSES = {'mse': 0, 'mae': 1}
+
+
+def explicit_forward(tables, users, items, ratings, kind, y_range, ws_buf, need_grad, loss_out,
+                     preds_out=None, status=None):
+    """Explicit branch of calculate_loss: MSE / MAE of forward(users, items) vs ratings, with the
+    backward staged in ``ws_buf`` (``collie_mf_explicit_forward``)."""
+    has_y = y_range is not None
+    check(load().collie_mf_explicit_forward(
+        byref(tables), ptr(users), idx_dtype(users), ptr(items), idx_dtype(items), ptr(ratings),
+        users.shape[0], EXPLICIT_LOSSES[kind], int(has_y), float(y_range[0]) if has_y else 0.0,
+        float(y_range[1]) if has_y else 0.0, ptr(ws_buf), ws_buf.numel(), 1 if need_grad else 0,
+        ptr(loss_out), ptr(preds_out), ptr(status), stream_ptr()), 'collie_mf_explicit_forward')
+
+
 def train_build_segments(tables, batch, ws_buf):
     check(load().collie_mf_train_build_segments(
         byref(tables), byref(batch), ptr(ws_buf), ws_buf.numel(), stream_ptr()),
@@ -121,7 +136,7 @@ def train_update(tables, batch, ws_buf, is_bias, dense, step_id, per_side, grad_
         s1[side], s2[side], st[side] = a, b, c
         mask |= 1 << side
     check(load().collie_mf_train_update(
-        byref(tables), byref(batch), ptr(ws_buf), ws_buf.numel(), mask, 1 if is_bias else 0,
+        byref(tables), byref(batch), ptr(ws_buf), ws_buf.numel(), mask, int(is_bias),
         1 if dense else 0, step_id, cfgs, _ptr_array(s1), _ptr_array(s2), _ptr_array(st),
         ptr(grad_scale), stream_ptr()), 'collie_mf_train_update')
 

@@ -54,6 +54,9 @@ enum {
 
 enum { COLLIE_SIDE_USER = 0, COLLIE_SIDE_ITEM = 1 };
 
+/* explicit-feedback losses (collie/model/base/base_pipeline.py:287-292) */
+enum { COLLIE_EXPLICIT_MSE = 0, COLLIE_EXPLICIT_MAE = 1 };
+
 #define COLLIE_MAX_META 4
 #define COLLIE_MAX_NEG 63 /* fused training path: one wave lane per (positive|negative) score */
 
@@ -173,7 +176,8 @@ int collie_mf_train_build_segments(const collie_mf_tables* t, const collie_mf_ba
                                    collie_stream_t stream);
 
 /* A10/A11  optimizer.step() for the embedding tables (is_bias = 0) or the bias tables
- * (is_bias = 1) of one or both sides in one launch.  table_mask: bit 0 = user table, bit 1 = item
+ * (is_bias = 1; 2 after collie_mf_explicit_forward: both bias tables carry a gradient) of one or
+ * both sides in one launch.  table_mask: bit 0 = user table, bit 1 = item
  * table; cfg / state1 / state2 / row_stamp are indexed [COLLIE_SIDE_USER], [COLLIE_SIDE_ITEM]
  * (entries of sides not in the mask are ignored).
  * Sparse algorithms (sparse=True models, dense = 0): SGD / ADAGRAD / SPARSE_ADAM touch exactly the
@@ -308,6 +312,23 @@ int collie_mf_eval_metrics(const int64_t* topk_ids, int32_t k, int64_t n_users, 
                            const int64_t* indptr, const int64_t* indices, const float* pos_scores,
                            const uint64_t* counts, int32_t has_y_range, float y_lo, float y_hi,
                            double* ap, float* rr, double* auc, collie_stream_t stream);
+
+/* ---- explicit feedback ----------------------------------------------------
+ * Replaces the explicit branch of BasePipeline.calculate_loss (base_pipeline.py:635-650):
+ * preds = forward(users, items) (matrix_factorization.py:143-157, y_range sigmoid rescale
+ * included), loss = torch.nn.MSELoss / L1Loss(reduction='mean')(preds, ratings), and the
+ * score-level backward, staged in the training workspace (collie_mf_train_workspace_bytes(batch,
+ * 1, dim, ...)) exactly as collie_mf_train_forward stages the implicit step.  Follow with
+ * collie_mf_train_build_segments and collie_mf_train_update on a batch descriptor whose
+ * pos_items / neg_items both point at `items` (num_neg = 1); the bias update must be called with
+ * is_bias = 2 (the user-bias gradient is not identically zero for an explicit loss).
+ * preds_out (optional): [batch] predictions.  need_grad = 0: loss (and preds) only. */
+int collie_mf_explicit_forward(const collie_mf_tables* t, const void* users, int32_t users_dtype,
+                               const void* items, int32_t items_dtype, const float* ratings,
+                               int64_t batch, int32_t loss_kind, int32_t has_y_range, float y_lo,
+                               float y_hi, void* workspace, size_t workspace_bytes,
+                               int32_t need_grad, float* loss_out, float* preds_out,
+                               int32_t* status, collie_stream_t stream);
 
 /* ---- device-side batch assembly + negative sampling ---------------------
  * Replaces Interactions.__getitem__ / _negative_sample (collie/interactions/datasets.py:375-445)

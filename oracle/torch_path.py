@@ -154,6 +154,20 @@ def train_step(model, optimizers, batch, loss_fn, **kw):
     return loss.detach(), pos_preds.detach(), neg_preds.detach()
 
 
+def explicit_train_step(model, optimizers, batch, loss='mse'):
+    """Explicit branch (base_pipeline.py:635-650, :287-292): MSELoss / L1Loss on forward()."""
+    users, items, ratings = batch
+    loss_fn = torch.nn.MSELoss(reduction='mean') if loss == 'mse' else torch.nn.L1Loss(reduction='mean')
+    for opt in optimizers:
+        opt.zero_grad()
+    preds = model(users.long(), items.long())
+    out = loss_fn(preds, ratings.float())
+    out.backward()
+    for opt in optimizers:
+        opt.step()
+    return out.detach(), preds.detach()
+
+
 def eval_users_torch(model, user_ids, n_items, k):
     """metrics.py:60-72,102-107,171: pair expansion, one forward over Bu*N pairs, topk."""
     users = torch.as_tensor(user_ids, dtype=torch.int64).repeat_interleave(n_items)

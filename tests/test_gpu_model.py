@@ -223,3 +223,96 @@ def test_out_of_range_ids_raise_at_check(dev):
     step(m, opts, batch)
     with pytest.raises(IndexError):
         m.check_status()
+
+
+@pytest.mark.parametrize('loss,y_range,sparse,opt,bias_opt,D', [
+    ('mse', None, True, 'sparse_adam', 'sgd', 64), ('mae', (1.0, 5.0), True, 'adagrad', 'sgd', 30),
+    ('mse', (0.0, 5.0), False, 'adam', 'sgd', 10), ('mae', None, True, 'sgd', 'infer', 128),
+    ('mse', None, True, 'sparse_adam', 'sgd', 8), ('mse', (1.0, 5.0), True, 'adagrad', 'sgd', 4),
+    ('mae', None, True, 'sparse_adam', 'sgd', 3)])
+def test_explicit_fused_trajectory_vs_torch_reference_path(loss, y_range, sparse, opt, bias_opt, D):
+    """Explicit feedback (base_pipeline.py:635-650): three steps of the fused HIP path against the
+    reference's torch op sequence on the CPU (oracle/torch_path.py), same tables, same batches."""
+    from oracle import torch_path as T
+    from collie_amd.model import MatrixFactorizationModel
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(7)
+    U, N, B = 200, 150, 700
+
+    class ExplicitShape:
+        num_users, num_items = U, N
+
+    torch.manual_seed(0)
+    model = MatrixFactorizationModel(train=ExplicitShape(), embedding_dim=D, sparse=sparse, lr=5e-2,
+                                     bias_lr=5e-2 if bias_opt != 'infer' else 'infer', loss=loss,
+                                     optimizer=opt, bias_optimizer=bias_opt, y_range=y_range,
+                                     lr_scheduler_func=None)
+    with torch.no_grad():
+        model.user_embeddings.weight.mul_(30.0)
+        model.item_embeddings.weight.mul_(30.0)
+        model.user_biases.weight.normal_(0, 0.1)
+        model.item_biases.weight.normal_(0, 0.1)
+    tables = {n: getattr(model, n).weight.detach().numpy().copy()
+              for n in ('user_embeddings', 'item_embeddings', 'user_biases', 'item_biases')}
+    ref = T.TorchMF(U, N, D, sparse=sparse, tables=tables, y_range=y_range)
+    ref_opts = T.make_optimizers(ref, opt, opt if bias_opt == 'infer' else bias_opt, 5e-2, 5e-2)
+    model.to(dev)
+    model.train()
+    opts = model.configure_optimizers()
+    for step in range(3):
+        users = (rng.zipf(1.4, B) % U).astype(np.int32)
+        items = rng.integers(0, N, B).astype(np.int64)
+        ratings = rng.integers(1, 6, B).astype(np.float64)
+        want_loss, _ = T.explicit_train_step(
+            ref, ref_opts, (torch.tensor(users), torch.tensor(items), torch.tensor(ratings)), loss)
+        for o in opts:
+            o.zero_grad()
+        got = model.calculate_loss((torch.tensor(users, device=dev), torch.tensor(items, device=dev),
+                                    torch.tensor(ratings, device=dev)))
+        got.backward()
+        for o in opts:
+            o.step()
+        np.testing.assert_allclose(got.item(), want_loss.item(), rtol=1e-5)
+        for n, want in ref.tables().items():
+            have = getattr(model, n).weight.detach().cpu().numpy()
+            np.testing.assert_allclose(have, want, rtol=2e-4, atol=2e-4 * np.abs(want).max(),
+                                       err_msg=f'step {step} table {n}')
+    model.check_status()
+    # evaluation-mode loss (no grad) and implicit/explicit mismatch errors keep the reference's form
+    with torch.no_grad():
+        v = model.calculate_loss((torch.tensor(users, device=dev), torch.tensor(items, device=dev),
+                                  torch.tensor(ratings, device=dev)))
+    assert v.dim() == 0 and torch.isfinite(v)
+    with pytest.raises(ValueError):
+        model.calculate_loss(((torch.tensor(users, device=dev), torch.tensor(items, device=dev)),
+                              torch.tensor(items, device=dev)))
+
+
+def test_explicit_loader_and_trainer_end_to_end():
+    """ExplicitInteractions -> device loader -> CollieMinimalTrainer: MSE falls (base_pipeline.py
+    :635-650 through the fused HIP path, ratings generated by a planted low-rank model)."""
+    from collie_amd.interactions import DeviceInteractionsDataLoader, ExplicitInteractions
+    from collie_amd.model import MatrixFactorizationModel
+    from collie_amd.trainer import CollieMinimalTrainer
+    rng = np.random.default_rng(3)
+    U, N, nnz = 300, 200, 12000
+    keys = rng.choice(U * N, nnz, replace=False)
+    rows, cols = keys // N, keys % N
+    pu, qi = rng.normal(0, 1, (U, 4)), rng.normal(0, 1, (N, 4))
+    ratings = np.clip(np.round(3 + (pu[rows] * qi[cols]).sum(1)), 1, 5)
+    data = ExplicitInteractions(users=rows, items=cols, ratings=ratings, num_users=U, num_items=N,
+                                allow_missing_ids=True)
+    loader = DeviceInteractionsDataLoader(data, batch_size=2048, shuffle=True, device='cuda:0')
+    torch.manual_seed(0)
+    model = MatrixFactorizationModel(train=loader, embedding_dim=8, lr=5e-2, loss='mse',
+                                     sparse=True, optimizer='sparse_adam', y_range=(1.0, 5.0))
+    trainer = CollieMinimalTrainer(model, max_epochs=1, gpus=1, verbosity=0, logger=None,
+                                   early_stopping_patience=None)
+    trainer.fit(model)
+    with torch.no_grad():
+        first = float(np.mean([model.calculate_loss(b).item() for b in loader]))
+    trainer.max_epochs = 15
+    trainer.fit(model)
+    with torch.no_grad():
+        last = float(np.mean([model.calculate_loss(b).item() for b in loader]))
+    assert last < 0.6 * first

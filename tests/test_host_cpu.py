@@ -286,3 +286,22 @@ def test_minimal_trainer_control_flow(capsys):
     assert log.calls[0] == 'hp' and log.calls[-1] == 'FINISHED'
     assert (('train_loss_epoch',), 1) in log.calls and (('train_loss_step',), 2) in log.calls
     assert t2.max_epochs == 2
+
+
+def test_explicit_interactions_batch_format_matches_reference():
+    """datasets.py:448-562: non-nested (users, items, ratings) batches, no num_negative_samples."""
+    import numpy as np
+    import pytest
+    from collie_amd.interactions import ExplicitInteractions, InteractionsDataLoader
+    with pytest.raises(ValueError):
+        ExplicitInteractions(users=[0, 1], items=[0, 1])
+    e = ExplicitInteractions(users=[0, 1, 2, 2, 2], items=[1, 0, 2, 1, 1], ratings=[5, 3, 1, 4, 2])
+    assert e.num_interactions == 4 and (e.num_users, e.num_items) == (3, 3)   # duplicate removed
+    assert (e.min_rating, e.max_rating) == (1, 5)
+    with pytest.raises(AttributeError):
+        e.num_negative_samples
+    loader = InteractionsDataLoader(e, batch_size=3)
+    assert not hasattr(loader, 'num_negative_samples')
+    batches = list(loader)
+    assert [len(b) for b in batches] == [3, 3] and batches[0][0].dtype.is_floating_point is False
+    np.testing.assert_array_equal(np.concatenate([b[2].numpy() for b in batches]), [5, 3, 1, 4])
