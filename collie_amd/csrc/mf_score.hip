@@ -242,6 +242,35 @@ int64_t loss_blocks(int64_t batch) {
   return blocks;
 }
 
+
+// cosine similarity of every row of one embedding table with row `id`
+// (base_pipeline.py:854-864: rows divided by their L2 norm, then one matmul row):
+//   out[j] = sum_d (E[j,d] / |E[j]|) * (E[id,d] / |E[id]|)
+// 16 lanes per row: squared-norm and dot in one pass over the row, fixed butterflies.
+__global__ __launch_bounds__(kBlock) void similarity_kernel(const float* __restrict__ emb,
+                                                            int64_t rows, int dim, int64_t id,
+                                                            float* __restrict__ out) {
+  constexpr int LPR = 16;
+  const int lig = lane_id() % LPR;
+  const float* ref = emb + id * dim;
+  float rn = 0.0f;
+  for (int d = lig; d < dim; d += LPR) rn = fmaf(ref[d], ref[d], rn);
+  rn = sqrtf(group_sum<LPR>(rn));
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * (kBlock / LPR);
+  for (int64_t j = static_cast<int64_t>(blockIdx.x) * (kBlock / LPR) + threadIdx.x / LPR;
+       j < rows + (kBlock / LPR); j += stride) {  // whole wave stays in step for the butterflies
+    const bool on = j < rows;
+    const float* row = emb + (on ? j : 0) * dim;
+    float n2 = 0.0f;
+    for (int d = lig; d < dim; d += LPR) n2 = fmaf(row[d], row[d], n2);
+    const float nj = sqrtf(group_sum<LPR>(n2));
+    float dot = 0.0f;
+    for (int d = lig; d < dim; d += LPR) dot = fmaf(row[d] / nj, ref[d] / rn, dot);
+    dot = group_sum<LPR>(dot);
+    if (on && lig == 0) out[j] = dot;
+  }
+}
+
 }  // namespace
 }  // namespace collie
 
@@ -337,4 +366,18 @@ extern "C" int collie_loss_forward_backward(const collie_loss_cfg* cfg, const fl
   hipLaunchKernelGGL(loss_finalize2_kernel, dim3(1), dim3(kWave), 0, stream, partials,
                      static_cast<int>(blocks), p.inv_b, loss_out);
   return check_launch("loss_finalize2_kernel");
+}
+
+extern "C" int collie_embedding_similarity(const float* emb, int64_t rows, int32_t dim, int64_t id,
+                                           float* out, collie_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  COLLIE_REQUIRE(emb && out, "embedding_similarity: NULL pointer");
+  COLLIE_REQUIRE(rows >= 1 && dim >= 1, "embedding_similarity: empty table");
+  COLLIE_REQUIRE(id >= 0 && id < rows, "embedding_similarity: id %lld is not in the table",
+                 static_cast<long long>(id));
+  int64_t blocks = (rows + (kBlock / 16) - 1) / (kBlock / 16);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(similarity_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0,
+                     stream, emb, rows, dim, id, out);
+  return check_launch("similarity_kernel");
 }

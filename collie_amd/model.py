@@ -564,3 +564,46 @@ class MatrixFactorizationModel(nn.Module):
                 drop = np.concatenate([drop, self.val_loader.mat.tocsr()[user_id, :].nonzero()[1]])
             return preds.drop(drop)
         return preds
+
+    def get_user_predictions(self, item_id: int = 0, unseen_users_only: bool = False,
+                             sort_values: bool = True):
+        """``base_pipeline.py:720-783``."""
+        import pandas as pd
+        if item_id >= self.hparams.num_items:
+            raise ValueError(f'``item_id`` {item_id} is not in the model. Expected ID between '
+                             f'``0`` and ``self.hparams.num_items - 1`` '
+                             f'(``{self.hparams.num_items - 1}``), not ``{item_id}``')
+        item = torch.full((self.hparams.num_users,), item_id, dtype=torch.long, device=self.device)
+        user = torch.arange(self.hparams.num_users, dtype=torch.long, device=self.device)
+        with torch.no_grad():
+            preds = pd.Series(self(user, item).detach().cpu().numpy())
+        if sort_values:
+            preds = preds.sort_values(ascending=False)
+        if unseen_users_only:
+            drop = self.train_loader.mat.tocsc()[:, item_id].nonzero()[0]
+            if self.val_loader is not None:
+                drop = np.concatenate([drop, self.val_loader.mat.tocsc()[:, item_id].nonzero()[0]])
+            return preds.drop(drop)
+        return preds
+
+    def item_item_similarity(self, item_id: int):
+        """``base_pipeline.py:785-817``: cosine similarity of every item with ``item_id``."""
+        if item_id >= self.hparams.num_items:
+            raise ValueError(f'``item_id`` {item_id} is not in the model. Expected ID between '
+                             f'``0`` and ``self.hparams.num_items - 1`` '
+                             f'(``{self.hparams.num_items - 1}``), not ``{item_id}``')
+        return self._calculate_embedding_similarity(self._get_item_embeddings(), item_id)
+
+    def user_user_similarity(self, user_id: int):
+        """``base_pipeline.py:819-852``."""
+        if user_id >= self.hparams.num_users:
+            raise ValueError(f'``user_id`` {user_id} is not in the model. Expected ID between '
+                             f'``0`` and ``self.hparams.num_users - 1`` '
+                             f'(``{self.hparams.num_users - 1}``), not ``{user_id}``')
+        return self._calculate_embedding_similarity(self._get_user_embeddings(), user_id)
+
+    def _calculate_embedding_similarity(self, embeddings: torch.Tensor, id: int):
+        """``base_pipeline.py:854-864`` as one HIP kernel (``collie_embedding_similarity``)."""
+        import pandas as pd
+        sims = ops.embedding_similarity(embeddings, id)
+        return pd.Series(sims.cpu().numpy()).sort_values(ascending=False)

@@ -231,6 +231,16 @@ def mf_score_backward(tables, users, items, grad_out, y_range=None, status=None)
     return gu, gi, gb
 
 
+def embedding_similarity(emb, idx):
+    """Cosine similarity of every row of ``emb`` with row ``idx`` (``collie_embedding_similarity``)."""
+    require_hip(emb, 'embeddings')
+    emb = emb.contiguous().float()
+    out = torch.empty(emb.shape[0], dtype=torch.float32, device=emb.device)
+    check(load().collie_embedding_similarity(ptr(emb), emb.shape[0], emb.shape[1], int(idx), ptr(out),
+                                             stream_ptr()), 'collie_embedding_similarity')
+    return out
+
+
 def loss_forward_backward(loss_cfg, s_pos, s_neg_KB, pos_items=None, neg_items_KB=None,
                           want_grad=True):
     """Stand-alone loss on score tensors.  s_neg_KB is [K, B].  Returns (loss[1], g_pos, g_neg)."""

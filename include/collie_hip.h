@@ -313,6 +313,11 @@ int collie_mf_eval_metrics(const int64_t* topk_ids, int32_t k, int64_t n_users, 
                            const uint64_t* counts, int32_t has_y_range, float y_lo, float y_hi,
                            double* ap, float* rr, double* auc, collie_stream_t stream);
 
+/* item_item_similarity / user_user_similarity (base_pipeline.py:785-864): cosine similarity of every
+ * row of one embedding table [rows, dim] with row `id`; out [rows]. */
+int collie_embedding_similarity(const float* emb, int64_t rows, int32_t dim, int64_t id, float* out,
+                                collie_stream_t stream);
+
 /* ---- explicit feedback ----------------------------------------------------
  * Replaces the explicit branch of BasePipeline.calculate_loss (base_pipeline.py:635-650):
  * preds = forward(users, items) (matrix_factorization.py:143-157, y_range sigmoid rescale

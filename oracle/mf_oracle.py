@@ -342,6 +342,13 @@ class TrainState:
 # --------------------------------------------------------------------------------------------
 # A13-A17  evaluation  (collie/metrics.py)
 # --------------------------------------------------------------------------------------------
+def embedding_similarity(embeddings, idx):
+    """base_pipeline.py:854-864: rows / L2 norm, then the matmul row of ``idx`` (fp32)."""
+    e = np.asarray(embeddings, np.float32)
+    e = e / np.sqrt((e * e).sum(1, dtype=np.float32))[:, None]
+    return (e[[idx], :] @ e.T).squeeze().astype(np.float32)
+
+
 def get_preds(tables, user_ids, n_items, y_range=None):
     """metrics.py:20-107: every (user, item) pair through ``forward``; [Bu, N]."""
     user_ids = np.asarray(user_ids).astype(np.int64)

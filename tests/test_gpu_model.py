@@ -316,3 +316,40 @@ def test_explicit_loader_and_trainer_end_to_end():
     with torch.no_grad():
         last = float(np.mean([model.calculate_loss(b).item() for b in loader]))
     assert last < 0.6 * first
+
+
+def test_similarity_and_user_predictions_vs_oracle():
+    """item_item_similarity / user_user_similarity / get_user_predictions
+    (base_pipeline.py:720-864) against the numpy restatement."""
+    from oracle import mf_oracle as O
+    from collie_amd.model import MatrixFactorizationModel
+    dev = torch.device('cuda:0')
+
+    class S:
+        num_users, num_items, num_negative_samples = 321, 123, 5
+
+    for D in (7, 30, 64):
+        torch.manual_seed(D)
+        model = MatrixFactorizationModel(train=S(), embedding_dim=D, lr_scheduler_func=None)
+        with torch.no_grad():
+            model.user_biases.weight.normal_(0, 0.1)
+            model.item_biases.weight.normal_(0, 0.1)
+        tables = {n: getattr(model, n).weight.detach().numpy().copy()
+                  for n in ('user_embeddings', 'item_embeddings', 'user_biases', 'item_biases')}
+        model.to(dev).eval()
+        for item in (0, 57, 122):
+            got = model.item_item_similarity(item)
+            want = O.embedding_similarity(tables['item_embeddings'], item)
+            assert got.index[0] == item                       # base_pipeline.py:799-801
+            np.testing.assert_allclose(got.sort_index().values, want, rtol=1e-5, atol=1e-6)
+        got = model.user_user_similarity(300)
+        np.testing.assert_allclose(got.sort_index().values,
+                                   O.embedding_similarity(tables['user_embeddings'], 300),
+                                   rtol=1e-5, atol=1e-6)
+        preds = model.get_user_predictions(item_id=5, sort_values=False)
+        want = O.mf_forward(tables, np.arange(321), np.full(321, 5))
+        np.testing.assert_allclose(preds.values, want, rtol=1e-5, atol=1e-6)
+        with pytest.raises(ValueError):
+            model.item_item_similarity(123)
+        with pytest.raises(ValueError):
+            model.get_user_predictions(item_id=123)
