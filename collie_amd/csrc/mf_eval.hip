@@ -421,9 +421,15 @@ __global__ __launch_bounds__(kBlockDma) void eval_gemm_dma_kernel(const EvalPara
       const int r = sub * 32 + col;
       const float4* arow = tile + r * CPR;
       const int sw = r & (S - 1);
+      // A fragments are fetched two steps ahead of the MFMAs that consume them (an LDS read is
+      // ~2 MFMAs long; read-then-use in the same step stalls the chain on every fragment)
+      float4 a0 = arow[(0 + h) ^ sw];
+      float4 a1 = arow[((D8 > 1 ? 2 : 0) + h) ^ sw];
 #pragma unroll
       for (int q = 0; q < D8; ++q) {
-        const float4 a = arow[(2 * q + h) ^ sw];
+        const float4 a = a0;
+        a0 = a1;
+        if (q + 2 < D8) a1 = arow[(2 * (q + 2) + h) ^ sw];
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, ufrag[q][0], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, ufrag[q][1], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, ufrag[q][2], acc, 0, 0, 0);
