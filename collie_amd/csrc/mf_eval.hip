@@ -487,6 +487,9 @@ __global__ __launch_bounds__(kBlockDma) void eval_gemm_dma_kernel(const EvalPara
         else if (n_thr <= 8) rank_subtile<8>(acc, top_s, top_i, bscore, bid, gid0, p.id_stride, t_above, t_lt, t_le);
         else if (n_thr <= 12) rank_subtile<12>(acc, top_s, top_i, bscore, bid, gid0, p.id_stride, t_above, t_lt, t_le);
         else rank_subtile<kCap>(acc, top_s, top_i, bscore, bid, gid0, p.id_stride, t_above, t_lt, t_le);
+        // the sub-tile counts stay 32-bit (without this the compiler accumulates every compare
+        // straight into the 64-bit counters: a v_lshl_add_u64 per compare)
+        asm volatile("" : "+v"(t_above), "+v"(t_lt), "+v"(t_le));
         c_above += t_above;
         c_lt += t_lt;
         c_le += t_le;
