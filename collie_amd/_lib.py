@@ -53,6 +53,18 @@ class OptimCfg(ctypes.Structure):
                 ('lr_decay', c_float)]
 
 
+DENSE_MAX_SEGS = 4
+
+
+class DenseSeg(ctypes.Structure):
+    _fields_ = [('src', c_void_p), ('idx', c_void_p), ('act_ref', c_void_p), ('ld', c_int64),
+                ('act_ld', c_int64), ('rows', c_int64), ('idx_dtype', c_int32), ('width', c_int32)]
+
+
+class DenseOperand(ctypes.Structure):
+    _fields_ = [('n_seg', c_int32), ('seg', DenseSeg * DENSE_MAX_SEGS)]
+
+
 # name -> (restype, argtypes): exactly the symbols include/collie_hip.h declares
 SIGNATURES = {
     'collie_last_error': (c_char_p, []),
@@ -118,6 +130,21 @@ SIGNATURES = {
     'collie_mf_eval_metrics': (ctypes.c_int, [c_void_p, c_int32, c_int64, c_int64, c_void_p,
                                               c_void_p, c_void_p, c_void_p, c_int32, c_float,
                                               c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'collie_dense_forward': (ctypes.c_int, [POINTER(DenseOperand), c_int64, c_void_p, c_int64,
+                                            c_int64, c_void_p, c_int32, c_int32, c_int32, c_float,
+                                            c_void_p, c_int32, c_void_p, c_int64, c_void_p, c_int32,
+                                            c_void_p, c_int64, c_void_p, c_int64, c_void_p,
+                                            c_void_p]),
+    'collie_dense_weight_grad_workspace_bytes': (c_size_t, [c_int64, c_int32, c_int32]),
+    'collie_dense_weight_grad': (ctypes.c_int, [POINTER(DenseOperand), POINTER(DenseOperand),
+                                                c_int64, c_int32, c_int32, c_float, c_void_p,
+                                                c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
+    'collie_dense_optim_step': (ctypes.c_int, [c_void_p, c_void_p, c_int64, POINTER(OptimCfg),
+                                               c_void_p, c_void_p, c_void_p, c_void_p]),
+    'collie_dense_rows_update': (ctypes.c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int32,
+                                                c_void_p, c_int64, POINTER(OptimCfg), c_void_p,
+                                                c_void_p, c_void_p, c_void_p, c_size_t, c_void_p,
+                                                c_void_p]),
 }
 
 _lib = None

@@ -877,3 +877,103 @@ extern "C" int collie_sparse_rows_update(float* table, int64_t num_rows, int32_t
   }
   return launch_emb<false>(p, m, stream);
 }
+
+// ---- dense-gradient variants (hybrid head) -----------------------------------
+namespace collie {
+namespace {
+
+// torch.optim.{Adam,SGD,Adagrad}.step on one dense parameter with a dense gradient (the Linear
+// weights and biases of the head): one element per thread, torch's formula (apply_update).
+__global__ __launch_bounds__(kBlock) void flat_update_kernel(float* __restrict__ param,
+                                                             const float* __restrict__ grad,
+                                                             float* __restrict__ s1p,
+                                                             float* __restrict__ s2p, int64_t n,
+                                                             const float* __restrict__ grad_scale,
+                                                             const Hyper h) {
+  const float scale = grad_scale ? *grad_scale : 1.0f;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) {
+    float s1 = s1p ? s1p[i] : 0.0f;
+    float s2 = s2p ? s2p[i] : 0.0f;
+    param[i] = apply_update(h, param[i], grad[i] * scale, s1, s2);
+    if (s1p) s1p[i] = s1;
+    if (s2p) s2p[i] = s2;
+  }
+}
+
+}  // namespace
+}  // namespace collie
+
+extern "C" int collie_dense_optim_step(float* param, const float* grad, int64_t n,
+                                       const collie_optim_cfg* cfg, float* state1, float* state2,
+                                       const float* grad_scale, collie_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  COLLIE_REQUIRE(param && grad && cfg && n >= 1, "dense_optim_step: NULL pointer / empty tensor");
+  COLLIE_REQUIRE(cfg->algo != COLLIE_OPT_SPARSE_ADAM,
+                 "SparseAdam does not support dense gradients, please consider Adam instead");
+  Hyper h;
+  float* s1 = cfg->algo == COLLIE_OPT_SGD ? nullptr : state1;
+  float* s2 = cfg->algo == COLLIE_OPT_ADAM ? state2 : nullptr;
+  if (make_hyper(h, cfg, 1, true, s1, s2)) return -1;
+  hipLaunchKernelGGL(flat_update_kernel, dim3(sweep_grid(n)), dim3(kBlock), 0, stream, param, grad,
+                     s1, s2, n, grad_scale, h);
+  return check_launch("flat_update_kernel");
+}
+
+extern "C" int collie_dense_rows_update(float* table, int64_t num_rows, int32_t dim,
+                                        const void* rows, int32_t rows_dtype, const float* vals,
+                                        int64_t m, const collie_optim_cfg* cfg, float* state1,
+                                        float* state2, int32_t* row_stamp, void* workspace,
+                                        size_t workspace_bytes, int32_t* status,
+                                        collie_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  COLLIE_REQUIRE(table && rows && vals && cfg, "dense_rows_update: NULL pointer");
+  COLLIE_REQUIRE(num_rows >= 1 && num_rows < (int64_t{1} << 31) && dim >= 1,
+                 "dense_rows_update: bad table shape");
+  COLLIE_REQUIRE(m >= 1 && m < (int64_t{1} << 30), "dense_rows_update: bad entry count");
+  COLLIE_REQUIRE(cfg->algo != COLLIE_OPT_SPARSE_ADAM,
+                 "SparseAdam does not support dense gradients, please consider Adam instead");
+  Carver c(workspace);
+  SortWs s;
+  carve_sort_ws(c, s, m, dim);
+  COLLIE_REQUIRE(workspace && workspace_bytes >= align_up(c.off, 256),
+                 "workspace too small: need %zu bytes, got %zu", align_up(c.off, 256),
+                 workspace_bytes);
+  hipLaunchKernelGGL(coo_entries_kernel, dim3(static_cast<unsigned>((m + kBlock - 1) / kBlock)),
+                     dim3(kBlock), 0, stream, rows, rows_dtype, m, num_rows, s.ekeys, s.ecodes,
+                     status);
+  if (check_launch("coo_entries_kernel")) return -2;
+  if (sort_and_segment(s, num_rows, 0xffffffffu, stream)) return -1;
+  UpdParams p;
+  memset(&p, 0, sizeof(p));
+  fill_sorted(p, s, num_rows, 0xffffffffu);
+  p.D = dim;
+  p.step = cfg->step;
+  TableDesc& d = p.d[0];
+  d.table = table;
+  d.stage = vals;
+  d.s1 = cfg->algo == COLLIE_OPT_SGD ? nullptr : state1;
+  d.s2 = cfg->algo == COLLIE_OPT_ADAM ? state2 : nullptr;
+  if (make_hyper(d.h, cfg, 1, true, d.s1, d.s2)) return -1;
+  // rows without an entry still move under Adam (moment decay) and under weight decay
+  const bool sweep = cfg->algo == COLLIE_OPT_ADAM || cfg->weight_decay != 0.0f;
+  if (sweep) {
+    COLLIE_REQUIRE(row_stamp != nullptr,
+                   "dense Adam / weight decay need row_stamp = int32[rows] scratch");
+    d.row_stamp = row_stamp;
+  }
+  if (dim == 1) {
+    hipLaunchKernelGGL(piece_bias_kernel<false>, dim3(piece_bias_grid(m)), dim3(kBlock), 0, stream,
+                       p);
+    hipLaunchKernelGGL(bias_rows_kernel<false>, dim3(bias_grid(m)), dim3(kBlock), 0, stream, p);
+    if (check_launch("dense_rows_update")) return -2;
+  } else if (launch_emb<false>(p, m, stream)) {
+    return -2;
+  }
+  if (sweep) {
+    hipLaunchKernelGGL(dense_sweep_kernel, dim3(sweep_grid(num_rows * dim)), dim3(kBlock), 0, stream,
+                       d.table, d.s1, d.s2, d.row_stamp, num_rows, dim, p.step, d.h);
+    if (check_launch("dense_sweep_kernel")) return -2;
+  }
+  return 0;
+}

@@ -1,0 +1,502 @@
+"""
+``HybridPretrainedModel`` — host-side mirror of the reference's
+``collie/model/hybrid_pretrained_matrix_factorization.py`` (BASELINE
+configs[4]): the four tables of a trained ``MatrixFactorizationModel`` are copied (embeddings
+optionally frozen), item and/or user metadata rows go through ``Linear + LeakyReLU`` layers, the
+concatenation ``[user_meta_out, U[u], I[i], item_meta_out]`` goes through ``Linear + LeakyReLU``
+layers and a final ``Linear(.., 1)``, and both bias-table rows are added.
+
+Same constructor arguments, module / parameter names (``embeddings.0.weight`` ...
+``combined_layer_3.bias``), ``save_model`` directory layout and errors as the reference.  All
+arithmetic runs in ``libcollie_hip.so``: every layer, forward and backward, is an exact-fp32 MFMA
+GEMM (``collie_dense_forward`` / ``collie_dense_weight_grad``) whose operand gathers the embedding /
+metadata rows on the fly (the ``torch.cat`` input is never materialised), and the optimizers are
+the ``collie_dense_optim_step`` / ``collie_dense_rows_update`` kernels.  There is no CPU fallback.
+"""
+import copy
+import os
+import warnings
+from collections import OrderedDict
+from functools import partial
+from pathlib import Path
+from typing import Callable, Dict, List, Optional, Union
+
+import numpy as np
+import torch
+from torch import nn
+from torch.optim.lr_scheduler import ReduceLROnPlateau
+
+from collie_amd import _lib, ops
+from collie_amd.layers import ScaledEmbedding, ZeroEmbedding
+from collie_amd.model import INTERACTIONS_LIKE_INPUT, MatrixFactorizationModel
+from collie_amd.optim import FusedAdagrad, FusedAdam, FusedSGD
+
+
+class _HeadScore(torch.autograd.Function):
+    """``HybridPretrainedModel.forward`` over M (user, item) pairs; ``params`` only tell autograd
+    which leaves the result depends on (their gradients come out of ``model._head_backward``)."""
+
+    @staticmethod
+    def forward(ctx, model, users, items, *params):
+        scores, saved = model._head_forward(users, items)
+        ctx.model, ctx.users, ctx.items, ctx.saved = model, users, items, saved
+        ctx.n_params = len(params)
+        return scores
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        grads = ctx.model._head_backward(ctx.users, ctx.items, ctx.saved,
+                                         grad_out.contiguous().float())
+        return (None, None, None) + tuple(grads)
+
+
+class _HeadMixin:
+    """``step()`` for the optimizers of the hybrid model: dense parameters with ``.grad`` go
+    through ``collie_dense_optim_step``; tables whose gradient the backward staged as an
+    uncoalesced COO list go through ``collie_dense_rows_update``."""
+
+    def zero_grad(self, set_to_none: bool = True):
+        model = getattr(self, '_collie_model', None)
+        if model is not None:
+            model._staged_rows.clear()
+        return torch.optim.Optimizer.zero_grad(self, set_to_none=set_to_none)
+
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        model = self._collie_model
+        for group in self.param_groups:
+            for p in group['params']:
+                staged = model._staged_rows.pop(id(p), None)
+                if staged is None and p.grad is None:
+                    continue
+                cfg, s1, s2, stamp = self._table_args(model, p, group, True)
+                if staged is not None:
+                    rows, vals = staged
+                    model._rows_ws = ops.dense_rows_update(
+                        p.data, rows, vals, cfg, s1, s2, stamp, model._status_flag(),
+                        model._rows_ws)
+                else:
+                    grad = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                    ops.dense_optim_step(p.data, grad, cfg, s1, s2)
+        return loss
+
+
+class HeadAdam(_HeadMixin, FusedAdam):
+    pass
+
+
+class HeadSGD(_HeadMixin, FusedSGD):
+    pass
+
+
+class HeadAdagrad(_HeadMixin, FusedAdagrad):
+    pass
+
+
+HEAD_OPTIMIZERS = {'adam': HeadAdam, 'sgd': HeadSGD, 'adagrad': HeadAdagrad}
+
+
+class HybridPretrainedModel(MatrixFactorizationModel):
+    """
+    Parameters are those of the reference (``hybrid_pretrained_matrix_factorization.py:102-126``):
+    ``train, val, item_metadata, user_metadata, trained_model, item_metadata_layers_dims,
+    user_metadata_layers_dims, combined_layers_dims=[128, 64, 32], freeze_embeddings=True,
+    dropout_p=0.0, lr=1e-3, lr_scheduler_func, weight_decay=0.0, optimizer='adam', loss='hinge',
+    metadata_for_loss, metadata_for_loss_weights, load_model_path, map_location``.
+    """
+    _mf_eval_fast = False       # evaluation goes through get_preds (the score is not a dot product)
+
+    def __init__(self,
+                 train: INTERACTIONS_LIKE_INPUT = None,
+                 val: INTERACTIONS_LIKE_INPUT = None,
+                 item_metadata=None,
+                 user_metadata=None,
+                 trained_model: MatrixFactorizationModel = None,
+                 item_metadata_layers_dims: Optional[List[int]] = None,
+                 user_metadata_layers_dims: Optional[List[int]] = None,
+                 combined_layers_dims: List[int] = [128, 64, 32],
+                 freeze_embeddings: bool = True,
+                 dropout_p: float = 0.0,
+                 lr: float = 1e-3,
+                 lr_scheduler_func: Optional[Callable] = partial(ReduceLROnPlateau, patience=1),
+                 weight_decay: float = 0.0,
+                 optimizer: Union[str, Callable] = 'adam',
+                 loss: Union[str, Callable[..., torch.Tensor]] = 'hinge',
+                 metadata_for_loss: Optional[Dict[str, torch.Tensor]] = None,
+                 metadata_for_loss_weights: Optional[Dict[str, float]] = None,
+                 load_model_path: Optional[str] = None,
+                 map_location: Optional[str] = None):
+        item_cols = user_cols = None
+        if load_model_path is None:
+            if trained_model is None:
+                raise ValueError('Must provide ``trained_model`` for ``HybridPretrainedModel``.')
+            if item_metadata is None and user_metadata is None:
+                raise ValueError('Must provide item metadata and/or user_metadata for '
+                                 '``HybridPretrainedModel``.')
+            item_metadata = self._as_float_tensor(item_metadata)
+            user_metadata = self._as_float_tensor(user_metadata)
+            item_cols = item_metadata.shape[1] if item_metadata is not None else None
+            user_cols = user_metadata.shape[1] if user_metadata is not None else None
+        self._pending = dict(
+            item_metadata=item_metadata, user_metadata=user_metadata, trained_model=trained_model,
+            hp=dict(item_metadata_layers_dims=item_metadata_layers_dims,
+                    user_metadata_layers_dims=user_metadata_layers_dims,
+                    combined_layers_dims=list(combined_layers_dims),
+                    freeze_embeddings=freeze_embeddings, item_metadata_num_cols=item_cols,
+                    user_metadata_num_cols=user_cols))
+        self.item_metadata = None
+        self.user_metadata = None
+        self._staged_rows = {}
+        self._rows_ws = None
+        self._wgrad_ws = None
+        self._materialize_table_grads = False
+        super().__init__(train=train, val=val, embedding_dim=0, dropout_p=dropout_p, sparse=False,
+                         lr=lr, bias_lr=None, lr_scheduler_func=lr_scheduler_func,
+                         weight_decay=weight_decay, optimizer=optimizer, bias_optimizer=None,
+                         loss=loss, metadata_for_loss=metadata_for_loss,
+                         metadata_for_loss_weights=metadata_for_loss_weights, y_range=None,
+                         load_model_path=load_model_path, map_location=map_location)
+
+    @staticmethod
+    def _as_float_tensor(metadata):
+        """``hybrid_pretrained_matrix_factorization.py:138-152``."""
+        if metadata is None:
+            return None
+        if hasattr(metadata, 'to_numpy'):
+            metadata = torch.from_numpy(metadata.to_numpy())
+        elif isinstance(metadata, np.ndarray):
+            metadata = torch.from_numpy(metadata)
+        return metadata.float()
+
+    # ---------------------------------------------------------------- construction / persistence
+    def _setup_model(self, **kwargs) -> None:
+        """``hybrid_pretrained_matrix_factorization.py:227-325``: same modules, names and init."""
+        hp = self.hparams
+        pending = getattr(self, '_pending', None)
+        if pending is not None and hp.get('load_model_path') is None:
+            hp.update(pending['hp'])
+            trained = pending['trained_model']
+            self.__dict__['_trained_model'] = trained     # not registered as a sub-module
+            self.item_metadata = pending['item_metadata']
+            self.user_metadata = pending['user_metadata']
+            self.embeddings = nn.Sequential(copy.deepcopy(trained.user_embeddings),
+                                            copy.deepcopy(trained.item_embeddings))
+            self.biases = nn.Sequential(copy.deepcopy(trained.user_biases),
+                                        copy.deepcopy(trained.item_biases))
+            if hp.freeze_embeddings:
+                self.freeze_embeddings()
+            else:
+                self.unfreeze_embeddings()
+            hp.user_num_embeddings = self.embeddings[0].num_embeddings
+            hp.user_embeddings_dim = self.embeddings[0].embedding_dim
+            hp.item_num_embeddings = self.embeddings[1].num_embeddings
+            hp.item_embeddings_dim = self.embeddings[1].embedding_dim
+            hp.embedding_dim = hp.user_embeddings_dim
+        else:
+            self.embeddings = nn.Sequential(
+                ScaledEmbedding(hp.user_num_embeddings, hp.user_embeddings_dim),
+                ScaledEmbedding(hp.item_num_embeddings, hp.item_embeddings_dim))
+            self.biases = nn.Sequential(ZeroEmbedding(hp.user_num_embeddings, 1),
+                                        ZeroEmbedding(hp.item_num_embeddings, 1))
+        self._pending = None
+        self.dropout = nn.Dropout(p=hp.dropout_p)
+
+        item_out = hp.item_metadata_num_cols
+        self.item_metadata_layers = None
+        if hp.item_metadata_layers_dims is not None:
+            self._configure_metadata_layers('item', hp.item_metadata_layers_dims,
+                                            hp.item_metadata_num_cols)
+            item_out = hp.item_metadata_layers_dims[-1]
+        user_out = hp.user_metadata_num_cols
+        self.user_metadata_layers = None
+        if hp.user_metadata_layers_dims is not None:
+            self._configure_metadata_layers('user', hp.user_metadata_layers_dims,
+                                            hp.user_metadata_num_cols)
+            user_out = hp.user_metadata_layers_dims[-1]
+
+        combined_in = hp.user_embeddings_dim + hp.item_embeddings_dim
+        combined_in += (item_out or 0) + (user_out or 0)
+        dims = [combined_in] + list(hp.combined_layers_dims) + [1]
+        self.combined_layers = [nn.Linear(dims[i - 1], dims[i]) for i in range(1, len(dims))]
+        for i, layer in enumerate(self.combined_layers):
+            nn.init.xavier_normal_(layer.weight)
+            self.add_module('combined_layer_{}'.format(i), layer)
+
+    def _configure_metadata_layers(self, metadata_type, layers_dims, num_cols) -> None:
+        """``hybrid_pretrained_matrix_factorization.py:188-225``."""
+        full = [num_cols] + list(layers_dims)
+        layers = [nn.Linear(full[i - 1], full[i]) for i in range(1, len(full))]
+        setattr(self, f'{metadata_type}_metadata_layers', layers)
+        for i, layer in enumerate(layers):
+            nn.init.xavier_normal_(layer.weight)
+            self.add_module(f'{metadata_type}_metadata_layer_{i}', layer)
+
+    def __setattr__(self, name, value):
+        # the layer LISTS are plain attributes in the reference too (the modules are registered
+        # one by one through add_module)
+        if name in ('item_metadata_layers', 'user_metadata_layers', 'combined_layers',
+                    'item_metadata', 'user_metadata'):
+            object.__setattr__(self, name, value)
+        else:
+            super().__setattr__(name, value)
+
+    def _load_model_init_helper(self, load_model_path, map_location) -> None:
+        """``hybrid_pretrained_matrix_factorization.py:168-186``: a directory written by ``save_model``."""
+        import joblib
+        super()._load_model_init_helper(os.path.join(str(load_model_path), 'model.pth'),
+                                        map_location)
+        self.hparams['load_model_path'] = load_model_path
+        for kind in ('item', 'user'):
+            try:
+                setattr(self, f'{kind}_metadata',
+                        joblib.load(os.path.join(str(load_model_path), f'{kind}_metadata.pkl')))
+            except FileNotFoundError:
+                if self.hparams.get(f'{kind}_metadata_layers_dims') is not None:
+                    warnings.warn(f'``{kind}_metadata.pkl`` not found')
+
+    def save_model(self, path='model', overwrite: bool = False) -> None:
+        """``hybrid_pretrained_matrix_factorization.py:486-534``."""
+        import joblib
+        path = str(path)
+        if os.path.exists(path):
+            if os.listdir(path) and overwrite is False:
+                raise ValueError(f'Data exists in ``path`` at {path} and ``overwrite`` is False.')
+        Path(path).mkdir(parents=True, exist_ok=True)
+        if self.item_metadata is not None:
+            joblib.dump(self.item_metadata.cpu(), os.path.join(path, 'item_metadata.pkl'))
+        if self.user_metadata is not None:
+            joblib.dump(self.user_metadata.cpu(), os.path.join(path, 'user_metadata.pkl'))
+        state = OrderedDict((k, v) for k, v in self.state_dict().items()
+                            if '_trained_model' not in k)
+        hparams = {k: v for k, v in self.hparams.items()}
+        torch.save({'state_dict': state, 'hparams': hparams}, os.path.join(path, 'model.pth'))
+
+    def load_from_hybrid_model(self, hybrid_model) -> None:
+        """``hybrid_pretrained_matrix_factorization.py:536-555``."""
+        for key, value in hybrid_model.hparams.items():
+            self.hparams[key] = value
+        self.hparams['load_model_path'] = 'copied'      # rebuild layers from hparams, not a trained model
+        self._setup_model()
+        self.hparams['load_model_path'] = None
+        self.load_state_dict(state_dict=hybrid_model.state_dict())
+        self.item_metadata = hybrid_model.item_metadata
+        self.user_metadata = hybrid_model.user_metadata
+        self.eval()
+
+    def freeze_embeddings(self) -> None:
+        self.embeddings[0].weight.requires_grad = False
+        self.embeddings[1].weight.requires_grad = False
+
+    def unfreeze_embeddings(self) -> None:
+        self.embeddings[0].weight.requires_grad = True
+        self.embeddings[1].weight.requires_grad = True
+
+    # ----------------------------------------------------------------- LightningModule stand-ins
+    @property
+    def device(self):
+        return self.embeddings[0].weight.device
+
+    def _move_any_external_data_to_device(self):
+        """``hybrid_pretrained_matrix_factorization.py:160-166``."""
+        super()._move_any_external_data_to_device()
+        if self.item_metadata is not None:
+            self.item_metadata = self.item_metadata.to(self.device).contiguous()
+        if self.user_metadata is not None:
+            self.user_metadata = self.user_metadata.to(self.device).contiguous()
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._staged_rows = {}
+        self._rows_ws = None
+        self._wgrad_ws = None
+        return out
+
+    def _get_optimizer(self, optimizer, **kwargs):
+        """``base_pipeline.py:406-437``; string optimizers become the HIP-kernel ones."""
+        if callable(optimizer):
+            self._materialize_table_grads = True
+            return super()._get_optimizer(optimizer, **kwargs)
+        self._materialize_table_grads = False
+        if optimizer == 'sparse_adam':
+            raise RuntimeError('SparseAdam does not support dense gradients, please consider Adam '
+                               'instead')
+        if optimizer not in HEAD_OPTIMIZERS:
+            raise ValueError('{} is not a valid optimizer!'.format(optimizer))
+        params = self._get_optimizer_parameters(include_weight_decay=True, **kwargs)
+        return HEAD_OPTIMIZERS[optimizer](params).attach(self)
+
+    def _drop_staged_step(self):
+        self._staged_rows.clear()
+
+    def _can_fuse(self):
+        return False        # calculate_loss: one head pass over all (1 + K) B pairs, see below
+
+    def _get_item_embeddings(self) -> torch.Tensor:
+        return self.embeddings[1].weight.data
+
+    def _get_user_embeddings(self) -> torch.Tensor:
+        return self.embeddings[0].weight.data
+
+    # ------------------------------------------------------------------------------- arithmetic
+    def forward(self, users: torch.Tensor, items: torch.Tensor) -> torch.Tensor:
+        """``hybrid_pretrained_matrix_factorization.py:401-464``."""
+        if self.training and self.hparams.dropout_p > 0:
+            raise NotImplementedError(
+                'dropout_p > 0 in training mode is not implemented in the HIP path '
+                '(SURVEY.md §7: torch-RNG parity is infeasible); use dropout_p=0.')
+        _lib.require_hip(self.embeddings[0].weight, 'HybridPretrainedModel')
+        _lib.require_hip(users, 'users')
+        _lib.require_hip(items, 'items')
+        if self.item_metadata is not None and not self.item_metadata.is_cuda:
+            self._move_any_external_data_to_device()
+        if self.user_metadata is not None and not self.user_metadata.is_cuda:
+            self._move_any_external_data_to_device()
+        params = [p for p in self.parameters() if p.requires_grad]
+        return _HeadScore.apply(self, users.contiguous(), items.contiguous(), *params).squeeze()
+
+    def calculate_loss(self, batch) -> torch.Tensor:
+        """``base_pipeline.py:582-654``.  The positive and the K B negative pairs go through the
+        head in ONE pass (rows [0, B) = positives, then the negatives k-major, exactly the
+        reference's ``users.repeat(K)`` / ``neg_items.flatten()`` order), so every layer is one
+        GEMM and every weight gradient one deterministic reduction."""
+        if len(batch) == 2 and hasattr(batch[0], '__len__') and len(batch[0]) == 2:
+            if self.hparams.get('_is_implicit') is False:
+                raise ValueError('Explicit loss with implicit data is invalid!')
+            ((users, pos_items), neg_items) = batch
+            if neg_items.dim() == 1:
+                neg_items = neg_items.reshape(-1, 1)
+            users = users.long()
+            pos_items = pos_items.long()
+            neg_items = torch.transpose(neg_items, 0, 1).long()
+            K, B = neg_items.shape
+            all_users = users.repeat(K + 1)
+            all_items = torch.cat([pos_items, neg_items.flatten()])
+            preds = self(all_users, all_items)
+            pos_preds = preds[:B]
+            neg_preds = preds[B:].view(K, B)
+            return self.loss_function(
+                pos_preds, neg_preds, num_items=self.hparams.num_items, positive_items=pos_items,
+                negative_items=neg_items, metadata=self.hparams.get('metadata_for_loss'),
+                metadata_weights=self.hparams.get('metadata_for_loss_weights'))
+        elif len(batch) == 3:
+            if self.hparams.get('_is_implicit') is True:
+                raise ValueError('Implicit loss with explicit data is invalid!')
+            (users, items, ratings) = batch
+            return self.loss_function(self(users.long(), items.long()), ratings.float())
+        raise ValueError(f'Unexpected format for batch: {batch}. See docs for expected format.')
+
+    def _metadata_stack(self, kind, ids, m, saved):
+        """``_compute_metadata_output`` (:327-361): the operand segment this side contributes."""
+        metadata = getattr(self, f'{kind}_metadata')
+        if metadata is None:
+            return None
+        layers = getattr(self, f'{kind}_metadata_layers')
+        seg = (metadata, ids, None)
+        if layers is None:
+            return seg
+        outs = []
+        for layer in layers:
+            x_op = ops.dense_operand(seg)
+            out = ops.dense_forward(x_op, m, layer.weight.data, layer.bias.data, True,
+                                    status=self._status_flag())
+            outs.append((seg, out))
+            seg = (out, None, None)
+        saved[kind] = outs
+        return seg
+
+    def _head_forward(self, users, items):
+        m = users.shape[0]
+        saved = {}
+        user_seg = self._metadata_stack('user', users, m, saved)
+        item_seg = self._metadata_stack('item', items, m, saved)
+        tagged = [('user_meta', user_seg),
+                  ('user_emb', (self.embeddings[0].weight.data, users, None)),
+                  ('item_emb', (self.embeddings[1].weight.data, items, None)),
+                  ('item_meta', item_seg)]
+        tagged = [(tag, seg) for tag, seg in tagged if seg is not None]
+        segs = [seg for _, seg in tagged]
+        saved['segments'] = tagged
+        x_segs = segs
+        outs = []
+        for layer in self.combined_layers[:-1]:
+            out = ops.dense_forward(ops.dense_operand(*x_segs), m, layer.weight.data,
+                                    layer.bias.data, True, status=self._status_flag())
+            outs.append((x_segs, out))
+            x_segs = [(out, None, None)]
+        last = self.combined_layers[-1]
+        scores = ops.dense_forward(
+            ops.dense_operand(*x_segs), m, last.weight.data, last.bias.data, False,
+            row_bias=(users, self.biases[0].weight.data, items, self.biases[1].weight.data),
+            status=self._status_flag())
+        outs.append((x_segs, None))
+        saved['combined'] = outs
+        return scores.reshape(-1), saved
+
+    def _layer_backward(self, layer, x_segs, out, dz, m, grads, need_dx):
+        """Gradients of one ``Linear (+ LeakyReLU)``: parameters into ``grads``; returns the operand
+        ``dz_op`` (dY with the activation backward folded in) for the caller's data backward."""
+        dz_op = ops.dense_operand((dz, None, out))
+        n_out, n_in = layer.weight.shape
+        dw, db, self._wgrad_ws = ops.dense_weight_grad(
+            dz_op, ops.dense_operand(*x_segs), m, n_out, n_in, True, self._wgrad_ws,
+            self._status_flag())
+        grads[id(layer.weight)] = dw
+        grads[id(layer.bias)] = db
+        return dz_op
+
+    def _head_backward(self, users, items, saved, g):
+        m = users.shape[0]
+        grads = {}
+        dz = g.reshape(m, 1)
+        # bias tables (hybrid_pretrained...:394-398): d score / d bias row = 1
+        for table, ids in ((self.biases[0].weight, users), (self.biases[1].weight, items)):
+            if table.requires_grad:
+                self._staged_rows[id(table)] = (ids, g)
+        combined = saved['combined']
+        for li in range(len(combined) - 1, 0, -1):
+            x_segs, out = combined[li]
+            layer = self.combined_layers[li]
+            dz_op = self._layer_backward(layer, x_segs, out, dz, m, grads, True)
+            dz = ops.dense_forward(dz_op, m, layer.weight.data, None, False, transposed=True)
+        x_segs, out = combined[0]
+        layer = self.combined_layers[0]
+        dz_op = self._layer_backward(layer, x_segs, out, dz, m, grads, True)
+        # data backward of the first combined layer, one column slice of W per segment that needs it
+        col = 0
+        for tag, (src, ids, _) in saved['segments']:
+            cols = (col, col + src.shape[1])
+            col += src.shape[1]
+            if tag in ('user_emb', 'item_emb'):
+                table = self.embeddings[0 if tag == 'user_emb' else 1].weight
+                if table.requires_grad:
+                    d_rows = ops.dense_forward(dz_op, m, layer.weight.data, None, False,
+                                               transposed=True, col_range=cols)
+                    self._staged_rows[id(table)] = (ids, d_rows)
+                continue
+            kind = 'user' if tag == 'user_meta' else 'item'
+            if kind not in saved:
+                continue        # raw metadata rows feed the head directly: nothing to train there
+            d_meta = ops.dense_forward(dz_op, m, layer.weight.data, None, False, transposed=True,
+                                       col_range=cols)
+            stack = saved[kind]
+            layers = getattr(self, f'{kind}_metadata_layers')
+            for lj in range(len(stack) - 1, -1, -1):
+                in_seg, out_j = stack[lj]
+                dzj = self._layer_backward(layers[lj], [in_seg], out_j, d_meta, m, grads, lj > 0)
+                if lj > 0:
+                    d_meta = ops.dense_forward(dzj, m, layers[lj].weight.data, None, False,
+                                               transposed=True)
+        if self._materialize_table_grads:
+            # a user-supplied torch optimizer reads ``.grad``: hand the staged rows over as the
+            # dense gradients nn.Embedding(sparse=False) would have produced
+            for table in (self.biases[0].weight, self.biases[1].weight, self.embeddings[0].weight,
+                          self.embeddings[1].weight):
+                staged = self._staged_rows.pop(id(table), None)
+                if staged is not None:
+                    ids, vals = staged
+                    grads[id(table)] = torch.zeros_like(table).index_add_(
+                        0, ids.long(), vals.reshape(ids.shape[0], -1))
+        return [grads.get(id(p)) for p in self.parameters() if p.requires_grad]

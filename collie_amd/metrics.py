@@ -182,7 +182,7 @@ def evaluate_in_batches(
         batch_size = len(test_users)
 
     from collie_amd.model import MatrixFactorizationModel
-    fast = (isinstance(model, MatrixFactorizationModel)
+    fast = (isinstance(model, MatrixFactorizationModel) and model._mf_eval_fast
             and all(m in _FAST for m in metric_list)
             and k <= ops.eval_topk_capacity()
             and model.hparams.embedding_dim <= 256)

@@ -134,6 +134,7 @@ class MatrixFactorizationModel(nn.Module):
     bias_optimizer='sgd', loss='hinge', metadata_for_loss=None, metadata_for_loss_weights=None,
     y_range=None, load_model_path=None, map_location=None``.
     """
+    _mf_eval_fast = True        # evaluate_in_batches may use the fused MFMA scoring kernels
 
     def __init__(self,
                  train: INTERACTIONS_LIKE_INPUT = None,

@@ -8,8 +8,8 @@ from ctypes import byref, c_void_p
 import torch
 
 from collie_amd import _lib
-from collie_amd._lib import (Batch, LossCfg, OptimCfg, check, idx_dtype, load, make_tables, ptr,
-                             require_hip, stream_ptr)
+from collie_amd._lib import (Batch, DenseOperand, LossCfg, OptimCfg, check, idx_dtype, load,
+                             make_tables, ptr, require_hip, stream_ptr)
 
 
 def make_batch(users, pos_items, neg_items):
@@ -264,6 +264,122 @@ def loss_forward_backward(loss_cfg, s_pos, s_neg_KB, pos_items=None, neg_items_K
     return loss, g_pos, g_neg
 
 
+
+
+# ---- hybrid head: dense layers --------------------------------------------------------------------
+LEAKY_SLOPE = 0.01      # F.leaky_relu default (hybrid_pretrained_matrix_factorization.py:357,389)
+
+
+def dense_operand(*segments):
+    """Operand of a dense layer = column-wise concatenation of ``segments``; a segment is
+    ``(src [rows, width], idx [m] or None, act_ref [m, width] or None)`` (see include/collie_hip.h)."""
+    if not 1 <= len(segments) <= _lib.DENSE_MAX_SEGS:
+        raise ValueError(f'a dense operand has 1..{_lib.DENSE_MAX_SEGS} segments')
+    op = DenseOperand()
+    op.n_seg = len(segments)
+    keep = []
+    width = 0
+    for i, (src, idx, act) in enumerate(segments):
+        require_hip(src, 'dense operand')
+        if src.dim() == 1:
+            src = src.reshape(-1, 1)
+        if src.dtype != torch.float32 or src.stride(1) != 1:
+            src = src.float().contiguous()
+        seg = op.seg[i]
+        seg.src = src.data_ptr()
+        seg.ld = src.stride(0) if src.shape[0] > 1 else src.shape[1]
+        seg.rows = src.shape[0]
+        seg.width = src.shape[1]
+        if idx is not None:
+            idx = idx.contiguous()
+            seg.idx = idx.data_ptr()
+            seg.idx_dtype = idx_dtype(idx)
+        if act is not None:
+            if act.dim() == 1:
+                act = act.reshape(-1, 1)
+            assert act.dtype == torch.float32 and act.stride(1) == 1 and act.shape[1] == src.shape[1]
+            seg.act_ref = act.data_ptr()
+            seg.act_ld = act.stride(0) if act.shape[0] > 1 else act.shape[1]
+        width += src.shape[1]
+        keep.append((src, idx, act))
+    op._keepalive = keep
+    op._width = width
+    return op
+
+
+def dense_forward(x_op, m, weight, bias, leaky, transposed=False, out=None, row_bias=None,
+                  status=None, col_range=None):
+    """``F.leaky_relu(nn.Linear)`` (``leaky``) or plain ``nn.Linear`` over an operand;
+    ``transposed=True`` multiplies by ``weight.T`` instead (data backward ``dZ @ W``).
+    ``row_bias = (users, user_bias_table, items, item_bias_table)`` adds the two bias-table rows."""
+    require_hip(weight, 'weight')
+    assert weight.dtype == torch.float32 and weight.is_contiguous() and weight.dim() == 2
+    w_ptr = ptr(weight)
+    if transposed:
+        # dZ @ W[:, c0:c1]: the "output features" of this product are W's input columns
+        c0, c1 = col_range if col_range is not None else (0, weight.shape[1])
+        n_out, n_in = c1 - c0, weight.shape[0]
+        ld_out, ld_in = 1, weight.shape[1]
+        w_ptr = c_void_p(weight.data_ptr() + 4 * c0)
+    else:
+        n_out, n_in = weight.shape
+        ld_out, ld_in = weight.shape[1], 1
+    if out is None:
+        out = torch.empty(m, n_out, dtype=torch.float32, device=weight.device)
+    users = items = ub = ib = None
+    nu = ni = 0
+    if row_bias is not None:
+        users, ub, items, ib = row_bias
+        users, items = users.contiguous(), items.contiguous()
+        nu, ni = ub.shape[0], ib.shape[0]
+    check(load().collie_dense_forward(
+        byref(x_op), m, w_ptr, ld_out, ld_in, ptr(bias), n_in, n_out, 1 if leaky else 0,
+        LEAKY_SLOPE, ptr(users), idx_dtype(users) if users is not None else 0, ptr(ub), nu,
+        ptr(items), idx_dtype(items) if items is not None else 0, ptr(ib), ni, ptr(out),
+        out.stride(0) if out.shape[0] > 1 else out.shape[1], ptr(status), stream_ptr()),
+        'collie_dense_forward')
+    return out
+
+
+def dense_weight_grad(dz_op, x_op, m, n_out, n_in, want_bias=True, workspace=None, status=None):
+    """(dW [n_out, n_in], db [n_out] or None, workspace) of ``nn.Linear`` from the two operands."""
+    dev = torch.device('cuda', torch.cuda.current_device())
+    need = int(load().collie_dense_weight_grad_workspace_bytes(m, n_out, n_in))
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+    dw = torch.empty(n_out, n_in, dtype=torch.float32, device=dev)
+    db = torch.empty(n_out, dtype=torch.float32, device=dev) if want_bias else None
+    check(load().collie_dense_weight_grad(
+        byref(dz_op), byref(x_op), m, n_out, n_in, LEAKY_SLOPE, ptr(dw), ptr(db), ptr(workspace),
+        workspace.numel(), ptr(status), stream_ptr()), 'collie_dense_weight_grad')
+    return dw, db, workspace
+
+
+def dense_optim_step(param, grad, cfg, state1=None, state2=None, grad_scale=None):
+    """``optimizer.step()`` of Adam / SGD / Adagrad on one dense parameter (in place)."""
+    require_hip(param, 'parameter')
+    assert param.is_contiguous() and grad.is_contiguous() and grad.dtype == torch.float32
+    check(load().collie_dense_optim_step(
+        ptr(param), ptr(grad), param.numel(), byref(cfg), ptr(state1), ptr(state2), ptr(grad_scale),
+        stream_ptr()), 'collie_dense_optim_step')
+
+
+def dense_rows_update(table, rows, vals, cfg, state1=None, state2=None, row_stamp=None,
+                      status=None, workspace=None):
+    """Dense-gradient optimizers on a table whose gradient is an uncoalesced COO list."""
+    require_hip(table, 'table')
+    rows = rows.contiguous()
+    vals = vals.contiguous().float()
+    m = rows.shape[0]
+    dim = table.shape[1] if table.dim() == 2 else 1
+    need = int(load().collie_sparse_rows_workspace_bytes(m, dim))
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=table.device)
+    check(load().collie_dense_rows_update(
+        ptr(table), table.shape[0], dim, ptr(rows), idx_dtype(rows), ptr(vals), m, byref(cfg),
+        ptr(state1), ptr(state2), ptr(row_stamp), ptr(workspace), workspace.numel(), ptr(status),
+        stream_ptr()), 'collie_dense_rows_update')
+    return workspace
 
 
 # ---- device-side batch assembly + negative sampling ------------------------------------------------

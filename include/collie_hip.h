@@ -355,6 +355,75 @@ int collie_sample_batch(const int32_t* rows, const int32_t* cols, int64_t nnz,
                         int32_t* users_out, int32_t* pos_out, int64_t* neg_out,
                         collie_stream_t stream);
 
+/* ---- hybrid head: dense layers (BASELINE configs[4]) ------------------------
+ * HybridPretrainedModel.forward (collie/model/hybrid_pretrained_matrix_factorization.py:327-464):
+ * metadata[ids, :] -> Linear + LeakyReLU stack (:350-361); torch.cat((user_meta_out, U[users],
+ * I[items], item_meta_out), 1) (:430-459) -> Linear + LeakyReLU stack -> Linear(.., 1) + user bias
+ * + item bias (:387-399); and the autograd of those ops.  Exact-fp32 MFMA GEMMs.
+ *
+ * An operand [m, width] is the column-wise concatenation of up to COLLIE_DENSE_MAX_SEGS segments
+ * and is never materialised.  Segment s contributes `width` columns: row j of the operand reads
+ * row idx[j] of src (idx == NULL: row j) -- the nn.Embedding / metadata[ids, :] gathers.  If
+ * act_ref != NULL the value is multiplied by LeakyReLU'(act_ref[j, c]) (1 if > 0 else slope): the
+ * activation backward (F.leaky_relu, :357) fused into the operand load; act_ref is the layer's saved
+ * OUTPUT (same sign as its input). */
+#define COLLIE_DENSE_MAX_SEGS 4
+typedef struct collie_dense_seg {
+  const float* src;     /* [rows, ld] */
+  const void* idx;      /* [m] int32/int64 row numbers into src, or NULL */
+  const float* act_ref; /* [m, act_ld] or NULL */
+  int64_t ld;
+  int64_t act_ld;
+  int64_t rows; /* rows of src; ids outside [0, rows) read as zeros and set bit 0 of *status */
+  int32_t idx_dtype;
+  int32_t width;
+} collie_dense_seg;
+
+typedef struct collie_dense_operand {
+  int32_t n_seg;
+  collie_dense_seg seg[COLLIE_DENSE_MAX_SEGS];
+} collie_dense_operand;
+
+/* nn.Linear (+ F.leaky_relu): y[j, n] = act(sum_k x[j, k] * W[n, k] + bias[n]), W[n, k] read at
+ * w[n * w_ld_out + k * w_ld_in] (a Linear weight: w_ld_out = n_in, w_ld_in = 1; its transpose for
+ * the data backward dX = dZ W: w_ld_out = 1, w_ld_in = row length of the weight).  bias may be
+ * NULL; leaky = 0: no activation.  If user_bias / item_bias are given the result additionally gets
+ * + user_bias[users[j]] + item_bias[items[j]] (:394-398, the final layer).  y is [m, y_ld]. */
+int collie_dense_forward(const collie_dense_operand* x, int64_t m, const float* w, int64_t w_ld_out,
+                         int64_t w_ld_in, const float* bias, int32_t n_in, int32_t n_out,
+                         int32_t leaky, float slope, const void* users, int32_t users_dtype,
+                         const float* user_bias, int64_t num_users, const void* items,
+                         int32_t items_dtype, const float* item_bias, int64_t num_items, float* y,
+                         int64_t y_ld, int32_t* status, collie_stream_t stream);
+
+/* autograd of nn.Linear w.r.t. its parameters: dw[n, k] = sum_j dz[j, n] * x[j, k] ([n_out, n_in]
+ * contiguous), db[n] = sum_j dz[j, n]; dz is usually the operand (dY, act_ref = Y).  Either output
+ * may be NULL.  Deterministic (fixed chunks of rows, partials added in fixed order). */
+size_t collie_dense_weight_grad_workspace_bytes(int64_t m, int32_t n_out, int32_t n_in);
+int collie_dense_weight_grad(const collie_dense_operand* dz, const collie_dense_operand* x,
+                             int64_t m, int32_t n_out, int32_t n_in, float slope, float* dw,
+                             float* db, void* workspace, size_t workspace_bytes, int32_t* status,
+                             collie_stream_t stream);
+
+/* torch.optim.{Adam,SGD,Adagrad}.step on one dense parameter with a dense gradient (the head's
+ * Linear weights; base_pipeline.py:406-437 builds one optimizer over all parameters of the hybrid
+ * model).  state1 = exp_avg | state_sum, state2 = exp_avg_sq.  grad_scale: optional device float. */
+int collie_dense_optim_step(float* param, const float* grad, int64_t n,
+                            const collie_optim_cfg* cfg, float* state1, float* state2,
+                            const float* grad_scale, collie_stream_t stream);
+
+/* The same optimizers on a table whose dense gradient is given as an UNCOALESCED COO list (rows [m],
+ * vals [m, dim]): what nn.Embedding(sparse=False).backward + a dense optimizer do to the bias /
+ * embedding tables of the hybrid model.  Rows with entries get the summed gradient (input order,
+ * deterministic); every other row gets the zero-gradient update where that is not the identity
+ * (Adam's moment decay, weight decay), which needs row_stamp = int32 [num_rows] scratch owned by the
+ * optimizer (zero-filled at creation).  workspace: collie_sparse_rows_workspace_bytes(m, dim). */
+int collie_dense_rows_update(float* table, int64_t num_rows, int32_t dim, const void* rows,
+                             int32_t rows_dtype, const float* vals, int64_t m,
+                             const collie_optim_cfg* cfg, float* state1, float* state2,
+                             int32_t* row_stamp, void* workspace, size_t workspace_bytes,
+                             int32_t* status, collie_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

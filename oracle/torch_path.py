@@ -175,3 +175,90 @@ def eval_users_torch(model, user_ids, n_items, k):
     with torch.no_grad():
         preds = model(users, items).view(-1, n_items)
     return preds, preds.topk(k, dim=1).indices
+
+
+class TorchHybrid(torch.nn.Module):
+    """
+    The reference's ``HybridPretrainedModel`` network restated with the torch calls it makes
+    (``collie/model/hybrid_pretrained_matrix_factorization.py``): table copies ``:243-250``,
+    freezing ``:476-484``, metadata layers ``:188-225,327-361``, combined layers ``:297-325``,
+    prediction ``:363-399``, forward / concatenation order ``:401-464``.  Module names are the
+    reference's (``embeddings.0`` ... ``combined_layer_3``).  The reference class itself cannot
+    be imported here (``pytorch_lightning`` is not installed), so vectors made with this class are
+    pinned by torch 2.10 run in this container, not by a reference known-answer test (the
+    reference has none for this model: ``tests/test_model.py`` only asserts thresholds).
+    """
+
+    def __init__(self, tables, item_metadata=None, user_metadata=None,
+                 item_metadata_layers_dims=None, user_metadata_layers_dims=None,
+                 combined_layers_dims=(128, 64, 32), freeze_embeddings=True):
+        super().__init__()
+        nn = torch.nn
+        U, D = tables['user_embeddings'].shape
+        N = tables['item_embeddings'].shape[0]
+        self.embeddings = nn.Sequential(nn.Embedding(U, D), nn.Embedding(N, D))
+        self.biases = nn.Sequential(nn.Embedding(U, 1), nn.Embedding(N, 1))
+        with torch.no_grad():
+            self.embeddings[0].weight.copy_(torch.as_tensor(tables['user_embeddings']))
+            self.embeddings[1].weight.copy_(torch.as_tensor(tables['item_embeddings']))
+            self.biases[0].weight.copy_(torch.as_tensor(tables['user_biases']))
+            self.biases[1].weight.copy_(torch.as_tensor(tables['item_biases']))
+        self.embeddings[0].weight.requires_grad = not freeze_embeddings
+        self.embeddings[1].weight.requires_grad = not freeze_embeddings
+        self.item_metadata = None if item_metadata is None else torch.as_tensor(item_metadata).float()
+        self.user_metadata = None if user_metadata is None else torch.as_tensor(user_metadata).float()
+        self.num_items = N
+
+        def stack(kind, metadata, dims):
+            if metadata is None:
+                return None, None
+            if dims is None:
+                return None, metadata.shape[1]
+            full = [metadata.shape[1]] + list(dims)
+            layers = [nn.Linear(full[i - 1], full[i]) for i in range(1, len(full))]
+            for i, layer in enumerate(layers):
+                nn.init.xavier_normal_(layer.weight)
+                self.add_module(f'{kind}_metadata_layer_{i}', layer)
+            return layers, dims[-1]
+
+        self.item_metadata_layers, item_out = stack('item', self.item_metadata,
+                                                    item_metadata_layers_dims)
+        self.user_metadata_layers, user_out = stack('user', self.user_metadata,
+                                                    user_metadata_layers_dims)
+        dims = [2 * D + (item_out or 0) + (user_out or 0)] + list(combined_layers_dims) + [1]
+        self.combined_layers = [nn.Linear(dims[i - 1], dims[i]) for i in range(1, len(dims))]
+        for i, layer in enumerate(self.combined_layers):
+            nn.init.xavier_normal_(layer.weight)
+            self.add_module(f'combined_layer_{i}', layer)
+
+    def _metadata_output(self, metadata, layers, ids):
+        out = metadata[ids, :]
+        if layers is not None:
+            for layer in layers:
+                out = torch.nn.functional.leaky_relu(layer(out))
+        return out
+
+    def forward(self, users, items):
+        parts = []
+        if self.user_metadata is not None:
+            parts.append(self._metadata_output(self.user_metadata, self.user_metadata_layers, users))
+        parts += [self.embeddings[0](users), self.embeddings[1](items)]
+        if self.item_metadata is not None:
+            parts.append(self._metadata_output(self.item_metadata, self.item_metadata_layers, items))
+        out = torch.cat(parts, 1)
+        for layer in self.combined_layers[:-1]:
+            out = torch.nn.functional.leaky_relu(layer(out))
+        out = self.combined_layers[-1](out) + self.biases[0](users) + self.biases[1](items)
+        return out.squeeze()
+
+    def calculate_loss(self, batch, loss_fn, metadata=None, metadata_weights=None):
+        """base_pipeline.py:603-634 (two forward calls, as the reference makes them)."""
+        (users, pos), neg = batch
+        users = users.long()
+        pos = pos.long()
+        neg = torch.transpose(neg, 0, 1).long()
+        pos_preds = self(users, pos)
+        neg_preds = self(users.repeat(neg.shape[0]), neg.flatten()).view(neg.shape[0], len(users))
+        return loss_fn(pos_preds, neg_preds, num_items=self.num_items, positive_items=pos,
+                       negative_items=neg, metadata=metadata,
+                       metadata_weights=metadata_weights), pos_preds, neg_preds

@@ -1,0 +1,357 @@
+"""
+GPU tests (``-m gpu``) of the hybrid head: the MFMA dense-layer kernels
+through the C ABI against a float64 numpy restatement / torch fp32 on the CPU, and
+``HybridPretrainedModel`` against ``oracle/torch_path.py:TorchHybrid`` (the reference's torch op
+sequence, ``hybrid_pretrained_matrix_factorization.py:227-464``) on identical batches.
+
+Tolerances: 1e-5 relative to the largest magnitude of the compared tensor for single kernels
+(fp32 GEMMs with a different summation order than the CPU's), 2e-4 for three-step trajectories.
+Parity is pinned by torch 2.10 run here: the reference holds no known-answer vector for this model.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+SLOPE = 0.01
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device('cuda:0')
+
+
+def close(a, b, rtol=1e-5):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    assert a.shape == b.shape
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=rtol * max(np.abs(b).max(), 1e-30))
+
+
+def _operand_case(rng, m, widths, gathered, act, dev):
+    """Segments for ops.dense_operand + the float64 matrix they denote."""
+    from collie_amd import ops
+    segs, cols = [], []
+    for w, g, a in zip(widths, gathered, act):
+        if g:
+            rows = int(rng.integers(m // 2 + 1, 2 * m + 5))
+            src = rng.normal(size=(rows, w)).astype(np.float32)
+            idx = rng.integers(0, rows, m).astype(np.int64 if w % 2 else np.int32)
+            val = src[idx].astype(np.float64)
+            idx_t = torch.tensor(idx, device=dev)
+        else:
+            src = rng.normal(size=(m, w)).astype(np.float32)
+            val = src.astype(np.float64)
+            idx_t = None
+        act_t = None
+        if a:
+            ref = rng.normal(size=(m, w)).astype(np.float32)
+            ref[rng.random((m, w)) < 0.1] = 0.0
+            val = val * np.where(ref > 0, 1.0, np.float32(SLOPE).astype(np.float64))
+            act_t = torch.tensor(ref, device=dev)
+        segs.append((torch.tensor(src, device=dev), idx_t, act_t))
+        cols.append(val)
+    return ops.dense_operand(*segs), np.concatenate(cols, 1)
+
+
+FWD_CASES = [
+    # m, segment widths, gathered?, act mask?, n_out, leaky
+    (1, [8], [False], [False], 4, True),
+    (37, [5, 3], [True, False], [False, False], 33, True),
+    (300, [16, 16, 24], [True, True, False], [False, False, False], 32, True),
+    (513, [128, 128, 128], [True, True, False], [False, False, False], 128, True),
+    (700, [256], [True], [False], 130, False),
+    (260, [64], [False], [True], 128, False),
+    (129, [7, 9, 1, 2], [True, True, False, True], [False, False, True, False], 1, False),
+]
+
+
+@pytest.mark.parametrize('case', FWD_CASES)
+def test_dense_forward_vs_float64(dev, case):
+    from collie_amd import ops
+    m, widths, gathered, act, n_out, leaky = case
+    rng = np.random.default_rng(m + n_out)
+    op, x = _operand_case(rng, m, widths, gathered, act, dev)
+    n_in = x.shape[1]
+    w = (rng.normal(size=(n_out, n_in)) / np.sqrt(n_in)).astype(np.float32)
+    b = rng.normal(size=n_out).astype(np.float32)
+    y = ops.dense_forward(op, m, torch.tensor(w, device=dev), torch.tensor(b, device=dev), leaky)
+    ref = x @ w.astype(np.float64).T + b
+    if leaky:
+        ref = np.where(ref > 0, ref, ref * np.float64(np.float32(SLOPE)))
+    close(y.cpu().numpy(), ref)
+
+
+def test_dense_forward_transposed_slice_and_row_bias(dev):
+    from collie_amd import ops
+    rng = np.random.default_rng(5)
+    m, n_out, n_in = 333, 48, 100
+    op, dz = _operand_case(rng, m, [n_out], [False], [True], dev)
+    w = rng.normal(size=(n_out, n_in)).astype(np.float32)
+    wt = torch.tensor(w, device=dev)
+    close(ops.dense_forward(op, m, wt, None, False, transposed=True).cpu().numpy(),
+          dz @ w.astype(np.float64))
+    close(ops.dense_forward(op, m, wt, None, False, transposed=True, col_range=(20, 61)).cpu().numpy(),
+          dz @ w.astype(np.float64)[:, 20:61])
+    # final layer: Linear(.., 1) + user bias + item bias
+    users = rng.integers(0, 50, m)
+    items = rng.integers(0, 70, m).astype(np.int32)
+    ub = rng.normal(size=(50, 1)).astype(np.float32)
+    ib = rng.normal(size=(70, 1)).astype(np.float32)
+    w1 = rng.normal(size=(1, n_out)).astype(np.float32)
+    b1 = rng.normal(size=1).astype(np.float32)
+    y = ops.dense_forward(op, m, torch.tensor(w1, device=dev), torch.tensor(b1, device=dev), False,
+                          row_bias=(torch.tensor(users, device=dev), torch.tensor(ub, device=dev),
+                                    torch.tensor(items, device=dev), torch.tensor(ib, device=dev)))
+    ref = dz @ w1.astype(np.float64).T + b1 + ub[users] + ib[items]
+    close(y.cpu().numpy(), ref)
+
+
+def test_dense_forward_flags_out_of_range_rows(dev):
+    from collie_amd import ops
+    src = torch.ones(10, 8, device=dev)
+    idx = torch.tensor([0, 3, 10, -1], device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    w = torch.ones(4, 8, device=dev)
+    y = ops.dense_forward(ops.dense_operand((src, idx, None)), 4, w, None, False, status=status)
+    assert int(status.item()) == 1
+    np.testing.assert_array_equal(y.cpu().numpy(), np.array([[8.] * 4, [8.] * 4, [0.] * 4, [0.] * 4]))
+
+
+WG_CASES = [
+    (1, [8], [False], 4),
+    (100, [5, 3], [True, False], 33),
+    (3000, [128, 128, 128], [True, True, False], 128),
+    (70000, [16], [True], 8),
+    (5000, [32], [False], 1),
+    (1111, [130], [True], 140),
+]
+
+
+@pytest.mark.parametrize('case', WG_CASES)
+def test_dense_weight_grad_vs_float64(dev, case):
+    from collie_amd import ops
+    m, widths, gathered, n_out = case
+    rng = np.random.default_rng(m)
+    x_op, x = _operand_case(rng, m, widths, gathered, [False] * len(widths), dev)
+    dz_op, dz = _operand_case(rng, m, [n_out], [False], [n_out > 1], dev)
+    dw, db, _ = ops.dense_weight_grad(dz_op, x_op, m, n_out, x.shape[1])
+    close(dw.cpu().numpy(), dz.T @ x)
+    close(db.cpu().numpy(), dz.sum(0))
+    # deterministic: a second run is bit-identical
+    dw2, db2, _ = ops.dense_weight_grad(dz_op, x_op, m, n_out, x.shape[1])
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+
+
+@pytest.mark.parametrize('algo,kw', [('adam', dict(lr=1e-2, weight_decay=1e-3)),
+                                     ('adam', dict(lr=1e-3)),
+                                     ('sgd', dict(lr=0.1, weight_decay=1e-2)),
+                                     ('adagrad', dict(lr=0.05))])
+def test_dense_optimizers_vs_torch(dev, algo, kw):
+    """collie_dense_optim_step (flat parameter) and collie_dense_rows_update (table + COO list)
+    against torch.optim on the CPU for three steps."""
+    from collie_amd import ops
+    rng = np.random.default_rng(11)
+    cls = {'adam': torch.optim.Adam, 'sgd': torch.optim.SGD, 'adagrad': torch.optim.Adagrad}[algo]
+    p0 = rng.normal(size=(37, 12)).astype(np.float32)
+    t0 = rng.normal(size=(90, 8)).astype(np.float32)
+    pc = torch.nn.Parameter(torch.tensor(p0))
+    tc = torch.nn.Parameter(torch.tensor(t0))
+    opt = cls([pc, tc], **kw)
+    pg = torch.tensor(p0, device=dev)
+    tg = torch.tensor(t0, device=dev)
+    s = {n: torch.zeros_like(x) for n, x in (('p1', pg), ('p2', pg), ('t1', tg), ('t2', tg))}
+    stamp = torch.zeros(90, dtype=torch.int32, device=dev)
+    for step in range(1, 4):
+        g = rng.normal(size=p0.shape).astype(np.float32)
+        rows = rng.integers(0, 30, 200)          # rows 30.. never get an entry
+        vals = rng.normal(size=(200, 8)).astype(np.float32)
+        pc.grad = torch.tensor(g)
+        tc.grad = torch.zeros_like(tc).index_add_(0, torch.tensor(rows), torch.tensor(vals))
+        opt.step()
+        cfg = ops.optim_cfg(algo, step, kw['lr'], weight_decay=kw.get('weight_decay', 0.0),
+                            eps=1e-10 if algo == 'adagrad' else 1e-8)
+        ops.dense_optim_step(pg, torch.tensor(g, device=dev), cfg, s['p1'], s['p2'])
+        ops.dense_rows_update(tg, torch.tensor(rows, device=dev), torch.tensor(vals, device=dev),
+                              cfg, s['t1'], s['t2'], stamp)
+    close(pg.cpu().numpy(), pc.detach().numpy(), 2e-5)
+    close(tg.cpu().numpy(), tc.detach().numpy(), 2e-5)
+
+
+# ---- model level ------------------------------------------------------------------------------------
+def _mf_model(dev, U, N, D, K, seed):
+    from collie_amd.interactions import Interactions
+    from collie_amd.model import MatrixFactorizationModel
+    rng = np.random.default_rng(seed)
+    inter = Interactions(users=rng.integers(0, U, 4 * U), items=rng.integers(0, N, 4 * U),
+                         num_users=U, num_items=N, allow_missing_ids=True, num_negative_samples=K,
+                         seed=seed, max_number_of_samples_to_consider=0)
+    torch.manual_seed(seed)
+    mf = MatrixFactorizationModel(train=inter, embedding_dim=D, lr_scheduler_func=None)
+    with torch.no_grad():
+        mf.user_embeddings.weight.mul_(8.0)
+        mf.item_embeddings.weight.mul_(8.0)
+        mf.user_biases.weight.normal_(0, 0.1)
+        mf.item_biases.weight.normal_(0, 0.1)
+    return inter, mf
+
+
+def _pair(dev, inter, mf, item_md, user_md, **kw):
+    """The product model on the GPU and the torch restatement on the CPU with equal parameters."""
+    from collie_amd.hybrid import HybridPretrainedModel
+    from oracle.torch_path import TorchHybrid
+    model = HybridPretrainedModel(train=inter, trained_model=mf, item_metadata=item_md,
+                                  user_metadata=user_md, lr_scheduler_func=None, **kw)
+    tables = {'user_embeddings': mf.user_embeddings.weight.detach().numpy(),
+              'item_embeddings': mf.item_embeddings.weight.detach().numpy(),
+              'user_biases': mf.user_biases.weight.detach().numpy(),
+              'item_biases': mf.item_biases.weight.detach().numpy()}
+    ref = TorchHybrid(tables, item_metadata=item_md, user_metadata=user_md,
+                      item_metadata_layers_dims=kw.get('item_metadata_layers_dims'),
+                      user_metadata_layers_dims=kw.get('user_metadata_layers_dims'),
+                      combined_layers_dims=kw.get('combined_layers_dims', [128, 64, 32]),
+                      freeze_embeddings=kw.get('freeze_embeddings', True))
+    ref.load_state_dict(model.state_dict())
+    assert [n for n, _ in ref.named_parameters()] == [n for n, _ in model.named_parameters()]
+    return model.to(dev), ref
+
+
+HYBRID_CASES = [
+    dict(D=16, meta=(24, None), kw=dict(item_metadata_layers_dims=[32], combined_layers_dims=[32, 16, 8],
+                                        loss='adaptive', optimizer='adam', lr=1e-2)),
+    dict(D=16, meta=(24, 10), kw=dict(item_metadata_layers_dims=[32, 12], user_metadata_layers_dims=[8],
+                                      combined_layers_dims=[20], freeze_embeddings=False,
+                                      loss='bpr', optimizer='sgd', lr=0.2)),
+    dict(D=10, meta=(7, None), kw=dict(combined_layers_dims=[6], freeze_embeddings=False,
+                                       loss='warp', optimizer='adagrad', lr=5e-2)),
+    dict(D=10, meta=(7, None), kw=dict(combined_layers_dims=[], freeze_embeddings=False,
+                                       loss='bpr', optimizer='sgd', lr=0.1)),
+    dict(D=128, meta=(256, None), kw=dict(item_metadata_layers_dims=[128], freeze_embeddings=False,
+                                          loss='adaptive_bpr', optimizer='adam', lr=1e-3,
+                                          weight_decay=1e-4)),
+    dict(D=12, meta=(None, 9), kw=dict(combined_layers_dims=[16, 4], loss='hinge', optimizer='adam',
+                                       lr=1e-2)),
+]
+
+
+@pytest.mark.parametrize('case', HYBRID_CASES)
+def test_hybrid_forward_and_trajectory_vs_torch_path(dev, case):
+    from oracle import torch_path as T
+    U, N, K, B = 90, 70, 5, 96
+    rng = np.random.default_rng(case['D'])
+    inter, mf = _mf_model(dev, U, N, case['D'], K, seed=case['D'])
+    ic, uc = case['meta']
+    item_md = rng.normal(size=(N, ic)).astype(np.float32) if ic else None
+    user_md = rng.normal(size=(U, uc)).astype(np.float32) if uc else None
+    torch.manual_seed(1)
+    model, ref = _pair(dev, inter, mf, item_md, user_md, **case['kw'])
+    kw = case['kw']
+
+    # forward(users, items)
+    users = torch.tensor(rng.integers(0, U, 200))
+    items = torch.tensor(rng.integers(0, N, 200))
+    model.eval()
+    with torch.no_grad():
+        got = model(users.to(dev), items.to(dev))
+        want = ref(users, items)
+    close(got.cpu().numpy(), want.numpy())
+
+    # three training steps on identical batches (trainer.py:458-470)
+    model.train()
+    opt = model.configure_optimizers()
+    ropt = T.make_optimizers(ref, kw['optimizer'], None, kw['lr'], None, kw.get('weight_decay', 0.0))
+    loss_kind = model._loss_kind
+    names = [n for n, _ in model.named_parameters()]
+    for it in range(3):
+        batch = ((torch.tensor(rng.integers(0, U, B), dtype=torch.int32),
+                  torch.tensor(rng.integers(0, N, B), dtype=torch.int32)),
+                 torch.tensor(rng.integers(0, N, (B, K))))
+        gbatch = ((batch[0][0].to(dev), batch[0][1].to(dev)), batch[1].to(dev))
+        opt.zero_grad()
+        loss = model.calculate_loss(gbatch)
+        loss.backward()
+        if it == 0:
+            # gradients of every trainable tensor, before any optimizer amplifies rounding: the
+            # Linear parameters arrive as .grad, the tables as staged (row, value) lists
+            for o in ropt:
+                o.zero_grad()
+            ref_loss, _, _ = ref.calculate_loss(batch, T.TORCH_LOSSES[loss_kind])
+            ref_loss.backward()
+            rparams = dict(ref.named_parameters())
+            for name, p in model.named_parameters():
+                if not p.requires_grad:
+                    assert rparams[name].grad is None
+                    continue
+                staged = model._staged_rows.get(id(p))
+                if staged is not None:
+                    ids, vals = staged
+                    got = np.zeros(p.shape, np.float64)
+                    np.add.at(got, ids.cpu().numpy(), vals.cpu().numpy().reshape(len(ids), -1))
+                else:
+                    got = p.grad.cpu().numpy()
+                want = rparams[name].grad.numpy()
+                # entries that cancel analytically (user bias, last Linear bias) are rounding
+                # residue on both sides: compare against the scale of the summed terms
+                scale = max(np.abs(want).max(), float(ref_loss) / B)
+                np.testing.assert_allclose(got, want, rtol=1e-5, atol=2e-5 * scale, err_msg=name)
+        want_loss, _, _ = T.train_step(ref, ropt, batch, T.TORCH_LOSSES[loss_kind])
+        model.optimizer_step(optimizer=opt)
+        close(loss.item(), want_loss.item(), 2e-5)
+    model.check_status()
+    want_state = ref.state_dict()
+    assert list(want_state) == names
+    for name, got in model.state_dict().items():
+        got, want = got.cpu().numpy(), want_state[name].numpy()
+        if kw['optimizer'] == 'sgd':
+            close(got, want, 2e-4)
+        else:
+            # Adam / Adagrad normalise the gradient, so an entry whose terms cancel (user bias,
+            # the later Linear biases: +g for the positive, -g for the selected negative) turns
+            # its fp32 rounding residue into a step of order lr on BOTH sides; such entries are
+            # only comparable within that bound, all others agree far more tightly
+            diff = np.abs(got - want)
+            assert diff.max() <= 1.2 * 3 * kw['lr'], name
+            last_bias = f'combined_layer_{len(model.combined_layers) - 1}.bias'
+            if name not in ('biases.0.weight', last_bias):     # those two cancel entirely
+                assert np.median(diff) <= 2e-4 * max(np.abs(want).max(), 1e-30), name
+
+
+def test_hybrid_evaluate_save_load(dev, tmp_path):
+    """evaluate_in_batches takes the generic get_preds route for the hybrid model; save_model /
+    load_model_path round-trip predictions (tests/test_model.py:1346-1385 in the reference)."""
+    from collie_amd.hybrid import HybridPretrainedModel
+    from collie_amd.metrics import auc, evaluate_in_batches, mapk, mrr
+    from oracle import mf_oracle as O
+    U, N, K = 60, 50, 3
+    rng = np.random.default_rng(2)
+    inter, mf = _mf_model(dev, U, N, 8, K, seed=2)
+    item_md = rng.normal(size=(N, 6)).astype(np.float32)
+    torch.manual_seed(4)
+    model, ref = _pair(dev, inter, mf, item_md, None, item_metadata_layers_dims=[8],
+                       combined_layers_dims=[16, 8])
+    model.eval()
+    got = evaluate_in_batches([mapk, mrr, auc], inter, model, k=5, batch_size=7)
+    with torch.no_grad():
+        uu = torch.arange(U).repeat_interleave(N)
+        ii = torch.arange(N).repeat(U)
+        scores = ref(uu, ii).view(U, N).numpy()
+    users = np.unique(inter.mat.row)
+    targets = inter.mat.tocsr()
+    acc = [0.0, 0.0, 0.0]
+    for i in range(int(np.ceil(len(users) / 7))):
+        ur = users[i * 7:(i + 1) * 7]
+        for j, fn in enumerate((O.mapk, O.mrr, O.auc)):
+            acc[j] += fn(targets, ur, scores[ur], 5) * len(ur)
+    want = [a / len(users) for a in acc]
+    close(got, want, 1e-5)
+
+    path = tmp_path / 'hybrid'
+    model.save_model(path)
+    with pytest.raises(ValueError):
+        model.save_model(path)
+    loaded = HybridPretrainedModel(load_model_path=str(path)).to(dev)
+    with torch.no_grad():
+        a = model(uu[:500].to(dev), ii[:500].to(dev))
+        b = loaded(uu[:500].to(dev), ii[:500].to(dev))
+    assert torch.equal(a, b)
+    assert list(loaded.state_dict()) == list(model.state_dict())

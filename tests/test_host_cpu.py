@@ -305,3 +305,88 @@ def test_explicit_interactions_batch_format_matches_reference():
     batches = list(loader)
     assert [len(b) for b in batches] == [3, 3] and batches[0][0].dtype.is_floating_point is False
     np.testing.assert_array_equal(np.concatenate([b[2].numpy() for b in batches]), [5, 3, 1, 4])
+
+
+# ---- hybrid head ---------------------------------------------------------------
+def _hybrid(**kw):
+    from collie_amd.hybrid import HybridPretrainedModel
+    from collie_amd.model import MatrixFactorizationModel
+    torch.manual_seed(0)
+    mf = MatrixFactorizationModel(train=Shape(), embedding_dim=8)
+    args = dict(train=Shape(), trained_model=mf, item_metadata=np.ones((20, 6)),
+                item_metadata_layers_dims=[12], combined_layers_dims=[16, 4])
+    args.update(kw)
+    return mf, HybridPretrainedModel(**args)
+
+
+def test_hybrid_construction_follows_reference(tmp_path):
+    """hybrid_pretrained_matrix_factorization.py:129-136,227-325,476-484."""
+    from collie_amd.hybrid import HeadAdam, HybridPretrainedModel
+    with pytest.raises(ValueError, match='trained_model'):
+        HybridPretrainedModel(train=Shape(), item_metadata=np.ones((20, 6)))
+    mf, _ = _hybrid()
+    with pytest.raises(ValueError, match='item metadata and/or user_metadata'):
+        HybridPretrainedModel(train=Shape(), trained_model=mf)
+    mf, model = _hybrid(user_metadata=np.ones((30, 3)))
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    assert shapes == {
+        'embeddings.0.weight': (30, 8), 'embeddings.1.weight': (20, 8),
+        'biases.0.weight': (30, 1), 'biases.1.weight': (20, 1),
+        'item_metadata_layer_0.weight': (12, 6), 'item_metadata_layer_0.bias': (12,),
+        # user metadata (3 raw columns, no layers) + 8 + 8 + item metadata output 12
+        'combined_layer_0.weight': (16, 31), 'combined_layer_0.bias': (16,),
+        'combined_layer_1.weight': (4, 16), 'combined_layer_1.bias': (4,),
+        'combined_layer_2.weight': (1, 4), 'combined_layer_2.bias': (1,)}
+    # the tables are copies (deepcopy, :243-250), frozen by default; biases stay trainable
+    assert torch.equal(model.embeddings[0].weight, mf.user_embeddings.weight)
+    assert model.embeddings[0].weight.data_ptr() != mf.user_embeddings.weight.data_ptr()
+    assert not model.embeddings[0].weight.requires_grad and model.biases[0].weight.requires_grad
+    model.unfreeze_embeddings()
+    assert model.embeddings[1].weight.requires_grad
+    assert model.hparams.user_num_embeddings == 30 and model.hparams.item_embeddings_dim == 8
+    assert model.hparams.item_metadata_num_cols == 6 and model._loss_kind == 'adaptive_hinge'
+    # one optimizer over all parameters (bias_optimizer is None for this model), HIP-kernel step
+    ret = model.configure_optimizers()
+    opts, scheds = ret
+    assert len(opts) == 1 and isinstance(opts[0], HeadAdam) and isinstance(opts[0], torch.optim.Adam)
+    assert len(opts[0].param_groups[0]['params']) == len(list(model.parameters()))
+    # save / load directory layout (:486-534, :168-186)
+    path = tmp_path / 'hybrid'
+    model.save_model(path)
+    assert sorted(os.listdir(path)) == ['item_metadata.pkl', 'model.pth', 'user_metadata.pkl']
+    with pytest.raises(ValueError, match='overwrite'):
+        model.save_model(path)
+    loaded = HybridPretrainedModel(load_model_path=str(path))
+    assert not loaded.training
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, loaded.state_dict()[k])
+    assert torch.equal(loaded.item_metadata, model.item_metadata)
+    # no CPU fallback
+    from collie_amd._lib import CollieHipError
+    users = torch.zeros(4, dtype=torch.long)
+    with pytest.raises(CollieHipError, match='no CPU fallback'):
+        model(users, users)
+
+
+def test_dense_c_abi_rejects_bad_arguments_without_touching_the_gpu():
+    from collie_amd import _lib
+    lib = _lib.load()
+    op = _lib.DenseOperand()
+    op.n_seg = 1
+    op.seg[0].src, op.seg[0].ld, op.seg[0].rows, op.seg[0].width = 256, 8, 4, 8
+    args = (None, 0, None, 0, None, 0, None, 0)          # no bias-table add
+    rc = lib.collie_dense_forward(ctypes.byref(op), 5, 256, 8, 1, None, 8, 4, 1, 0.01, *args,
+                                  256, 4, None, None)
+    assert rc != 0 and b'4 rows for 5 operand rows' in lib.collie_last_error()
+    rc = lib.collie_dense_forward(ctypes.byref(op), 4, 256, 9, 1, None, 9, 4, 1, 0.01, *args,
+                                  256, 4, None, None)
+    assert rc != 0 and b'operand has 8 columns, layer expects 9' in lib.collie_last_error()
+    op.n_seg = 5
+    rc = lib.collie_dense_forward(ctypes.byref(op), 4, 256, 8, 1, None, 8, 4, 1, 0.01, *args,
+                                  256, 4, None, None)
+    assert rc != 0 and b'n_seg' in lib.collie_last_error()
+    assert lib.collie_dense_weight_grad_workspace_bytes(100000, 128, 384) >= 391 * 128 * 385 * 4
+    assert lib.collie_dense_weight_grad_workspace_bytes(0, 128, 384) == 0
+    cfg = _lib.OptimCfg(_lib.OPT_SPARSE_ADAM, 1, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0.0)
+    rc = lib.collie_dense_optim_step(256, 256, 10, ctypes.byref(cfg), 256, 256, None, None)
+    assert rc != 0 and b'SparseAdam does not support dense gradients' in lib.collie_last_error()
