@@ -126,6 +126,7 @@ struct FwdParams {
   float* y;
   int64_t y_ld;
   int32_t* status;
+  int has_act;  // some segment of x carries an activation reference
 };
 
 // 8 waves x 32 operand rows; every wave multiplies its rows by the same NTILES x 32 output columns.
@@ -225,6 +226,212 @@ __global__ __launch_bounds__(kFwdBlock) void dense_fwd_kernel(const FwdParams p)
   }
 }
 
+
+// ---- fast path (every segment, ld and base float4-aligned) -----------------------------------------
+// Same tiling and MFMA mapping as dense_fwd_kernel, but (i) the row numbers of the gathered
+// segments are read once per workgroup into LDS, (ii) the global loads of chunk c+1 (operand rows and
+// weights) are issued into registers before the MFMAs of chunk c and written to LDS after them, so
+// HBM/L2 latency hides under the matrix pipe.
+__device__ __forceinline__ void load_w_slot(const FwdParams& p, int n0, int k0, int e, int NT,
+                                            float (&w)[4], int& n, int& kk, bool w_vec) {
+  // slot e of the NT x 32 weight tile: four consecutive elements along W's contiguous direction
+  if (p.w_ld_in == 1) {
+    n = e >> 3;
+    kk = (e & 7) * 4;
+    const int64_t base = static_cast<int64_t>(n0 + n) * p.w_ld_out + (k0 + kk);
+    if (w_vec && n0 + n < p.n_out && k0 + kk + 3 < p.n_in) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(p.w + base);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w[j] = v[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        w[j] = (n0 + n < p.n_out && k0 + kk + j < p.n_in) ? p.w[base + j] : 0.0f;
+    }
+  } else {
+    kk = e & 31;      // lanes walk kk: the four LDS stores of a slot hit 32 distinct banks
+    n = (e >> 5) * 4;
+    const int64_t base = static_cast<int64_t>(n0 + n) * p.w_ld_out + static_cast<int64_t>(k0 + kk) * p.w_ld_in;
+    if (w_vec && p.w_ld_out == 1 && n0 + n + 3 < p.n_out && k0 + kk < p.n_in) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(p.w + base);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w[j] = v[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        w[j] = (n0 + n + j < p.n_out && k0 + kk < p.n_in) ? p.w[base + j * p.w_ld_out] : 0.0f;
+    }
+  }
+}
+
+template <int NTILES>
+__global__ __launch_bounds__(kFwdBlock) void dense_fwd_fast_kernel(const FwdParams p, const int w_vec) {
+  constexpr int NT = 32 * NTILES;
+  constexpr int WSLOTS = NT * kKC / 4 / kFwdBlock;  // 16-byte weight slots per thread: 2, 1 or 1/2
+  constexpr int WS = WSLOTS > 0 ? WSLOTS : 1;
+  __shared__ __attribute__((aligned(16))) float Xs[kFwdRows * kLD];
+  __shared__ __attribute__((aligned(16))) float Ws[NT * kLD];
+  __shared__ int32_t rowid[COLLIE_DENSE_MAX_SEGS][kFwdRows];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int col = lane & 31;
+  const int h = lane >> 5;
+  const int64_t m0 = static_cast<int64_t>(blockIdx.x) * kFwdRows;
+  const int n0 = blockIdx.y * NT;
+  const int c4 = tid & 7;    // this thread's 16-byte column slot inside a 32-column chunk
+  const int r0 = tid >> 3;   // and its rows r0, r0 + 64, r0 + 128, r0 + 192
+
+  // ---- row numbers of the gathered segments (-1: row past the end or id out of range) -----------
+  for (int e = tid; e < COLLIE_DENSE_MAX_SEGS * kFwdRows; e += kFwdBlock) {
+    const int si = e / kFwdRows, r = e - si * kFwdRows;
+    int32_t v = -1;
+    if (si < p.x.n_seg && m0 + r < p.m) {
+      const Seg& s = p.x.s[si];
+      if (s.idx) {
+        const int64_t id = load_idx(s.idx, s.idx_dtype, m0 + r);
+        if (id >= 0 && id < s.rows) v = static_cast<int32_t>(id);
+        else if (p.status) atomicOr(p.status, 1);
+      } else {
+        v = 0;  // identity: the row is m0 + r
+      }
+    }
+    rowid[si][r] = v;
+  }
+  __syncthreads();
+
+  f32x16 acc[NTILES];
+#pragma unroll
+  for (int nt = 0; nt < NTILES; ++nt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[nt][i] = 0.0f;
+
+  f32x4 xr[4], ar[4];
+  float wr[WS][4];
+  int wn[WS], wk[WS];
+
+  // Loads of the NEXT chunk.  The segment of this thread's column slot is selected with static
+  // indices (descriptors stay in SGPRs: no dependent kernarg loads in the loop) and nothing here
+  // consumes a loaded value, so every load stays in flight until commit().
+  auto fetch = [&](int k0) {
+    const int k = k0 + c4 * 4;
+    const float* src = nullptr;
+    const float* act = nullptr;
+    int64_t ld = 0, act_ld = 0;
+    int off = 0, si = 0;
+    bool gathered = false, on = false;
+#pragma unroll
+    for (int j = 0; j < COLLIE_DENSE_MAX_SEGS; ++j) {
+      const bool hit = j < p.x.n_seg && k >= p.x.s[j].begin && k < p.x.s[j].end;
+      src = hit ? p.x.s[j].src : src;
+      act = hit ? p.x.s[j].act : act;
+      ld = hit ? p.x.s[j].ld : ld;
+      act_ld = hit ? p.x.s[j].act_ld : act_ld;
+      off = hit ? k - p.x.s[j].begin : off;
+      gathered = hit ? p.x.s[j].idx != nullptr : gathered;
+      si = hit ? j : si;
+      on = on || hit;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = r0 + 64 * i;
+      const int32_t id = rowid[si][r];
+      const bool valid = on && id >= 0;
+      const int64_t row = gathered ? static_cast<int64_t>(id) : m0 + r;
+      f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+      f32x4 a = {1.0f, 1.0f, 1.0f, 1.0f};
+      if (valid) {
+        v = *reinterpret_cast<const f32x4*>(src + row * ld + off);
+        if (p.has_act && act) a = *reinterpret_cast<const f32x4*>(act + (m0 + r) * act_ld + off);
+      }
+      xr[i] = v;
+      ar[i] = a;
+    }
+#pragma unroll
+    for (int j = 0; j < WS; ++j) {
+      const int e = tid + kFwdBlock * j;
+      if (e < NT * kKC / 4) load_w_slot(p, n0, k0, e, NT, wr[j], wn[j], wk[j], w_vec != 0);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f32x4 v = xr[i];
+      if (p.has_act) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = ar[i][e] > 0.0f ? v[e] : v[e] * p.slope;
+      }
+      *reinterpret_cast<f32x4*>(&Xs[(r0 + 64 * i) * kLD + c4 * 4]) = v;
+    }
+#pragma unroll
+    for (int j = 0; j < WS; ++j) {
+      const int e = tid + kFwdBlock * j;
+      if (e < NT * kKC / 4) {
+        if (p.w_ld_in == 1) {
+          *reinterpret_cast<f32x4*>(&Ws[wn[j] * kLD + wk[j]]) =
+              f32x4{wr[j][0], wr[j][1], wr[j][2], wr[j][3]};
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) Ws[(wn[j] + q) * kLD + wk[j]] = wr[j][q];
+        }
+      }
+    }
+  };
+
+  fetch(0);
+  for (int k0 = 0; k0 < p.n_in; k0 += kKC) {
+    __syncthreads();  // every wave is done reading the previous chunk
+    commit();
+    __syncthreads();
+    if (k0 + kKC < p.n_in) fetch(k0 + kKC);  // in flight during the MFMAs below
+
+    const float* arow = &Xs[(wave * 32 + col) * kLD + 4 * h];
+    const float* brow = &Ws[col * kLD + 4 * h];
+    f32x4 a[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a[q] = *reinterpret_cast<const f32x4*>(arow + 8 * q);
+    // B fragments one step ahead of the MFMAs that consume them
+    f32x4 b = *reinterpret_cast<const f32x4*>(brow);
+#pragma unroll
+    for (int step = 0; step < NTILES * 4; ++step) {
+      const int nt = step >> 2, q = step & 3;
+      f32x4 bn = b;
+      if (step + 1 < NTILES * 4)
+        bn = *reinterpret_cast<const f32x4*>(brow + ((step + 1) >> 2) * 32 * kLD + 8 * ((step + 1) & 3));
+      acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][0], b[0], acc[nt], 0, 0, 0);
+      acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][1], b[1], acc[nt], 0, 0, 0);
+      acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][2], b[2], acc[nt], 0, 0, 0);
+      acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][3], b[3], acc[nt], 0, 0, 0);
+      b = bn;
+    }
+  }
+
+#pragma unroll
+  for (int nt = 0; nt < NTILES; ++nt) {
+    const int n = n0 + nt * 32 + col;
+    if (n >= p.n_out) continue;
+    const float bn = p.bias ? p.bias[n] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (m >= p.m) continue;
+      float v = acc[nt][r] + bn;
+      if (p.leaky) v = v > 0.0f ? v : v * p.slope;
+      if (p.user_bias) {
+        const int64_t u = load_idx(p.users, p.users_dtype, m);
+        const int64_t it = load_idx(p.items, p.items_dtype, m);
+        if (u < 0 || u >= p.num_users || it < 0 || it >= p.num_items) {
+          if (p.status) atomicOr(p.status, 1);
+        } else {
+          v = (v + p.user_bias[u]) + p.item_bias[it];
+        }
+      }
+      p.y[m * p.y_ld + n] = v;
+    }
+  }
+}
+
 // ---- weight gradient ------------------------------------------------------------------------------
 constexpr int kWgBlock = 256;
 constexpr int kWgTile = 128;          // output rows (n) and columns (k) per workgroup
@@ -239,6 +446,7 @@ struct WgParams {
   float slope;
   float* partial;  // [nchunks, n_out, n_in + 1]; column n_in = bias gradient
   int32_t* status;
+  int dz_scalar;   // fast path only: dz is one column (the final Linear(.., 1)), read as scalars
 };
 
 template <bool VEC>
@@ -310,23 +518,218 @@ __global__ __launch_bounds__(kWgBlock) void dense_wgrad_kernel(const WgParams p)
   }
 }
 
+
+// Fast path of the weight gradient: a thread's 16-byte column slot is fixed for the whole kernel, so
+// its segment (source, index array, activation reference) is resolved once; the rows of slab s+1
+// are loaded into registers (and the row numbers of slab s+2 fetched) while the MFMAs of slab s
+// run.  The bias gradient is a column sum of the staged dZ slab (no ones column: n_in = 128 / 256 /
+// 384 would otherwise cost a whole extra block of column tiles).  Tiles outside [n_out) x [n_in)
+// are skipped by whole waves.
+struct Slot {
+  const float* src;
+  const void* idx;
+  const float* act;
+  int64_t ld, act_ld, rows;
+  int idx_dtype;
+  int colo;   // column inside the segment
+  bool on;
+};
+
+__device__ __forceinline__ Slot make_slot(const Operand& op, int k) {
+  Slot t;
+  t.on = false;
+  t.src = nullptr; t.idx = nullptr; t.act = nullptr;
+  t.ld = t.act_ld = t.rows = 0; t.idx_dtype = 0; t.colo = 0;
+#pragma unroll
+  for (int j = 0; j < COLLIE_DENSE_MAX_SEGS; ++j) {
+    if (j < op.n_seg && k >= op.s[j].begin && k < op.s[j].end) {
+      const Seg& s = op.s[j];
+      t.src = s.src; t.idx = s.idx; t.act = s.act; t.ld = s.ld; t.act_ld = s.act_ld;
+      t.rows = s.rows; t.idx_dtype = s.idx_dtype; t.colo = k - s.begin; t.on = true;
+    }
+  }
+  return t;
+}
+
+// row number of operand row m for this slot (-1: past the end), NOT yet validated: nothing
+// consumes the loaded id here, so the load stays in flight (slot_load checks the range one slab later)
+__device__ __forceinline__ int64_t slot_row(const Slot& t, int64_t m, int64_t mend) {
+  if (!t.on || m >= mend) return -1;
+  if (!t.idx) return m;
+  return load_idx(t.idx, t.idx_dtype, m);
+}
+
+// raw value and activation reference of one slot; nothing is consumed here, so both loads stay in
+// flight until slot_value() at the LDS store
+__device__ __forceinline__ void slot_load(const Slot& t, int64_t row, int64_t m, f32x4& v, f32x4& a,
+                                          int32_t* status, bool scalar1 = false) {
+  v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  a = f32x4{1.0f, 1.0f, 1.0f, 1.0f};
+  if (row < 0 || row >= t.rows) {
+    if (t.on && t.idx && row != -1 && status) atomicOr(status, 1);
+    return;
+  }
+  if (scalar1) {
+    v[0] = t.src[row * t.ld + t.colo];
+    if (t.act) a[0] = t.act[m * t.act_ld + t.colo];
+    return;
+  }
+  v = *reinterpret_cast<const f32x4*>(t.src + row * t.ld + t.colo);
+  if (t.act) a = *reinterpret_cast<const f32x4*>(t.act + m * t.act_ld + t.colo);
+}
+
+__device__ __forceinline__ f32x4 slot_value(f32x4 v, const f32x4& a, float slope) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = a[e] > 0.0f ? v[e] : v[e] * slope;
+  return v;
+}
+
+__global__ __launch_bounds__(kWgBlock) void dense_wgrad_fast_kernel(const WgParams p) {
+  __shared__ __attribute__((aligned(16))) float Zs[32 * kWgLD];
+  __shared__ __attribute__((aligned(16))) float Xs[32 * kWgLD];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int col = lane & 31;
+  const int h = lane >> 5;
+  const int kb = blockIdx.y * kWgTile;
+  const int nb = blockIdx.z * kWgTile;
+  const int64_t mbeg = static_cast<int64_t>(blockIdx.x) * p.chunk;
+  int64_t mend = mbeg + p.chunk;
+  if (mend > p.m) mend = p.m;
+  const int c4 = tid & 31;   // 16-byte column slot
+  const int r0 = tid >> 5;   // rows r0, r0 + 8, r0 + 16, r0 + 24 of a slab
+
+  const Slot zt = make_slot(p.dz, nb + c4 * 4);
+  const Slot xt = make_slot(p.x, kb + c4 * 4);
+  const bool my_ntile = nb + wave * 32 < p.n_out;
+  int nkt = (p.n_in - kb + 31) / 32;
+  if (nkt > 4) nkt = 4;
+  const bool do_bias = blockIdx.y == 0 && tid < kWgTile;
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[kt][i] = 0.0f;
+  float bsum = 0.0f;
+
+  int64_t zrow[4], xrow[4];   // row numbers of the slab being fetched next
+  f32x4 zr[4], xr[4], za[4], xa[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    zrow[i] = slot_row(zt, mbeg + r0 + 8 * i, mend);
+    xrow[i] = slot_row(xt, mbeg + r0 + 8 * i, mend);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    slot_load(zt, zrow[i], mbeg + r0 + 8 * i, zr[i], za[i], p.status, p.dz_scalar != 0);
+    slot_load(xt, xrow[i], mbeg + r0 + 8 * i, xr[i], xa[i], p.status);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    zrow[i] = slot_row(zt, mbeg + 32 + r0 + 8 * i, mend);
+    xrow[i] = slot_row(xt, mbeg + 32 + r0 + 8 * i, mend);
+  }
+
+  for (int64_t ms = mbeg; ms < mend; ms += 32) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<f32x4*>(&Zs[(r0 + 8 * i) * kWgLD + c4 * 4]) = slot_value(zr[i], za[i], p.slope);
+      *reinterpret_cast<f32x4*>(&Xs[(r0 + 8 * i) * kWgLD + c4 * 4]) = slot_value(xr[i], xa[i], p.slope);
+    }
+    __syncthreads();
+    if (ms + 32 < mend) {
+      // slab s+1 into registers (row numbers were fetched one slab ago), then the numbers of s+2
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        slot_load(zt, zrow[i], ms + 32 + r0 + 8 * i, zr[i], za[i], p.status, p.dz_scalar != 0);
+        slot_load(xt, xrow[i], ms + 32 + r0 + 8 * i, xr[i], xa[i], p.status);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        zrow[i] = slot_row(zt, ms + 64 + r0 + 8 * i, mend);
+        xrow[i] = slot_row(xt, ms + 64 + r0 + 8 * i, mend);
+      }
+    }
+    if (do_bias) {
+      float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 32; r += 2) {
+        s0 += Zs[r * kWgLD + tid];
+        s1 += Zs[(r + 1) * kWgLD + tid];
+      }
+      bsum += s0 + s1;
+    }
+    if (my_ntile) {
+      // operands of step t+1 are read from LDS before the MFMAs of step t
+      const float* zq = &Zs[h * kWgLD + wave * 32 + col];
+      const float* xq = &Xs[h * kWgLD + col];
+      float a = zq[0];
+      float b[4];
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) b[kt] = xq[kt * 32];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        float an = a, bn[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) bn[kt] = b[kt];
+        if (t + 1 < 16) {
+          an = zq[2 * (t + 1) * kWgLD];
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt) bn[kt] = xq[2 * (t + 1) * kWgLD + kt * 32];
+        }
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+          if (kt < nkt) acc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[kt], acc[kt], 0, 0, 0);
+        a = an;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) b[kt] = bn[kt];
+      }
+    }
+  }
+
+  const int ldp = p.n_in + 1;
+  float* out = p.partial + static_cast<int64_t>(blockIdx.x) * p.n_out * ldp;
+  if (my_ntile) {
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      const int k = kb + kt * 32 + col;
+      if (kt >= nkt || k >= p.n_in) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = nb + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (n < p.n_out) out[static_cast<int64_t>(n) * ldp + k] = acc[kt][r];
+      }
+    }
+  }
+  if (do_bias && nb + tid < p.n_out) out[static_cast<int64_t>(nb + tid) * ldp + p.n_in] = bsum;
+}
+
+// Adds the per-chunk partials in a fixed order: 16 lanes per output element each sum the chunks
+// c = lane (mod 16) in increasing order, then a fixed-shape butterfly combines the 16 sums —
+// deterministic, and 16x shorter dependent chains than one thread per element.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial,
                                                            int nchunks, int n_out, int n_in,
                                                            float* __restrict__ dw,
                                                            float* __restrict__ db) {
   const int ldp = n_in + 1;
   const int64_t total = static_cast<int64_t>(n_out) * ldp;
-  const int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-  if (e >= total) return;
-  // four interleaved running sums, combined in a fixed order: deterministic
-  float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-  int c = 0;
-  for (; c + 4 <= nchunks; c += 4) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) s[q] += partial[(c + q) * total + e];
+  const int sub = threadIdx.x & 15;
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * 16 + (threadIdx.x >> 4);
+  float s0 = 0.0f, s1 = 0.0f;
+  if (e < total) {
+    int c = sub;
+    for (; c + 16 < nchunks; c += 32) {
+      s0 += partial[c * total + e];
+      s1 += partial[(c + 16) * total + e];
+    }
+    if (c < nchunks) s0 += partial[c * total + e];
   }
-  for (int q = 0; c < nchunks; ++c, ++q) s[q] += partial[c * total + e];
-  const float sum = (s[0] + s[1]) + (s[2] + s[3]);
+  const float sum = group_sum<16>(s0 + s1);
+  if (e >= total || sub != 0) return;
   const int n = static_cast<int>(e / ldp);
   const int k = static_cast<int>(e - static_cast<int64_t>(n) * ldp);
   if (k < n_in) {
@@ -375,17 +778,27 @@ int build_operand(Operand& op, const collie_dense_operand* in, int64_t m, bool& 
   return 0;
 }
 
-template <bool VEC>
-void launch_fwd(const FwdParams& p, hipStream_t stream) {
+void launch_fwd(const FwdParams& p, bool vec, hipStream_t stream) {
   const unsigned gx = static_cast<unsigned>((p.m + kFwdRows - 1) / kFwdRows);
-  if (p.n_out <= 32) {
-    hipLaunchKernelGGL((dense_fwd_kernel<1, VEC>), dim3(gx, 1), dim3(kFwdBlock), 0, stream, p);
-  } else if (p.n_out <= 64) {
-    hipLaunchKernelGGL((dense_fwd_kernel<2, VEC>), dim3(gx, 1), dim3(kFwdBlock), 0, stream, p);
-  } else {
-    const unsigned gy = static_cast<unsigned>((p.n_out + 127) / 128);
-    hipLaunchKernelGGL((dense_fwd_kernel<4, VEC>), dim3(gx, gy), dim3(kFwdBlock), 0, stream, p);
+  const unsigned gy = static_cast<unsigned>((p.n_out + 127) / 128);
+  if (vec) {
+    // weights load as 16-byte slots when their contiguous direction is float4-aligned
+    const int64_t ldw = p.w_ld_in == 1 ? p.w_ld_out : p.w_ld_in;
+    const int w_vec = (reinterpret_cast<uintptr_t>(p.w) % 16 == 0 && ldw % 4 == 0) ? 1 : 0;
+    if (p.n_out <= 32)
+      hipLaunchKernelGGL(dense_fwd_fast_kernel<1>, dim3(gx, 1), dim3(kFwdBlock), 0, stream, p, w_vec);
+    else if (p.n_out <= 64)
+      hipLaunchKernelGGL(dense_fwd_fast_kernel<2>, dim3(gx, 1), dim3(kFwdBlock), 0, stream, p, w_vec);
+    else
+      hipLaunchKernelGGL(dense_fwd_fast_kernel<4>, dim3(gx, gy), dim3(kFwdBlock), 0, stream, p, w_vec);
+    return;
   }
+  if (p.n_out <= 32)
+    hipLaunchKernelGGL((dense_fwd_kernel<1, false>), dim3(gx, 1), dim3(kFwdBlock), 0, stream, p);
+  else if (p.n_out <= 64)
+    hipLaunchKernelGGL((dense_fwd_kernel<2, false>), dim3(gx, 1), dim3(kFwdBlock), 0, stream, p);
+  else
+    hipLaunchKernelGGL((dense_fwd_kernel<4, false>), dim3(gx, gy), dim3(kFwdBlock), 0, stream, p);
 }
 
 int64_t wgrad_chunks(int64_t m, int64_t* chunk_out) {
@@ -450,8 +863,9 @@ extern "C" int collie_dense_forward(const collie_dense_operand* x, int64_t m, co
   p.y = y;
   p.y_ld = y_ld;
   p.status = status;
-  if (vec) launch_fwd<true>(p, stream);
-  else launch_fwd<false>(p, stream);
+  for (int i = 0; i < p.x.n_seg; ++i)
+    if (p.x.s[i].act) p.has_act = 1;
+  launch_fwd(p, vec, stream);
   return check_launch("dense_fwd_kernel");
 }
 
@@ -475,9 +889,13 @@ extern "C" int collie_dense_weight_grad(const collie_dense_operand* dz,
                  "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
   WgParams p;
   memset(&p, 0, sizeof(p));
-  bool vec = true;
-  if (build_operand(p.dz, dz, m, vec, "dense_weight_grad(dz)")) return -1;
+  bool vec = true, zvec = true;
+  if (build_operand(p.dz, dz, m, zvec, "dense_weight_grad(dz)")) return -1;
   if (build_operand(p.x, x, m, vec, "dense_weight_grad(x)")) return -1;
+  if (!zvec) {
+    if (n_out == 1 && p.dz.n_seg == 1) p.dz_scalar = 1;  // one column: scalar loads in the fast kernel
+    else vec = false;
+  }
   COLLIE_REQUIRE(p.dz.width == n_out && p.x.width == n_in,
                  "dense_weight_grad: operands are [m, %d] and [m, %d], expected [m, %d] and [m, %d]",
                  p.dz.width, p.x.width, n_out, n_in);
@@ -491,13 +909,18 @@ extern "C" int collie_dense_weight_grad(const collie_dense_operand* dz,
   p.slope = slope;
   p.partial = static_cast<float*>(workspace);
   p.status = status;
-  const dim3 grid(static_cast<unsigned>(nchunks), static_cast<unsigned>((n_in + 1 + kWgTile - 1) / kWgTile),
-                  static_cast<unsigned>((n_out + kWgTile - 1) / kWgTile));
-  if (vec) hipLaunchKernelGGL(dense_wgrad_kernel<true>, grid, dim3(kWgBlock), 0, stream, p);
-  else hipLaunchKernelGGL(dense_wgrad_kernel<false>, grid, dim3(kWgBlock), 0, stream, p);
+  const unsigned gz = static_cast<unsigned>((n_out + kWgTile - 1) / kWgTile);
+  if (vec) {
+    const dim3 grid(static_cast<unsigned>(nchunks), static_cast<unsigned>((n_in + kWgTile - 1) / kWgTile), gz);
+    hipLaunchKernelGGL(dense_wgrad_fast_kernel, grid, dim3(kWgBlock), 0, stream, p);
+  } else {
+    const dim3 grid(static_cast<unsigned>(nchunks),
+                    static_cast<unsigned>((n_in + 1 + kWgTile - 1) / kWgTile), gz);
+    hipLaunchKernelGGL(dense_wgrad_kernel<false>, grid, dim3(kWgBlock), 0, stream, p);
+  }
   if (check_launch("dense_wgrad_kernel")) return -2;
   const int64_t total = static_cast<int64_t>(n_out) * (n_in + 1);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256),
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(static_cast<unsigned>((total + 15) / 16)), dim3(256),
                      0, stream, p.partial, static_cast<int>(nchunks), n_out, n_in, dw, db);
   return check_launch("wgrad_reduce_kernel");
 }
