@@ -803,7 +803,7 @@ void launch_fwd(const FwdParams& p, bool vec, hipStream_t stream) {
 
 int64_t wgrad_chunks(int64_t m, int64_t* chunk_out) {
   int64_t nchunks = (m + 255) / 256;
-  if (nchunks > 1024) nchunks = 1024;
+  if (nchunks > 512) nchunks = 512;  // two resident workgroups per CU: one round of chunks
   if (nchunks < 1) nchunks = 1;
   int64_t chunk = (m + nchunks - 1) / nchunks;
   chunk = (chunk + 31) / 32 * 32;
