@@ -284,14 +284,22 @@ def main():
     ap.add_argument('--batch', type=int, default=1048576,
                     help='positives per step per GPU (SURVEY.md 8d lists 1024, 65536, 1048576)')
     ap.add_argument('--dist', choices=['uniform', 'zipf'], default='uniform')
-    ap.add_argument('--shape', choices=['c2', 'c4'], default='c2',
+    ap.add_argument('--shape', choices=['c2', 'c4', 'c5'], default='c2',
                     help="c2 = BASELINE configs[1] (the headline line); c4 = configs[3]'s tables "
-                         '(100M users x 10M items, dim 128) on ONE GPU: the shape no cache holds')
+                         '(100M users x 10M items, dim 128) on ONE GPU: the shape no cache holds; '
+                         'c5 = configs[4], the hybrid MLP head (tools/hybrid_bench.py)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--eval-users', type=int, default=65536,
                     help='users in the eval leg (0 = skip it)')
     args = ap.parse_args()
 
+    if args.shape == 'c5':
+        import runpy
+        sys.argv = ['hybrid_bench.py', '--steps', str(args.steps), '--warmup', str(args.warmup)] + (
+            ['--batch', str(args.batch)] if args.batch != 1048576 else []) + (
+            [] if args.no_cpu_baseline else ['--cpu-seconds', '12'])
+        runpy.run_path(os.path.join(ROOT, 'tools', 'hybrid_bench.py'), run_name='__main__')
+        return
     if args.shape == 'c4':
         global NUM_USERS, NUM_ITEMS, NUM_INTERACTIONS, DIM, WORKLOAD
         NUM_USERS, NUM_ITEMS, NUM_INTERACTIONS, DIM = 100_000_000, 10_000_000, 0, 128
