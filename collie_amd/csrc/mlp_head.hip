@@ -232,60 +232,68 @@ __global__ __launch_bounds__(kFwdBlock) void dense_fwd_kernel(const FwdParams p)
 // segments are read once per workgroup into LDS, (ii) the global loads of chunk c+1 (operand rows and
 // weights) are issued into registers before the MFMAs of chunk c and written to LDS after them, so
 // HBM/L2 latency hides under the matrix pipe.
-__device__ __forceinline__ void load_w_slot(const FwdParams& p, int n0, int k0, int e, int NT,
-                                            float (&w)[4], int& n, int& kk, bool w_vec) {
-  // slot e of the NT x 32 weight tile: four consecutive elements along W's contiguous direction
-  if (p.w_ld_in == 1) {
-    n = e >> 3;
-    kk = (e & 7) * 4;
-    const int64_t base = static_cast<int64_t>(n0 + n) * p.w_ld_out + (k0 + kk);
-    if (w_vec && n0 + n < p.n_out && k0 + kk + 3 < p.n_in) {
+// Fast-path geometry: 4 waves x 32 rows per workgroup and 32-column chunks, so that TWO workgroups
+// are resident per CU (registers and LDS both allow it) and run out of phase: the prologue (row ids,
+// first fetch), the LDS commits and the epilogue of one hide under the MFMAs of the other.  (8 waves
+// x 64-column chunks, one workgroup per CU, measured 10-25 % slower: every wave of the CU sat in the
+// same non-MFMA phase at the same time.)
+constexpr int kFKC = 32;
+constexpr int kFLD = kFKC + 4;
+constexpr int kFBlock = 256;
+constexpr int kFRows = 32 * (kFBlock / kWave);  // 128
+
+// slot e of the NT x 32 weight tile = four consecutive elements along W's contiguous direction:
+// row-major W (a Linear weight): (n, kk .. kk+3); transposed W (data backward): (n .. n+3, kk),
+// lanes walking kk so that the four LDS stores of a slot hit distinct banks.
+// WVEC: one predicated 16-byte load (the host guarantees alignment and n_in % 4 == 0, and
+// n_out % 4 == 0 for the transposed form); otherwise four predicated scalar loads.  No else-paths:
+// a join of two load paths would make the compiler wait for every outstanding load right here.
+template <bool WVEC>
+__device__ __forceinline__ void load_w_slot(const FwdParams& p, int n0, int k0, int e, float (&w)[4],
+                                            int& n, int& kk) {
+  const bool rowmajor = p.w_ld_in == 1;
+  n = rowmajor ? (e >> 3) : (e >> 5) * 4;
+  kk = rowmajor ? (e & 7) * 4 : (e & 31);
+  const int dn = rowmajor ? 0 : 1, dk = rowmajor ? 1 : 0;
+  const int64_t base = static_cast<int64_t>(n0 + n) * p.w_ld_out + static_cast<int64_t>(k0 + kk) * p.w_ld_in;
+  const int64_t step = rowmajor ? p.w_ld_in : p.w_ld_out;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) w[j] = 0.0f;
+  if (WVEC) {
+    if (n0 + n + 3 * dn < p.n_out && k0 + kk + 3 * dk < p.n_in) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(p.w + base);
 #pragma unroll
       for (int j = 0; j < 4; ++j) w[j] = v[j];
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        w[j] = (n0 + n < p.n_out && k0 + kk + j < p.n_in) ? p.w[base + j] : 0.0f;
     }
   } else {
-    kk = e & 31;      // lanes walk kk: the four LDS stores of a slot hit 32 distinct banks
-    n = (e >> 5) * 4;
-    const int64_t base = static_cast<int64_t>(n0 + n) * p.w_ld_out + static_cast<int64_t>(k0 + kk) * p.w_ld_in;
-    if (w_vec && p.w_ld_out == 1 && n0 + n + 3 < p.n_out && k0 + kk < p.n_in) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(p.w + base);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) w[j] = v[j];
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        w[j] = (n0 + n + j < p.n_out && k0 + kk < p.n_in) ? p.w[base + j * p.w_ld_out] : 0.0f;
-    }
+    for (int j = 0; j < 4; ++j)
+      if (n0 + n + dn * j < p.n_out && k0 + kk + dk * j < p.n_in) w[j] = p.w[base + j * step];
   }
 }
 
-template <int NTILES>
-__global__ __launch_bounds__(kFwdBlock) void dense_fwd_fast_kernel(const FwdParams p, const int w_vec) {
+template <int NTILES, bool WVEC, bool ACT>
+__global__ __launch_bounds__(kFBlock) void dense_fwd_fast_kernel(const FwdParams p) {
   constexpr int NT = 32 * NTILES;
-  constexpr int WSLOTS = NT * kKC / 4 / kFwdBlock;  // 16-byte weight slots per thread: 2, 1 or 1/2
+  constexpr int WSLOTS = NT * kFKC / 4 / kFBlock;  // 16-byte weight slots per thread: 4, 2 or 1
   constexpr int WS = WSLOTS > 0 ? WSLOTS : 1;
-  __shared__ __attribute__((aligned(16))) float Xs[kFwdRows * kLD];
-  __shared__ __attribute__((aligned(16))) float Ws[NT * kLD];
-  __shared__ int32_t rowid[COLLIE_DENSE_MAX_SEGS][kFwdRows];
+  __shared__ __attribute__((aligned(16))) float Xs[kFRows * kFLD];
+  __shared__ __attribute__((aligned(16))) float Ws[NT * kFLD];
+  __shared__ int32_t rowid[COLLIE_DENSE_MAX_SEGS][kFRows];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int col = lane & 31;
   const int h = lane >> 5;
-  const int64_t m0 = static_cast<int64_t>(blockIdx.x) * kFwdRows;
+  const int64_t m0 = static_cast<int64_t>(blockIdx.x) * kFRows;
   const int n0 = blockIdx.y * NT;
   const int c4 = tid & 7;    // this thread's 16-byte column slot inside a 32-column chunk
-  const int r0 = tid >> 3;   // and its rows r0, r0 + 64, r0 + 128, r0 + 192
+  const int r0 = tid >> 3;   // and its rows r0, r0 + 32, r0 + 64, r0 + 96
 
   // ---- row numbers of the gathered segments (-1: row past the end or id out of range) -----------
-  for (int e = tid; e < COLLIE_DENSE_MAX_SEGS * kFwdRows; e += kFwdBlock) {
-    const int si = e / kFwdRows, r = e - si * kFwdRows;
+  for (int e = tid; e < COLLIE_DENSE_MAX_SEGS * kFRows; e += kFBlock) {
+    const int si = e / kFRows, r = e - si * kFRows;
     int32_t v = -1;
     if (si < p.x.n_seg && m0 + r < p.m) {
       const Seg& s = p.x.s[si];
@@ -307,7 +315,7 @@ __global__ __launch_bounds__(kFwdBlock) void dense_fwd_fast_kernel(const FwdPara
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[nt][i] = 0.0f;
 
-  f32x4 xr[4], ar[4];
+  f32x4 xr[4], ar[ACT ? 4 : 1];
   float wr[WS][4];
   int wn[WS], wk[WS];
 
@@ -335,7 +343,7 @@ __global__ __launch_bounds__(kFwdBlock) void dense_fwd_fast_kernel(const FwdPara
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int r = r0 + 64 * i;
+      const int r = r0 + 32 * i;
       const int32_t id = rowid[si][r];
       const bool valid = on && id >= 0;
       const int64_t row = gathered ? static_cast<int64_t>(id) : m0 + r;
@@ -343,51 +351,53 @@ __global__ __launch_bounds__(kFwdBlock) void dense_fwd_fast_kernel(const FwdPara
       f32x4 a = {1.0f, 1.0f, 1.0f, 1.0f};
       if (valid) {
         v = *reinterpret_cast<const f32x4*>(src + row * ld + off);
-        if (p.has_act && act) a = *reinterpret_cast<const f32x4*>(act + (m0 + r) * act_ld + off);
+        if (ACT && act) a = *reinterpret_cast<const f32x4*>(act + (m0 + r) * act_ld + off);
       }
       xr[i] = v;
-      ar[i] = a;
+      if (ACT) ar[i] = a;
     }
 #pragma unroll
     for (int j = 0; j < WS; ++j) {
-      const int e = tid + kFwdBlock * j;
-      if (e < NT * kKC / 4) load_w_slot(p, n0, k0, e, NT, wr[j], wn[j], wk[j], w_vec != 0);
+      const int e = tid + kFBlock * j;
+      if (e < NT * kFKC / 4) load_w_slot<WVEC>(p, n0, k0, e, wr[j], wn[j], wk[j]);
     }
   };
   auto commit = [&]() {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       f32x4 v = xr[i];
-      if (p.has_act) {
+      if (ACT) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = ar[i][e] > 0.0f ? v[e] : v[e] * p.slope;
       }
-      *reinterpret_cast<f32x4*>(&Xs[(r0 + 64 * i) * kLD + c4 * 4]) = v;
+      *reinterpret_cast<f32x4*>(&Xs[(r0 + 32 * i) * kFLD + c4 * 4]) = v;
     }
 #pragma unroll
     for (int j = 0; j < WS; ++j) {
-      const int e = tid + kFwdBlock * j;
-      if (e < NT * kKC / 4) {
+      const int e = tid + kFBlock * j;
+      if (e < NT * kFKC / 4) {
         if (p.w_ld_in == 1) {
-          *reinterpret_cast<f32x4*>(&Ws[wn[j] * kLD + wk[j]]) =
+          *reinterpret_cast<f32x4*>(&Ws[wn[j] * kFLD + wk[j]]) =
               f32x4{wr[j][0], wr[j][1], wr[j][2], wr[j][3]};
         } else {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) Ws[(wn[j] + q) * kLD + wk[j]] = wr[j][q];
+          for (int q = 0; q < 4; ++q) Ws[(wn[j] + q) * kFLD + wk[j]] = wr[j][q];
         }
       }
     }
   };
 
   fetch(0);
-  for (int k0 = 0; k0 < p.n_in; k0 += kKC) {
+  for (int k0 = 0; k0 < p.n_in; k0 += kFKC) {
     __syncthreads();  // every wave is done reading the previous chunk
     commit();
     __syncthreads();
-    if (k0 + kKC < p.n_in) fetch(k0 + kKC);  // in flight during the MFMAs below
+#ifndef COLLIE_EXP_NOFETCH
+    if (k0 + kFKC < p.n_in) fetch(k0 + kFKC);  // in flight during the MFMAs below
+#endif
 
-    const float* arow = &Xs[(wave * 32 + col) * kLD + 4 * h];
-    const float* brow = &Ws[col * kLD + 4 * h];
+    const float* arow = &Xs[(wave * 32 + col) * kFLD + 4 * h];
+    const float* brow = &Ws[col * kFLD + 4 * h];
     f32x4 a[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) a[q] = *reinterpret_cast<const f32x4*>(arow + 8 * q);
@@ -398,7 +408,7 @@ __global__ __launch_bounds__(kFwdBlock) void dense_fwd_fast_kernel(const FwdPara
       const int nt = step >> 2, q = step & 3;
       f32x4 bn = b;
       if (step + 1 < NTILES * 4)
-        bn = *reinterpret_cast<const f32x4*>(brow + ((step + 1) >> 2) * 32 * kLD + 8 * ((step + 1) & 3));
+        bn = *reinterpret_cast<const f32x4*>(brow + ((step + 1) >> 2) * 32 * kFLD + 8 * ((step + 1) & 3));
       acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][0], b[0], acc[nt], 0, 0, 0);
       acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][1], b[1], acc[nt], 0, 0, 0);
       acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][2], b[2], acc[nt], 0, 0, 0);
@@ -531,7 +541,8 @@ struct Slot {
   const float* act;
   int64_t ld, act_ld, rows;
   int idx_dtype;
-  int colo;   // column inside the segment
+  int idx_shift;  // log2 of the index element size
+  int colo;       // column inside the segment
   bool on;
 };
 
@@ -539,37 +550,45 @@ __device__ __forceinline__ Slot make_slot(const Operand& op, int k) {
   Slot t;
   t.on = false;
   t.src = nullptr; t.idx = nullptr; t.act = nullptr;
-  t.ld = t.act_ld = t.rows = 0; t.idx_dtype = 0; t.colo = 0;
+  t.ld = t.act_ld = t.rows = 0; t.idx_dtype = 0; t.idx_shift = 2; t.colo = 0;
 #pragma unroll
   for (int j = 0; j < COLLIE_DENSE_MAX_SEGS; ++j) {
     if (j < op.n_seg && k >= op.s[j].begin && k < op.s[j].end) {
       const Seg& s = op.s[j];
       t.src = s.src; t.idx = s.idx; t.act = s.act; t.ld = s.ld; t.act_ld = s.act_ld;
-      t.rows = s.rows; t.idx_dtype = s.idx_dtype; t.colo = k - s.begin; t.on = true;
+      t.rows = s.rows; t.idx_dtype = s.idx_dtype; t.idx_shift = s.idx_dtype == COLLIE_I64 ? 3 : 2;
+      t.colo = k - s.begin; t.on = true;
     }
   }
   return t;
 }
 
-// row number of operand row m for this slot (-1: past the end), NOT yet validated: nothing
-// consumes the loaded id here, so the load stays in flight (slot_load checks the range one slab later)
-__device__ __forceinline__ int64_t slot_row(const Slot& t, int64_t m, int64_t mend) {
-  if (!t.on || m >= mend) return -1;
-  if (!t.idx) return m;
-  return load_idx(t.idx, t.idx_dtype, m);
+// id of operand row m for a gathered slot, as the raw low 32 bits (little endian) of the index
+// element: one predicated load for either index dtype and nothing else — no validation, no
+// widening, no alternative value written to the same register (an if/else or a dtype branch would
+// make the compiler wait for every outstanding load at the join).  Tables have < 2^31 rows, so a
+// valid id is its low word; slot_load resolves and range-checks it one slab later.
+__device__ __forceinline__ int32_t slot_row(const Slot& t, int64_t m, int64_t mend) {
+  int32_t raw = -1;
+  if (t.on && t.idx && m < mend)
+    raw = *reinterpret_cast<const int32_t*>(static_cast<const char*>(t.idx) + (m << t.idx_shift));
+  return raw;
 }
 
 // raw value and activation reference of one slot; nothing is consumed here, so both loads stay in
 // flight until slot_value() at the LDS store
-__device__ __forceinline__ void slot_load(const Slot& t, int64_t row, int64_t m, f32x4& v, f32x4& a,
-                                          int32_t* status, bool scalar1 = false) {
+template <bool SCALAR1 = false>
+__device__ __forceinline__ void slot_load(const Slot& t, int32_t raw, int64_t m, int64_t mend,
+                                          f32x4& v, f32x4& a, int32_t* status) {
   v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   a = f32x4{1.0f, 1.0f, 1.0f, 1.0f};
+  if (!t.on || m >= mend) return;
+  const int64_t row = t.idx ? static_cast<int64_t>(raw) : m;
   if (row < 0 || row >= t.rows) {
-    if (t.on && t.idx && row != -1 && status) atomicOr(status, 1);
+    if (status) atomicOr(status, 1);
     return;
   }
-  if (scalar1) {
+  if (SCALAR1) {
     v[0] = t.src[row * t.ld + t.colo];
     if (t.act) a[0] = t.act[m * t.act_ld + t.colo];
     return;
@@ -584,6 +603,7 @@ __device__ __forceinline__ f32x4 slot_value(f32x4 v, const f32x4& a, float slope
   return v;
 }
 
+template <bool ZS>  // ZS: dz is a single column (final Linear(.., 1)), loaded as scalars
 __global__ __launch_bounds__(kWgBlock) void dense_wgrad_fast_kernel(const WgParams p) {
   __shared__ __attribute__((aligned(16))) float Zs[32 * kWgLD];
   __shared__ __attribute__((aligned(16))) float Xs[32 * kWgLD];
@@ -615,7 +635,7 @@ __global__ __launch_bounds__(kWgBlock) void dense_wgrad_fast_kernel(const WgPara
     for (int i = 0; i < 16; ++i) acc[kt][i] = 0.0f;
   float bsum = 0.0f;
 
-  int64_t zrow[4], xrow[4];   // row numbers of the slab being fetched next
+  int32_t zrow[4], xrow[4];   // raw row numbers of the slab being fetched next
   f32x4 zr[4], xr[4], za[4], xa[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -624,8 +644,8 @@ __global__ __launch_bounds__(kWgBlock) void dense_wgrad_fast_kernel(const WgPara
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    slot_load(zt, zrow[i], mbeg + r0 + 8 * i, zr[i], za[i], p.status, p.dz_scalar != 0);
-    slot_load(xt, xrow[i], mbeg + r0 + 8 * i, xr[i], xa[i], p.status);
+    slot_load<ZS>(zt, zrow[i], mbeg + r0 + 8 * i, mend, zr[i], za[i], p.status);
+    slot_load(xt, xrow[i], mbeg + r0 + 8 * i, mend, xr[i], xa[i], p.status);
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -645,8 +665,8 @@ __global__ __launch_bounds__(kWgBlock) void dense_wgrad_fast_kernel(const WgPara
       // slab s+1 into registers (row numbers were fetched one slab ago), then the numbers of s+2
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        slot_load(zt, zrow[i], ms + 32 + r0 + 8 * i, zr[i], za[i], p.status, p.dz_scalar != 0);
-        slot_load(xt, xrow[i], ms + 32 + r0 + 8 * i, xr[i], xa[i], p.status);
+        slot_load<ZS>(zt, zrow[i], ms + 32 + r0 + 8 * i, mend, zr[i], za[i], p.status);
+        slot_load(xt, xrow[i], ms + 32 + r0 + 8 * i, mend, xr[i], xa[i], p.status);
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -782,15 +802,27 @@ void launch_fwd(const FwdParams& p, bool vec, hipStream_t stream) {
   const unsigned gx = static_cast<unsigned>((p.m + kFwdRows - 1) / kFwdRows);
   const unsigned gy = static_cast<unsigned>((p.n_out + 127) / 128);
   if (vec) {
+    const unsigned gx = static_cast<unsigned>((p.m + kFRows - 1) / kFRows);
     // weights load as 16-byte slots when their contiguous direction is float4-aligned
-    const int64_t ldw = p.w_ld_in == 1 ? p.w_ld_out : p.w_ld_in;
-    const int w_vec = (reinterpret_cast<uintptr_t>(p.w) % 16 == 0 && ldw % 4 == 0) ? 1 : 0;
-    if (p.n_out <= 32)
-      hipLaunchKernelGGL(dense_fwd_fast_kernel<1>, dim3(gx, 1), dim3(kFwdBlock), 0, stream, p, w_vec);
-    else if (p.n_out <= 64)
-      hipLaunchKernelGGL(dense_fwd_fast_kernel<2>, dim3(gx, 1), dim3(kFwdBlock), 0, stream, p, w_vec);
-    else
-      hipLaunchKernelGGL(dense_fwd_fast_kernel<4>, dim3(gx, gy), dim3(kFwdBlock), 0, stream, p, w_vec);
+    const bool rowmajor = p.w_ld_in == 1;
+    const int64_t ldw = rowmajor ? p.w_ld_out : p.w_ld_in;
+    const bool w_vec = reinterpret_cast<uintptr_t>(p.w) % 16 == 0 && ldw % 4 == 0 &&
+                       (rowmajor || (p.w_ld_out == 1 && p.n_out % 4 == 0));
+#define COLLIE_LAUNCH_FWD(NT_, GY_)                                                                  \
+  do {                                                                                               \
+    if (w_vec && p.has_act)                                                                          \
+      hipLaunchKernelGGL((dense_fwd_fast_kernel<NT_, true, true>), dim3(gx, GY_), dim3(kFBlock), 0, stream, p); \
+    else if (w_vec)                                                                                  \
+      hipLaunchKernelGGL((dense_fwd_fast_kernel<NT_, true, false>), dim3(gx, GY_), dim3(kFBlock), 0, stream, p); \
+    else if (p.has_act)                                                                              \
+      hipLaunchKernelGGL((dense_fwd_fast_kernel<NT_, false, true>), dim3(gx, GY_), dim3(kFBlock), 0, stream, p); \
+    else                                                                                             \
+      hipLaunchKernelGGL((dense_fwd_fast_kernel<NT_, false, false>), dim3(gx, GY_), dim3(kFBlock), 0, stream, p); \
+  } while (0)
+    if (p.n_out <= 32) COLLIE_LAUNCH_FWD(1, 1);
+    else if (p.n_out <= 64) COLLIE_LAUNCH_FWD(2, 1);
+    else COLLIE_LAUNCH_FWD(4, gy);
+#undef COLLIE_LAUNCH_FWD
     return;
   }
   if (p.n_out <= 32)
@@ -828,7 +860,7 @@ extern "C" int collie_dense_forward(const collie_dense_operand* x, int64_t m, co
   COLLIE_REQUIRE(m >= 1 && m < (int64_t{1} << 39), "dense_forward: bad row count %lld",
                  static_cast<long long>(m));
   COLLIE_REQUIRE(w && y && n_in >= 1 && n_out >= 1 && y_ld >= n_out, "dense_forward: bad W / Y");
-  COLLIE_REQUIRE((m + kFwdRows - 1) / kFwdRows < (int64_t{1} << 31), "dense_forward: too many rows");
+  COLLIE_REQUIRE((m + kFRows - 1) / kFRows < (int64_t{1} << 31), "dense_forward: too many rows");
   FwdParams p;
   memset(&p, 0, sizeof(p));
   bool vec = true;
@@ -912,7 +944,8 @@ extern "C" int collie_dense_weight_grad(const collie_dense_operand* dz,
   const unsigned gz = static_cast<unsigned>((n_out + kWgTile - 1) / kWgTile);
   if (vec) {
     const dim3 grid(static_cast<unsigned>(nchunks), static_cast<unsigned>((n_in + kWgTile - 1) / kWgTile), gz);
-    hipLaunchKernelGGL(dense_wgrad_fast_kernel, grid, dim3(kWgBlock), 0, stream, p);
+    if (p.dz_scalar) hipLaunchKernelGGL(dense_wgrad_fast_kernel<true>, grid, dim3(kWgBlock), 0, stream, p);
+    else hipLaunchKernelGGL(dense_wgrad_fast_kernel<false>, grid, dim3(kWgBlock), 0, stream, p);
   } else {
     const dim3 grid(static_cast<unsigned>(nchunks),
                     static_cast<unsigned>((n_in + 1 + kWgTile - 1) / kWgTile), gz);
