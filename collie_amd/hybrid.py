@@ -108,6 +108,7 @@ class HybridPretrainedModel(MatrixFactorizationModel):
     metadata_for_loss, metadata_for_loss_weights, load_model_path, map_location``.
     """
     _mf_eval_fast = False       # evaluation goes through get_preds (the score is not a dot product)
+    _NO_GRAD_CHUNK = 1 << 21    # pairs per head pass when no gradient is needed
 
     def __init__(self,
                  train: INTERACTIONS_LIKE_INPUT = None,
@@ -354,8 +355,15 @@ class HybridPretrainedModel(MatrixFactorizationModel):
             self._move_any_external_data_to_device()
         if self.user_metadata is not None and not self.user_metadata.is_cuda:
             self._move_any_external_data_to_device()
+        users, items = users.contiguous(), items.contiguous()
         params = [p for p in self.parameters() if p.requires_grad]
-        return _HeadScore.apply(self, users.contiguous(), items.contiguous(), *params).squeeze()
+        if not (torch.is_grad_enabled() and params) and users.shape[0] > self._NO_GRAD_CHUNK:
+            # scoring only (get_preds expands users x items pairs): bounded activation memory
+            step = self._NO_GRAD_CHUNK
+            with torch.no_grad():
+                return torch.cat([self._head_forward(users[i:i + step], items[i:i + step])[0]
+                                  for i in range(0, users.shape[0], step)]).squeeze()
+        return _HeadScore.apply(self, users, items, *params).squeeze()
 
     def calculate_loss(self, batch) -> torch.Tensor:
         """``base_pipeline.py:582-654``.  The positive and the K B negative pairs go through the
@@ -435,7 +443,7 @@ class HybridPretrainedModel(MatrixFactorizationModel):
         saved['combined'] = outs
         return scores.reshape(-1), saved
 
-    def _layer_backward(self, layer, x_segs, out, dz, m, grads, need_dx):
+    def _layer_backward(self, layer, x_segs, out, dz, m, grads):
         """Gradients of one ``Linear (+ LeakyReLU)``: parameters into ``grads``; returns the operand
         ``dz_op`` (dY with the activation backward folded in) for the caller's data backward."""
         dz_op = ops.dense_operand((dz, None, out))
@@ -459,11 +467,11 @@ class HybridPretrainedModel(MatrixFactorizationModel):
         for li in range(len(combined) - 1, 0, -1):
             x_segs, out = combined[li]
             layer = self.combined_layers[li]
-            dz_op = self._layer_backward(layer, x_segs, out, dz, m, grads, True)
+            dz_op = self._layer_backward(layer, x_segs, out, dz, m, grads)
             dz = ops.dense_forward(dz_op, m, layer.weight.data, None, False, transposed=True)
         x_segs, out = combined[0]
         layer = self.combined_layers[0]
-        dz_op = self._layer_backward(layer, x_segs, out, dz, m, grads, True)
+        dz_op = self._layer_backward(layer, x_segs, out, dz, m, grads)
         # data backward of the first combined layer, one column slice of W per segment that needs it
         col = 0
         for tag, (src, ids, _) in saved['segments']:
@@ -485,7 +493,7 @@ class HybridPretrainedModel(MatrixFactorizationModel):
             layers = getattr(self, f'{kind}_metadata_layers')
             for lj in range(len(stack) - 1, -1, -1):
                 in_seg, out_j = stack[lj]
-                dzj = self._layer_backward(layers[lj], [in_seg], out_j, d_meta, m, grads, lj > 0)
+                dzj = self._layer_backward(layers[lj], [in_seg], out_j, d_meta, m, grads)
                 if lj > 0:
                     d_meta = ops.dense_forward(dzj, m, layers[lj].weight.data, None, False,
                                                transposed=True)

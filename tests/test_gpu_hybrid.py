@@ -331,6 +331,7 @@ def test_hybrid_evaluate_save_load(dev, tmp_path):
     model, ref = _pair(dev, inter, mf, item_md, None, item_metadata_layers_dims=[8],
                        combined_layers_dims=[16, 8])
     model.eval()
+    model._NO_GRAD_CHUNK = 128      # 7 users x 50 items per call: exercises the chunked scoring path
     got = evaluate_in_batches([mapk, mrr, auc], inter, model, k=5, batch_size=7)
     with torch.no_grad():
         uu = torch.arange(U).repeat_interleave(N)
