@@ -390,3 +390,54 @@ def test_dense_c_abi_rejects_bad_arguments_without_touching_the_gpu():
     cfg = _lib.OptimCfg(_lib.OPT_SPARSE_ADAM, 1, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0.0)
     rc = lib.collie_dense_optim_step(256, 256, 10, ctypes.byref(cfg), 256, 256, None, None)
     assert rc != 0 and b'SparseAdam does not support dense gradients' in lib.collie_last_error()
+
+
+def test_cold_start_construction_and_stages(tmp_path, capsys):
+    """cold_start_matrix_factorization.py:159-241, multi_stage_pipeline.py:96-257."""
+    from collie_amd.cold_start import ColdStartModel
+    from collie_amd.optim import FusedAdam
+    buckets = np.arange(20) % 4
+    with pytest.raises(ValueError, match='Length of ``item_buckets``'):
+        ColdStartModel(train=Shape(), item_buckets=buckets[:5])
+    with pytest.raises(ValueError, match='must start at 0'):
+        ColdStartModel(train=Shape(), item_buckets=buckets + 1)
+    torch.manual_seed(0)
+    m = ColdStartModel(train=Shape(), item_buckets=buckets, embedding_dim=8)
+    assert list(m.state_dict()) == [
+        'item_bucket_biases.weight', 'item_bucket_embeddings.weight', 'user_biases.weight',
+        'item_biases.weight', 'user_embeddings.weight', 'item_embeddings.weight']
+    assert m.hparams.num_item_buckets == 4 and m.hparams.stage_list == ['item_buckets', 'no_buckets']
+    assert m.hparams.stage == 'item_buckets' and not m._mf_eval_fast
+    opts, scheds = m.configure_optimizers()
+    assert len(opts) == 2 and all(isinstance(o, FusedAdam) for o in opts)
+    owned = [{id(p) for p in o.param_groups[0]['params']} for o in opts]
+    assert id(m.item_bucket_embeddings.weight) in owned[0] and id(m.item_embeddings.weight) not in owned[0]
+    assert id(m.item_embeddings.weight) in owned[1] and id(m.item_bucket_biases.weight) not in owned[1]
+    assert id(m.user_embeddings.weight) in owned[0] and id(m.user_embeddings.weight) in owned[1]
+    # only the current stage's optimizer steps (multi_stage_pipeline.py:253-256)
+    calls = []
+
+    class Probe:
+        def __init__(self, tag):
+            self.tag = tag
+
+        def step(self, closure=None):
+            calls.append(self.tag)
+    m.optimizer_step(optimizer=Probe(0), optimizer_idx=0)
+    m.optimizer_step(optimizer=Probe(1), optimizer_idx=1)
+    assert calls == [0]
+    with pytest.raises(ValueError, match='not a valid stage'):
+        m.set_stage('nope')
+    with torch.no_grad():
+        m.item_bucket_embeddings.weight.normal_()
+    m.advance_stage()
+    assert m.hparams.stage == 'no_buckets' and m._mf_eval_fast
+    assert torch.equal(m.item_embeddings.weight, m.item_bucket_embeddings.weight[torch.tensor(buckets)])
+    m.optimizer_step(optimizer=Probe(0), optimizer_idx=0)
+    m.optimizer_step(optimizer=Probe(1), optimizer_idx=1)
+    assert calls == [0, 1]
+    m.save_model(tmp_path / 'cs.pth')
+    loaded = ColdStartModel(load_model_path=str(tmp_path / 'cs.pth'))
+    assert loaded.hparams.stage == 'no_buckets' and not loaded.training
+    assert torch.equal(loaded.item_embeddings.weight, m.item_embeddings.weight)
+    assert 'Set ``self.hparams.stage``' in capsys.readouterr().out
