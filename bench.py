@@ -221,6 +221,19 @@ def eval_leg(device, n_users, sharded_world=1, group_rank=0):
                      'note': 'end-to-end time, not kernel time: a lower bound on the kernel rate'}}
 
 
+def hybrid_leg(steps, warmup, batch=65536, cpu_seconds=0.0):
+    """BASELINE configs[4]: the HybridPretrainedModel head (tools/hybrid_bench.py)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('hybrid_bench',
+                                                  os.path.join(ROOT, 'tools', 'hybrid_bench.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    argv = ['--steps', str(steps), '--warmup', str(warmup), '--batch', str(batch)]
+    if cpu_seconds > 0:
+        argv += ['--cpu-seconds', str(cpu_seconds)]
+    return mod.run(argv)
+
+
 def main_sharded(args, world, rank, device):
     """N > 1: row-sharded tables, one rank per GPU, RCCL all-to-all each way."""
     import torch.distributed as dist
@@ -291,14 +304,15 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--eval-users', type=int, default=65536,
                     help='users in the eval leg (0 = skip it)')
+    ap.add_argument('--hybrid-steps', type=int, default=10,
+                    help="steps of the configs[4] leg (hybrid MLP head, reported under 'hybrid'; "
+                         '0 = skip it; single-GPU runs only)')
     args = ap.parse_args()
 
     if args.shape == 'c5':
-        import runpy
-        sys.argv = ['hybrid_bench.py', '--steps', str(args.steps), '--warmup', str(args.warmup)] + (
-            ['--batch', str(args.batch)] if args.batch != 1048576 else []) + (
-            [] if args.no_cpu_baseline else ['--cpu-seconds', '12'])
-        runpy.run_path(os.path.join(ROOT, 'tools', 'hybrid_bench.py'), run_name='__main__')
+        print(json.dumps(hybrid_leg(args.steps, args.warmup,
+                                    args.batch if args.batch != 1048576 else 65536,
+                                    0.0 if args.no_cpu_baseline else 12.0)))
         return
     if args.shape == 'c4':
         global NUM_USERS, NUM_ITEMS, NUM_INTERACTIONS, DIM, WORKLOAD
@@ -406,6 +420,12 @@ def main():
             del model, optimizers, batches
             torch.cuda.empty_cache()
             result['eval'] = eval_leg(device, args.eval_users)
+        if args.hybrid_steps > 0 and args.shape == 'c2':
+            model = optimizers = batches = None
+            torch.cuda.empty_cache()
+            leg = hybrid_leg(args.hybrid_steps, 3)
+            result['hybrid'] = {k: leg[k] for k in ('metric', 'value', 'unit', 'ms_per_step',
+                                                    'config', 'roofline')}
         print(json.dumps(result))
     if dist_on:
         dist.destroy_process_group()

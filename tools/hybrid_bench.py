@@ -43,7 +43,8 @@ def step_flops(m, d, meta_cols, meta_dims, comb_dims, unfrozen):
     return total
 
 
-def main():
+def run(argv=None):
+    """Runs the benchmark and returns the result dict (bench.py embeds it as its ``hybrid`` leg)."""
     ap = argparse.ArgumentParser()
     ap.add_argument('--batch', type=int, default=65536)
     ap.add_argument('--steps', type=int, default=20)
@@ -53,7 +54,7 @@ def main():
     ap.add_argument('--unfrozen', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=0.0,
                     help='also time the torch CPU op sequence of the reference (oracle/torch_path.py)')
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     from collie_amd.hybrid import HybridPretrainedModel
     from collie_amd.model import MatrixFactorizationModel
     U, N, D, K, MC = args.users, args.items, 128, 10, 256
@@ -142,7 +143,13 @@ def main():
                                'cores': threads, 'kind': 'port',
                                'sample': f'{n} steps of B={cb}, tables {cu} x {cn} (the head does not '
                                          f'depend on the table sizes), {cdt:.1f} s'}
-    print(json.dumps(out))
+    del model, opt, batches, item_md
+    torch.cuda.empty_cache()
+    return out
+
+
+def main():
+    print(json.dumps(run()))
 
 
 if __name__ == '__main__':
