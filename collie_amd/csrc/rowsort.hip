@@ -31,10 +31,29 @@ __global__ __launch_bounds__(kBlock) void radix_hist_kernel(const uint32_t* __re
     if (idx < m) atomicAdd(&h[(keys_in[idx] >> shift) & (RADIX - 1)], 1u);
   }
   __syncthreads();
-  for (int d = threadIdx.x; d < RADIX; d += kBlock) {
-    const uint32_t c = h[d];
-    hist[static_cast<int64_t>(d) * ntiles + blockIdx.x] = c;
-    if (c) atomicAdd(&totals[d], c);
+  for (int d = threadIdx.x; d < RADIX; d += kBlock)
+    hist[static_cast<int64_t>(d) * ntiles + blockIdx.x] = h[d];
+  (void)totals;
+}
+
+// one workgroup per digit: the number of keys with that digit = the sum of its per-tile counts.
+// (Formerly every tile added its counts to totals[] with global atomics: ntiles x RADIX atomics on
+// RADIX addresses, which cost more than the histogram itself.)
+__global__ __launch_bounds__(kBlock) void radix_totals_kernel(const uint32_t* __restrict__ hist,
+                                                              int64_t ntiles,
+                                                              uint32_t* __restrict__ totals) {
+  __shared__ uint32_t sh[kBlock / kWave];
+  const uint32_t* row = hist + static_cast<int64_t>(blockIdx.x) * ntiles;
+  uint32_t local = 0;
+  for (int64_t i = threadIdx.x; i < ntiles; i += kBlock) local += row[i];
+#pragma unroll
+  for (int o = kWave / 2; o > 0; o >>= 1) local += __shfl_xor(local, o, kWave);
+  if ((threadIdx.x & (kWave - 1)) == 0) sh[threadIdx.x / kWave] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t t = 0;
+    for (int w = 0; w < kBlock / kWave; ++w) t += sh[w];
+    totals[blockIdx.x] = t;
   }
 }
 
@@ -408,6 +427,8 @@ int run_pass(const SortWs& s, const uint32_t* kin, const uint32_t* vin, uint32_t
   const dim3 grid(static_cast<unsigned>(s.ntiles));
   hipLaunchKernelGGL(radix_hist_kernel<BITS>, grid, dim3(kBlock), 0, stream, kin, s.m, shift,
                      s.hist, s.ntiles, totals);
+  hipLaunchKernelGGL(radix_totals_kernel, dim3(1u << BITS), dim3(kBlock), 0, stream, s.hist,
+                     s.ntiles, totals);
   hipLaunchKernelGGL(radix_scan_kernel, dim3(1u << BITS), dim3(kBlock), 0, stream, s.hist,
                      s.ntiles, totals);
   hipLaunchKernelGGL((radix_scatter_kernel<BITS>), grid, dim3(kBlock), 0, stream, kin, vin, s.m,
@@ -429,8 +450,6 @@ int sort_and_segment(const SortWs& s, int64_t nkeys, uint32_t split, hipStream_t
                        s.seg_start, s.nseg, s.long_base, s.piece_start, s.piece_end);
     return check_launch("small_sort_segment_kernel");
   }
-  COLLIE_CHECK_HIP(hipMemsetAsync(s.totals, 0, 4 * (size_t{1} << kMaxRadixBits) * sizeof(uint32_t),
-                                  stream));
   for (int pass = 0; pass < plan.passes; ++pass) {
     const uint32_t* kin = pass == 0 ? s.ekeys : s.keys[(pass - 1) & 1];
     const uint32_t* vin = pass == 0 ? s.ecodes : s.vals[(pass - 1) & 1];
