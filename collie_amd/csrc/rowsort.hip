@@ -98,6 +98,16 @@ __global__ __launch_bounds__(kBlock) void radix_scan_kernel(uint32_t* __restrict
   }
 }
 
+// Workgroups are dispatched round-robin over the 8 XCDs, each with its own L2.  A tile's run inside a
+// bucket is only a few entries long and the neighbouring runs of the same output line belong to the
+// neighbouring tiles: with tile = blockIdx those come from 8 different L2s and every line is written
+// back 8 times as a partial line.  This bijection gives each XCD one contiguous range of tiles.
+__device__ __forceinline__ int64_t xcd_tile(int64_t b, int64_t ntiles) {
+  const int64_t q = ntiles / 8, r = ntiles % 8;
+  const int64_t x = b % 8, j = b / 8;
+  return x * q + (x < r ? x : r) + j;
+}
+
 template <int BITS>
 __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, int64_t m,
@@ -114,7 +124,8 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
   __syncthreads();
 
   // wave-striped tile: wave w owns entries [w*512, (w+1)*512) of the tile, iteration-major
-  const int64_t wbase = static_cast<int64_t>(blockIdx.x) * kSortTile + w * (kWave * kItems);
+  const int64_t tile = xcd_tile(blockIdx.x, ntiles);
+  const int64_t wbase = tile * kSortTile + w * (kWave * kItems);
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   uint32_t key[kItems], val[kItems], rnk[kItems];
   volatile uint32_t* mycount = wcount[w];
@@ -149,7 +160,7 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
       wcount[i][d] = run;
       run += c;
     }
-    gbase[d] = hist[static_cast<int64_t>(d) * ntiles + blockIdx.x];
+    gbase[d] = hist[static_cast<int64_t>(d) * ntiles + tile];
   }
   __syncthreads();
 #pragma unroll
