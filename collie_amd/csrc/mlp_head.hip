@@ -613,9 +613,12 @@ __global__ __launch_bounds__(kWgBlock) void dense_wgrad_fast_kernel(const WgPara
   const int wave = tid >> 6;
   const int col = lane & 31;
   const int h = lane >> 5;
-  const int kb = blockIdx.y * kWgTile;
+  // grid.x = column block of dW (fastest), grid.y = row chunk: the workgroups that re-read the same
+  // dZ slabs for different column blocks are dispatched together, so all but the first read hit the
+  // Infinity Cache instead of HBM
+  const int kb = blockIdx.x * kWgTile;
   const int nb = blockIdx.z * kWgTile;
-  const int64_t mbeg = static_cast<int64_t>(blockIdx.x) * p.chunk;
+  const int64_t mbeg = static_cast<int64_t>(blockIdx.y) * p.chunk;
   int64_t mend = mbeg + p.chunk;
   if (mend > p.m) mend = p.m;
   const int c4 = tid & 31;   // 16-byte column slot
@@ -626,7 +629,7 @@ __global__ __launch_bounds__(kWgBlock) void dense_wgrad_fast_kernel(const WgPara
   const bool my_ntile = nb + wave * 32 < p.n_out;
   int nkt = (p.n_in - kb + 31) / 32;
   if (nkt > 4) nkt = 4;
-  const bool do_bias = blockIdx.y == 0 && tid < kWgTile;
+  const bool do_bias = blockIdx.x == 0 && tid < kWgTile;
 
   f32x16 acc[4];
 #pragma unroll
@@ -712,7 +715,7 @@ __global__ __launch_bounds__(kWgBlock) void dense_wgrad_fast_kernel(const WgPara
   }
 
   const int ldp = p.n_in + 1;
-  float* out = p.partial + static_cast<int64_t>(blockIdx.x) * p.n_out * ldp;
+  float* out = p.partial + static_cast<int64_t>(blockIdx.y) * p.n_out * ldp;
   if (my_ntile) {
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
@@ -943,7 +946,7 @@ extern "C" int collie_dense_weight_grad(const collie_dense_operand* dz,
   p.status = status;
   const unsigned gz = static_cast<unsigned>((n_out + kWgTile - 1) / kWgTile);
   if (vec) {
-    const dim3 grid(static_cast<unsigned>(nchunks), static_cast<unsigned>((n_in + kWgTile - 1) / kWgTile), gz);
+    const dim3 grid(static_cast<unsigned>((n_in + kWgTile - 1) / kWgTile), static_cast<unsigned>(nchunks), gz);
     if (p.dz_scalar) hipLaunchKernelGGL(dense_wgrad_fast_kernel<true>, grid, dim3(kWgBlock), 0, stream, p);
     else hipLaunchKernelGGL(dense_wgrad_fast_kernel<false>, grid, dim3(kWgBlock), 0, stream, p);
   } else {
