@@ -357,3 +357,50 @@ def test_hybrid_evaluate_save_load(dev, tmp_path):
         b = loaded(uu[:500].to(dev), ii[:500].to(dev))
     assert torch.equal(a, b)
     assert list(loaded.state_dict()) == list(model.state_dict())
+
+
+def test_hybrid_forward_backward_vs_numpy_oracle(dev):
+    """The product model against oracle/hybrid_oracle.py (numpy): scores, Linear gradients and the
+    staged table gradients for an arbitrary d loss / d scores."""
+    from oracle import hybrid_oracle as H
+    U, N, K = 70, 55, 4
+    rng = np.random.default_rng(9)
+    inter, mf = _mf_model(dev, U, N, 12, K, seed=9)
+    item_md = rng.normal(size=(N, 8)).astype(np.float32)
+    user_md = rng.normal(size=(U, 4)).astype(np.float32)
+    torch.manual_seed(2)
+    model, _ = _pair(dev, inter, mf, item_md, user_md, item_metadata_layers_dims=[16, 8],
+                     combined_layers_dims=[24, 12], freeze_embeddings=False)
+    model.train()
+    M = 333
+    users = rng.integers(0, U, M)
+    items = rng.integers(0, N, M)
+    g = rng.normal(size=M).astype(np.float32)
+    scores = model(torch.tensor(users, device=dev), torch.tensor(items, device=dev))
+    scores.backward(torch.tensor(g, device=dev))
+
+    def wb(layers):
+        return None if layers is None else [(l.weight.detach().cpu().numpy(), l.bias.detach().cpu().numpy())
+                                            for l in layers]
+    tables = {'user_embeddings': model.embeddings[0].weight.detach().cpu().numpy(),
+              'item_embeddings': model.embeddings[1].weight.detach().cpu().numpy(),
+              'user_biases': model.biases[0].weight.detach().cpu().numpy(),
+              'item_biases': model.biases[1].weight.detach().cpu().numpy()}
+    params = {'item_metadata_layers': wb(model.item_metadata_layers), 'user_metadata_layers': None,
+              'combined_layers': wb(model.combined_layers)}
+    s, cache = H.forward(params, tables, users, items, item_metadata=item_md, user_metadata=user_md)
+    close(scores.detach().cpu().numpy(), s)
+    want = H.backward(params, tables, cache, g)
+    for (dw, db), layer in zip(want['combined_layers'], model.combined_layers):
+        close(layer.weight.grad.cpu().numpy(), dw)
+        close(layer.bias.grad.cpu().numpy(), db)
+    for (dw, db), layer in zip(want['item_metadata_layers'], model.item_metadata_layers):
+        close(layer.weight.grad.cpu().numpy(), dw)
+        close(layer.bias.grad.cpu().numpy(), db)
+    for name, table in (('user_embeddings', model.embeddings[0].weight),
+                        ('item_embeddings', model.embeddings[1].weight),
+                        ('user_biases', model.biases[0].weight), ('item_biases', model.biases[1].weight)):
+        ids, vals = model._staged_rows[id(table)]
+        got = np.zeros(table.shape, np.float64)
+        np.add.at(got, ids.cpu().numpy(), vals.cpu().numpy().reshape(len(ids), -1))
+        close(got, want[name])

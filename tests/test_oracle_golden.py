@@ -211,3 +211,51 @@ def test_eval_case(golden_dir):
         assert np.all(np.diff(s) <= 0)
         same = np.nonzero(np.diff(s) == 0)[0]
         assert np.all(ids[i][same] < ids[i][same + 1])
+
+
+def test_hybrid_numpy_oracle_matches_torch_restatement():
+    """oracle/hybrid_oracle.py (numpy) against oracle/torch_path.py:TorchHybrid (the reference's
+    torch calls, hybrid_pretrained_matrix_factorization.py:327-464) run by torch here: scores and
+    every gradient, with both metadata sides, stacked metadata layers and unfrozen embeddings."""
+    import torch
+    from oracle import hybrid_oracle as H
+    from oracle.torch_path import TorchHybrid
+    rng = np.random.default_rng(0)
+    U, N, D, M = 30, 25, 6, 64
+    tables = {'user_embeddings': rng.normal(size=(U, D)).astype(np.float32),
+              'item_embeddings': rng.normal(size=(N, D)).astype(np.float32),
+              'user_biases': rng.normal(size=(U, 1)).astype(np.float32),
+              'item_biases': rng.normal(size=(N, 1)).astype(np.float32)}
+    item_md = rng.normal(size=(N, 7)).astype(np.float32)
+    user_md = rng.normal(size=(U, 4)).astype(np.float32)
+    torch.manual_seed(0)
+    ref = TorchHybrid(tables, item_metadata=item_md, user_metadata=user_md,
+                      item_metadata_layers_dims=[9, 5], user_metadata_layers_dims=None,
+                      combined_layers_dims=[12, 6], freeze_embeddings=False)
+    users = rng.integers(0, U, M)
+    items = rng.integers(0, N, M)
+    g = rng.normal(size=M).astype(np.float32)
+    scores = ref(torch.as_tensor(users), torch.as_tensor(items))
+    scores.backward(torch.as_tensor(g))
+
+    def wb(layers):
+        return None if layers is None else [(l.weight.detach().numpy(), l.bias.detach().numpy())
+                                            for l in layers]
+    params = {'item_metadata_layers': wb(ref.item_metadata_layers), 'user_metadata_layers': None,
+              'combined_layers': wb(ref.combined_layers)}
+    s, cache = H.forward(params, tables, users, items, item_metadata=item_md, user_metadata=user_md)
+    np.testing.assert_allclose(s, scores.detach().numpy(), rtol=1e-5, atol=1e-5)
+    grads = H.backward(params, tables, cache, g)
+
+    def close(a, b):
+        np.testing.assert_allclose(a, b.numpy(), rtol=1e-4, atol=1e-5 * max(float(b.abs().max()), 1.0))
+    for (dw, db), layer in zip(grads['combined_layers'], ref.combined_layers):
+        close(dw, layer.weight.grad)
+        close(db, layer.bias.grad)
+    for (dw, db), layer in zip(grads['item_metadata_layers'], ref.item_metadata_layers):
+        close(dw, layer.weight.grad)
+        close(db, layer.bias.grad)
+    close(grads['user_embeddings'], ref.embeddings[0].weight.grad)
+    close(grads['item_embeddings'], ref.embeddings[1].weight.grad)
+    close(grads['user_biases'], ref.biases[0].weight.grad)
+    close(grads['item_biases'], ref.biases[1].weight.grad)
