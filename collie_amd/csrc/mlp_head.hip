@@ -4,17 +4,20 @@
 //   item_meta_out), 1) -> Linear + LeakyReLU stack -> Linear(.., 1) + user bias + item bias.
 //
 // Everything is exact-fp32 MFMA (v_mfma_f32_32x32x2_f32, 157 TFLOP/s dense peak), because the parity
-// bar is 1e-5 against the reference's fp32 CPU path.  Three GEMM shapes, two kernels:
-//   * dense_fwd_kernel:   Y[m, n] = act(sum_k X[m, k] W[n, k] + b[n])  (+ bias-table rows)
+// bar is 1e-5 against the reference's fp32 CPU path.  Three GEMM shapes, two kernel families:
+//   * dense_fwd_*:   Y[m, n] = act(sum_k X[m, k] W[n, k] + b[n])  (+ bias-table rows)
 //       X is never materialised: an operand is up to four column segments, each the rows of a
 //       table selected by an index array (nn.Embedding gather, metadata[ids, :]) or the previous
 //       layer's activations, optionally multiplied by LeakyReLU'(saved output) — so the same kernel
 //       is the data backward (dX = dZ W, W read through swapped strides) with the activation
 //       backward fused into its operand load.
-//   * dense_wgrad_kernel: dW[n, k] = sum_m dZ[m, n] X[m, k], db[n] = sum_m dZ[m, n] (a ones
-//       column appended to X).  The batch is cut into fixed chunks; each workgroup writes the
-//       partial of its chunk and wgrad_reduce_kernel adds the partials in fixed order — no
-//       floating-point atomics, deterministic.
+//   * dense_wgrad_*: dW[n, k] = sum_m dZ[m, n] X[m, k], db[n] = sum_m dZ[m, n].  The batch is cut
+//       into fixed chunks; each workgroup writes the partial of its chunk and wgrad_reduce_kernel
+//       adds the partials in fixed order — no floating-point atomics, deterministic.
+// Each family has a generic kernel (any widths / alignment, element-wise staging; dense_fwd_kernel,
+// dense_wgrad_kernel with the bias gradient as a ones column of X) and a fast kernel for the
+// float4-aligned case every real layer is in (dense_fwd_fast_kernel, dense_wgrad_fast_kernel:
+// register-prefetched tiles, see the comments there).
 // MFMA mapping (both kernels): a lane supplies A[i = lane & 31][kk = lane >> 5] and
 // B[kk = lane >> 5][j = lane & 31]; accumulator register r of a lane is D[i = (r & 3) + 8 (r >> 2)
 // + 4 (lane >> 5)][j = lane & 31].
@@ -62,32 +65,11 @@ __device__ __forceinline__ int64_t seg_row(const Seg& s, int64_t m, bool& ok, in
   return r;
 }
 
-// operand columns k .. k+3 of row m.  VEC: every segment boundary, ld and base is float4-aligned,
-// so the four columns live in one segment and load as one 16-byte access.
-template <bool VEC>
+// operand columns k .. k+3 of row m, element by element (generic path: any widths / alignment; the
+// float4-aligned case has its own kernels below)
 __device__ __forceinline__ f32x4 load_op4(const Operand& op, int64_t m, int k, float slope,
                                           int32_t* status) {
   f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-  if (VEC) {
-    if (k >= op.width) return v;
-#pragma unroll
-    for (int si = 0; si < COLLIE_DENSE_MAX_SEGS; ++si) {
-      if (si >= op.n_seg) break;
-      const Seg& s = op.s[si];
-      if (k < s.begin || k >= s.end) continue;
-      bool ok = true;
-      const int64_t r = seg_row(s, m, ok, status);
-      if (!ok) return v;
-      v = *reinterpret_cast<const f32x4*>(s.src + r * s.ld + (k - s.begin));
-      if (s.act) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(s.act + m * s.act_ld + (k - s.begin));
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = a[e] > 0.0f ? v[e] : v[e] * slope;
-      }
-      return v;
-    }
-    return v;
-  }
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int kk = k + e;
@@ -130,7 +112,7 @@ struct FwdParams {
 };
 
 // 8 waves x 32 operand rows; every wave multiplies its rows by the same NTILES x 32 output columns.
-template <int NTILES, bool VEC>
+template <int NTILES>
 __global__ __launch_bounds__(kFwdBlock) void dense_fwd_kernel(const FwdParams p) {
   constexpr int NT = 32 * NTILES;
   __shared__ __attribute__((aligned(16))) float Xs[kFwdRows * kLD];
@@ -159,7 +141,7 @@ __global__ __launch_bounds__(kFwdBlock) void dense_fwd_kernel(const FwdParams p)
       const int c4 = s & 7;
       const int64_t m = m0 + r;
       f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (m < p.m) v = load_op4<VEC>(p.x, m, k0 + c4 * 4, p.slope, p.status);
+      if (m < p.m) v = load_op4(p.x, m, k0 + c4 * 4, p.slope, p.status);
       *reinterpret_cast<f32x4*>(&Xs[r * kLD + c4 * 4]) = v;
     }
     // ---- weights: NT x 32 floats; threads walk along the contiguous direction of W -------------
@@ -459,7 +441,6 @@ struct WgParams {
   int dz_scalar;   // fast path only: dz is one column (the final Linear(.., 1)), read as scalars
 };
 
-template <bool VEC>
 __global__ __launch_bounds__(kWgBlock) void dense_wgrad_kernel(const WgParams p) {
   __shared__ __attribute__((aligned(16))) float Zs[32 * kWgLD];
   __shared__ __attribute__((aligned(16))) float Xs[32 * kWgLD];
@@ -492,9 +473,9 @@ __global__ __launch_bounds__(kWgBlock) void dense_wgrad_kernel(const WgParams p)
       f32x4 x = {0.0f, 0.0f, 0.0f, 0.0f};
       if (m < mend) {
         const int n = nb + c4 * 4;
-        if (n < p.n_out) z = load_op4<VEC>(p.dz, m, n, p.slope, p.status);
+        if (n < p.n_out) z = load_op4(p.dz, m, n, p.slope, p.status);
         const int k = kb + c4 * 4;
-        if (k < p.n_in) x = load_op4<VEC>(p.x, m, k, p.slope, p.status);
+        if (k < p.n_in) x = load_op4(p.x, m, k, p.slope, p.status);
         // the ones column that turns the last output column into the bias gradient
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -829,11 +810,11 @@ void launch_fwd(const FwdParams& p, bool vec, hipStream_t stream) {
     return;
   }
   if (p.n_out <= 32)
-    hipLaunchKernelGGL((dense_fwd_kernel<1, false>), dim3(gx, 1), dim3(kFwdBlock), 0, stream, p);
+    hipLaunchKernelGGL(dense_fwd_kernel<1>, dim3(gx, 1), dim3(kFwdBlock), 0, stream, p);
   else if (p.n_out <= 64)
-    hipLaunchKernelGGL((dense_fwd_kernel<2, false>), dim3(gx, 1), dim3(kFwdBlock), 0, stream, p);
+    hipLaunchKernelGGL(dense_fwd_kernel<2>, dim3(gx, 1), dim3(kFwdBlock), 0, stream, p);
   else
-    hipLaunchKernelGGL((dense_fwd_kernel<4, false>), dim3(gx, gy), dim3(kFwdBlock), 0, stream, p);
+    hipLaunchKernelGGL(dense_fwd_kernel<4>, dim3(gx, gy), dim3(kFwdBlock), 0, stream, p);
 }
 
 int64_t wgrad_chunks(int64_t m, int64_t* chunk_out) {
@@ -952,7 +933,7 @@ extern "C" int collie_dense_weight_grad(const collie_dense_operand* dz,
   } else {
     const dim3 grid(static_cast<unsigned>(nchunks),
                     static_cast<unsigned>((n_in + 1 + kWgTile - 1) / kWgTile), gz);
-    hipLaunchKernelGGL(dense_wgrad_kernel<false>, grid, dim3(kWgBlock), 0, stream, p);
+    hipLaunchKernelGGL(dense_wgrad_kernel, grid, dim3(kWgBlock), 0, stream, p);
   }
   if (check_launch("dense_wgrad_kernel")) return -2;
   const int64_t total = static_cast<int64_t>(n_out) * (n_in + 1);
