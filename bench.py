@@ -258,6 +258,13 @@ def main_sharded(args, world, rank, device):
     dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    # a few more, untimed steps with an event at every phase boundary: where the sharded step spends
+    # its time on this rank (plan / row exchange / compute / gradient exchange / owner update)
+    model.profile_phases(True)
+    for i in range(min(args.steps, 10)):
+        model.train_step(batches[i % n_distinct])
+    phases = model.phase_times()
+    model.profile_phases(False)
     t = torch.tensor([elapsed], device=device, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -280,6 +287,7 @@ def main_sharded(args, world, rank, device):
                                'RCCL all-to-all lookup + gradient exchange',
                 'final_loss': float(loss.item()),
                 'rows_exchanged_per_rank_per_step': model.last_exchange.get('rows_requested'),
+                'phase_ms_rank0': phases,
             },
             'roofline': None,
         }

@@ -432,6 +432,34 @@ class ShardedMatrixFactorizationModel:
             torch.save({'state_dict': sd, 'hparams': hp}, str(filename))
 
     # ---- training ----------------------------------------------------------------------------------
+    def profile_phases(self, enable=True):
+        """Record a device event at every phase boundary of ``train_step`` (cheap: no sync);
+        ``phase_times()`` turns them into mean milliseconds per phase.  The only way to see where a
+        multi-GPU step spends its time from inside the benchmark (rocprofv3 aside)."""
+        self._phase_events = [] if enable else None
+
+    def _phase_mark(self, name):
+        ev = getattr(self, '_phase_events', None)
+        if ev is None or not torch.cuda.is_available() or self.device.type != 'cuda':
+            return
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        ev.append((name, e))
+
+    def phase_times(self):
+        """Mean ms per phase over the recorded steps (synchronises)."""
+        ev = getattr(self, '_phase_events', None)
+        if not ev:
+            return {}
+        torch.cuda.synchronize()
+        sums, steps = {}, 0
+        for (name, a), (_, b) in zip(ev[:-1], ev[1:]):
+            if name is None:
+                continue
+            sums[name] = sums.get(name, 0.0) + a.elapsed_time(b)
+            steps += name == 'plan'
+        return {k: v / max(steps, 1) for k, v in sums.items()}
+
     def _plan(self, users, pos_items, neg_items):
         """Steps 1-2 of the module docstring: compact numbering + the request exchange."""
         comm, G = self.comm, self.comm.world
@@ -473,13 +501,17 @@ class ShardedMatrixFactorizationModel:
             neg_items = neg_items.reshape(-1, 1)
         comm, eng, dev = self.comm, self.engine, self.device
         D = self.hparams['embedding_dim']
+        mark = self._phase_mark
+        mark('plan')
         p = self._plan(users, pos_items, neg_items)
         n, crow = p['n'], p['crow']
         # 3. owners serve the rows
+        mark('lookup_exchange')
         cemb = comm.all_to_all(self.emb.index_select(0, crow), p['recv_splits'], p['send_splits'])
         cbias = comm.all_to_all(self.bias.index_select(0, crow), p['recv_splits'],
                                 p['send_splits'])
         # 4. fused forward + segment reduce on the compact tables
+        mark('forward_backward')
         codes = []
         for c in self._codes or []:          # category codes of the compact rows (items only)
             cc = torch.zeros(n, dtype=torch.int32, device=dev)
@@ -491,9 +523,11 @@ class ShardedMatrixFactorizationModel:
                                             self._loss_kind, self.hparams['num_items'], codes,
                                             self._weights, scale)
         # 5. gradients home
+        mark('gradient_exchange')
         grows = comm.all_to_all(gemb, p['send_splits'], p['recv_splits'])
         gb = comm.all_to_all(gbias, p['send_splits'], p['recv_splits'])
         # 6. owners update
+        mark('owner_update')
         self.steps += 1
         hp = self.hparams
         if crow.shape[0] > 0:
@@ -502,6 +536,7 @@ class ShardedMatrixFactorizationModel:
             eng.rows_update(self.bias, crow, gb, hp['bias_optimizer'], self.steps, hp['bias_lr'],
                             self.state['bias'], self._HYPER[hp['bias_optimizer']])
         total = comm.all_reduce(loss * scale)
+        mark(None)
         self.last_exchange = dict(rows_requested=n, rows_served=int(crow.shape[0]),
                                   bytes_each_way=n * (D + 1) * 4)
         return total.reshape(())

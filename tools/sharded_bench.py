@@ -26,6 +26,11 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
 print(f'B={B}: {dt * 1e3:.3f} ms/step, {B * 11 / dt / 1e9:.3f} G interactions/s, '
       f'rows/step {m.last_exchange}')
+m.profile_phases(True)
+for i in range(10):
+    m.train_step(batches[i % 8])
+print('phase ms:', {k: round(v, 3) for k, v in m.phase_times().items()})
+m.profile_phases(False)
 if os.environ.get('PROFILE'):
     from torch.profiler import ProfilerActivity, profile
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
