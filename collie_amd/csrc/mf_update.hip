@@ -878,6 +878,60 @@ extern "C" int collie_sparse_rows_update(float* table, int64_t num_rows, int32_t
   return launch_emb<false>(p, m, stream);
 }
 
+extern "C" int collie_sparse_rows_update_pair(float* table, float* bias_table, int64_t num_rows,
+                                              int32_t dim, const void* rows, int32_t rows_dtype,
+                                              const float* vals, const float* bias_vals, int64_t m,
+                                              const collie_optim_cfg* cfg,
+                                              const collie_optim_cfg* bias_cfg, float* state1,
+                                              float* state2, float* bias_state1, float* bias_state2,
+                                              void* workspace, size_t workspace_bytes,
+                                              int32_t* status, collie_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  COLLIE_REQUIRE(table && bias_table && rows && vals && bias_vals && cfg && bias_cfg,
+                 "sparse_rows_update_pair: NULL pointer");
+  COLLIE_REQUIRE(num_rows >= 1 && num_rows < (int64_t{1} << 31) && dim >= 2,
+                 "sparse_rows_update_pair: bad table shape");
+  COLLIE_REQUIRE(m >= 1 && m < (int64_t{1} << 30), "sparse_rows_update_pair: bad entry count");
+  COLLIE_REQUIRE(cfg->algo != COLLIE_OPT_ADAM && bias_cfg->algo != COLLIE_OPT_ADAM,
+                 "Adam does not support sparse gradients, please consider SparseAdam instead");
+  Carver c(workspace);
+  SortWs s;
+  carve_sort_ws(c, s, m, dim);
+  COLLIE_REQUIRE(workspace && workspace_bytes >= align_up(c.off, 256),
+                 "workspace too small: need %zu bytes, got %zu", align_up(c.off, 256),
+                 workspace_bytes);
+  hipLaunchKernelGGL(coo_entries_kernel, dim3(static_cast<unsigned>((m + kBlock - 1) / kBlock)),
+                     dim3(kBlock), 0, stream, rows, rows_dtype, m, num_rows, s.ekeys, s.ecodes,
+                     status);
+  if (check_launch("coo_entries_kernel")) return -2;
+  if (sort_and_segment(s, num_rows, 0xffffffffu, stream)) return -1;
+  // the two tables share the row list, so one coalesce serves both updates
+  UpdParams p;
+  memset(&p, 0, sizeof(p));
+  fill_sorted(p, s, num_rows, 0xffffffffu);
+  p.D = dim;
+  p.step = cfg->step;
+  p.d[0].table = table;
+  p.d[0].stage = vals;
+  p.d[0].s1 = cfg->algo == COLLIE_OPT_SGD ? nullptr : state1;
+  p.d[0].s2 = cfg->algo == COLLIE_OPT_SPARSE_ADAM ? state2 : nullptr;
+  if (make_hyper(p.d[0].h, cfg, 0, true, p.d[0].s1, p.d[0].s2)) return -1;
+  UpdParams q;
+  memset(&q, 0, sizeof(q));
+  fill_sorted(q, s, num_rows, 0xffffffffu);
+  q.D = 1;
+  q.step = bias_cfg->step;
+  q.d[0].table = bias_table;
+  q.d[0].stage = bias_vals;
+  q.d[0].s1 = bias_cfg->algo == COLLIE_OPT_SGD ? nullptr : bias_state1;
+  q.d[0].s2 = bias_cfg->algo == COLLIE_OPT_SPARSE_ADAM ? bias_state2 : nullptr;
+  if (make_hyper(q.d[0].h, bias_cfg, 0, true, q.d[0].s1, q.d[0].s2)) return -1;
+  if (launch_emb<false>(p, m, stream)) return -2;
+  hipLaunchKernelGGL(piece_bias_kernel<false>, dim3(piece_bias_grid(m)), dim3(kBlock), 0, stream, q);
+  hipLaunchKernelGGL(bias_rows_kernel<false>, dim3(bias_grid(m)), dim3(kBlock), 0, stream, q);
+  return check_launch("sparse_rows_update_pair");
+}
+
 // ---- dense-gradient variants (hybrid head) -----------------------------------
 namespace collie {
 namespace {

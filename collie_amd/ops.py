@@ -191,6 +191,29 @@ def sparse_rows_update(table, rows, vals, cfg, state1=None, state2=None, status=
     return workspace
 
 
+def sparse_rows_update_pair(table, bias_table, rows, vals, bias_vals, cfg, bias_cfg, state,
+                            bias_state, status=None, workspace=None):
+    """``sparse_rows_update`` for an embedding table and its bias table over one row list: one
+    coalesce, two updates (``collie_sparse_rows_update_pair``).  state = (state1, state2)."""
+    require_hip(table, 'table')
+    rows = rows.contiguous()
+    vals = vals.contiguous().float()
+    bias_vals = bias_vals.contiguous().float()
+    m = rows.shape[0]
+    if m == 0:
+        return workspace
+    dim = table.shape[1]
+    need = int(load().collie_sparse_rows_workspace_bytes(m, dim))
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=table.device)
+    check(load().collie_sparse_rows_update_pair(
+        ptr(table), ptr(bias_table), table.shape[0], dim, ptr(rows), idx_dtype(rows), ptr(vals),
+        ptr(bias_vals), m, byref(cfg), byref(bias_cfg), ptr(state[0]), ptr(state[1]),
+        ptr(bias_state[0]), ptr(bias_state[1]), ptr(workspace), workspace.numel(), ptr(status),
+        stream_ptr()), 'collie_sparse_rows_update_pair')
+    return workspace
+
+
 def optim_cfg(algo, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, lr_decay=0.0):
     return OptimCfg(_lib.OPT_ALGOS[algo] if isinstance(algo, str) else int(algo), int(step),
                     float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),

@@ -146,6 +146,14 @@ class HipEngine:
         self._rows_ws = ops.sparse_rows_update(table, rows, vals, cfg, s1, s2, self._status,
                                                self._rows_ws)
 
+    def rows_update_pair(self, emb, bias, rows, gemb, gbias, algos, step, lrs, states, hypers):
+        """Embedding rows and their bias rows share the row list: one coalesce, two updates."""
+        cfgs = [ops.optim_cfg(a, step, lr, h.get('beta1', 0.9), h.get('beta2', 0.999), h['eps'], 0.0,
+                              h.get('lr_decay', 0.0)) for a, lr, h in zip(algos, lrs, hypers)]
+        st = [(s.get('exp_avg', s.get('sum')), s.get('exp_avg_sq')) for s in states]
+        self._rows_ws = ops.sparse_rows_update_pair(emb, bias, rows, gemb, gbias, cfgs[0], cfgs[1],
+                                                    st[0], st[1], self._status, self._rows_ws)
+
     # ---- catalog-sharded evaluation --------------------------------------------------------------
     def _eval_tables(self, utile, ubias, iemb, ibias):
         return _lib.make_tables(utile, iemb, ubias.view(-1, 1), ibias.view(-1, 1))
@@ -530,7 +538,12 @@ class ShardedMatrixFactorizationModel:
         mark('owner_update')
         self.steps += 1
         hp = self.hparams
-        if crow.shape[0] > 0:
+        if crow.shape[0] > 0 and hasattr(eng, 'rows_update_pair') and D >= 2:
+            eng.rows_update_pair(self.emb, self.bias, crow, grows, gb,
+                                 (hp['optimizer'], hp['bias_optimizer']), self.steps,
+                                 (hp['lr'], hp['bias_lr']), (self.state['emb'], self.state['bias']),
+                                 (self._HYPER[hp['optimizer']], self._HYPER[hp['bias_optimizer']]))
+        elif crow.shape[0] > 0:
             eng.rows_update(self.emb, crow, grows, hp['optimizer'], self.steps, hp['lr'],
                             self.state['emb'], self._HYPER[hp['optimizer']])
             eng.rows_update(self.bias, crow, gb, hp['bias_optimizer'], self.steps, hp['bias_lr'],

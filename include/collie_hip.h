@@ -217,6 +217,17 @@ int collie_sparse_rows_update(float* table, int64_t num_rows, int32_t dim, const
                               void* workspace, size_t workspace_bytes, int32_t* status,
                               collie_stream_t stream);
 
+/* The same step for an embedding table [num_rows, dim] and its bias table [num_rows, 1] whose
+ * gradients share ONE row list (the owner side of the row-sharded step: every received row carries
+ * an embedding gradient and a bias gradient): one coalesce, two updates.  Equivalent to two
+ * collie_sparse_rows_update calls, without the second sort.  workspace as above for (m, dim). */
+int collie_sparse_rows_update_pair(float* table, float* bias_table, int64_t num_rows, int32_t dim,
+                                   const void* rows, int32_t rows_dtype, const float* vals,
+                                   const float* bias_vals, int64_t m, const collie_optim_cfg* cfg,
+                                   const collie_optim_cfg* bias_cfg, float* state1, float* state2,
+                                   float* bias_state1, float* bias_state2, void* workspace,
+                                   size_t workspace_bytes, int32_t* status, collie_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Row-sharded training, requester side (no counterpart in the reference, which has no multi-GPU
  * path for the tables: SURVEY.md 8e).  Replaces, for one rank's batch
