@@ -104,7 +104,10 @@ __global__ __launch_bounds__(kBlock) void plan_mark_kernel(const collie_mf_batch
       *bad_flag = 1;
       continue;
     }
-    stamp[cell_of(r, kind, id)] = step;
+    // read before write: after the first few thousand ids almost every cell is already stamped, and
+    // a (cached) load is far cheaper than a store to a line every CU is writing
+    int32_t* cell = stamp + cell_of(r, kind, id);
+    if (*cell != step) *cell = step;
   }
 }
 
