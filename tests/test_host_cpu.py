@@ -441,3 +441,30 @@ def test_cold_start_construction_and_stages(tmp_path, capsys):
     assert loaded.hparams.stage == 'no_buckets' and not loaded.training
     assert torch.equal(loaded.item_embeddings.weight, m.item_embeddings.weight)
     assert 'Set ``self.hparams.stage``' in capsys.readouterr().out
+
+
+def test_ctypes_prototypes_match_the_header():
+    """Every prototype in include/collie_hip.h has as many parameters as its ctypes argtypes list
+    in collie_amd/_lib.py, and pointer / integer / float kinds line up (a drifted binding would
+    otherwise only show up as garbage arguments on the GPU)."""
+    from collie_amd import _lib
+    text = open(os.path.join(ROOT, 'include', 'collie_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    protos = re.findall(r'\b(collie_[a-z0-9_]+)\s*\(([^;{}]*?)\)\s*;', text, flags=re.S)
+    assert len(protos) == len(_lib.SIGNATURES)
+    for name, params in protos:
+        params = ' '.join(params.split())
+        plist = [] if params in ('', 'void') else [p.strip() for p in params.split(',')]
+        argtypes = _lib.SIGNATURES[name][1]
+        assert len(plist) == len(argtypes), f'{name}: header has {len(plist)} parameters, ctypes {len(argtypes)}'
+        for decl, ct in zip(plist, argtypes):
+            is_ptr = '*' in decl or 'collie_stream_t' in decl
+            ct_is_ptr = ct in (ctypes.c_void_p, ctypes.c_char_p) or hasattr(ct, 'contents') or \
+                getattr(ct, '_type_', None) is not None and not isinstance(ct._type_, str)
+            assert is_ptr == ct_is_ptr, f'{name}: "{decl}" vs {ct}'
+            if not is_ptr:
+                is_float = decl.startswith('float') or decl.startswith('double')
+                assert is_float == (ct in (ctypes.c_float, ctypes.c_double)), f'{name}: "{decl}" vs {ct}'
+                if not is_float:
+                    wide = any(t in decl for t in ('int64_t', 'size_t', 'uint64_t'))
+                    assert wide == (ctypes.sizeof(ct) == 8), f'{name}: "{decl}" vs {ct}'
