@@ -743,6 +743,107 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+// ---- the one-column layer (the head's final Linear(.., 1)) -------------------------------------------
+// With a single output (or input) column the three GEMMs are memory-bound vector operations; on the
+// MFMA tiles they would pad that column to 32.  Operands here are one identity segment of width
+// n <= 256, float4-aligned (checked by the host), without an activation reference.
+constexpr int kNarrowBlock = 256;
+
+// y[m] = sum_k x[m, k] w[k] + b (+ bias-table rows): LPR = n / 4 lanes per row
+__global__ __launch_bounds__(kNarrowBlock) void narrow_gemv_kernel(const FwdParams p, int lpr) {
+  const int rows_per_block = kNarrowBlock / lpr;
+  const int sub = threadIdx.x % lpr;
+  const int64_t m = static_cast<int64_t>(blockIdx.x) * rows_per_block + threadIdx.x / lpr;
+  const Seg& s = p.x.s[0];
+  float acc = 0.0f;
+  if (m < p.m) {
+    const f32x4 x = *reinterpret_cast<const f32x4*>(s.src + m * s.ld + sub * 4);
+    const f32x4 w = *reinterpret_cast<const f32x4*>(p.w + sub * 4);
+    acc = fmaf(x[3], w[3], fmaf(x[2], w[2], fmaf(x[1], w[1], x[0] * w[0])));
+  }
+  for (int o = lpr / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, kWave);
+  if (m >= p.m || sub != 0) return;
+  float v = acc + (p.bias ? p.bias[0] : 0.0f);
+  if (p.leaky) v = v > 0.0f ? v : v * p.slope;
+  if (p.user_bias) {
+    const int64_t u = load_idx(p.users, p.users_dtype, m);
+    const int64_t it = load_idx(p.items, p.items_dtype, m);
+    if (u < 0 || u >= p.num_users || it < 0 || it >= p.num_items) {
+      if (p.status) atomicOr(p.status, 1);
+    } else {
+      v = (v + p.user_bias[u]) + p.item_bias[it];
+    }
+  }
+  p.y[m * p.y_ld] = v;
+}
+
+// y[m, n] = g[m] * w[n] (the data gradient of that layer: x is the single column g, W' is [n, 1])
+__global__ __launch_bounds__(kNarrowBlock) void narrow_outer_kernel(const FwdParams p, int lpr) {
+  const int rows_per_block = kNarrowBlock / lpr;
+  const int sub = threadIdx.x % lpr;
+  const int64_t m = static_cast<int64_t>(blockIdx.x) * rows_per_block + threadIdx.x / lpr;
+  if (m >= p.m) return;
+  const Seg& s = p.x.s[0];
+  const float g = s.src[m * s.ld];
+  f32x4 v;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = g * p.w[static_cast<int64_t>(sub * 4 + e) * p.w_ld_out];
+  *reinterpret_cast<f32x4*>(p.y + m * p.y_ld + sub * 4) = v;
+}
+
+// partial[chunk][0][k] = sum over the chunk's rows of g[m] * x[m, k]; [n_in] = sum of g[m].  A thread
+// owns one 16-byte column slot and every (256 / lpr)-th row of the chunk; the row groups are combined
+// through LDS in fixed order: deterministic.
+__global__ __launch_bounds__(kNarrowBlock) void narrow_wgrad_kernel(const WgParams p, int lpr) {
+  __shared__ float red[kNarrowBlock * 5];
+  const int groups = kNarrowBlock / lpr;
+  const int sub = threadIdx.x % lpr, grp = threadIdx.x / lpr;
+  const int64_t mbeg = static_cast<int64_t>(blockIdx.x) * p.chunk;
+  int64_t mend = mbeg + p.chunk;
+  if (mend > p.m) mend = p.m;
+  const Seg& zs = p.dz.s[0];
+  const Seg& xs = p.x.s[0];
+  float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f, ag = 0.0f;
+  for (int64_t m = mbeg + grp; m < mend; m += groups) {
+    const float g = zs.src[m * zs.ld];
+    const f32x4 x = *reinterpret_cast<const f32x4*>(xs.src + m * xs.ld + sub * 4);
+    a0 = fmaf(g, x[0], a0);
+    a1 = fmaf(g, x[1], a1);
+    a2 = fmaf(g, x[2], a2);
+    a3 = fmaf(g, x[3], a3);
+    ag += g;
+  }
+  float* mine = red + threadIdx.x * 5;
+  mine[0] = a0; mine[1] = a1; mine[2] = a2; mine[3] = a3; mine[4] = ag;
+  __syncthreads();
+  if (grp != 0) return;
+  for (int q = 1; q < groups; ++q) {
+    const float* o = red + (q * lpr + sub) * 5;
+    a0 += o[0]; a1 += o[1]; a2 += o[2]; a3 += o[3]; ag += o[4];
+  }
+  float* out = p.partial + static_cast<int64_t>(blockIdx.x) * (p.n_in + 1);
+  out[sub * 4 + 0] = a0;
+  out[sub * 4 + 1] = a1;
+  out[sub * 4 + 2] = a2;
+  out[sub * 4 + 3] = a3;
+  if (sub == 0) out[p.n_in] = ag;
+}
+
+// one identity segment, float4-aligned rows, no activation reference
+bool narrow_operand(const Operand& op, int width) {
+  if (op.n_seg != 1 || op.width != width) return false;
+  const Seg& s = op.s[0];
+  if (s.idx || s.act) return false;
+  if (width == 1) return true;
+  return width % 4 == 0 && s.ld % 4 == 0 && reinterpret_cast<uintptr_t>(s.src) % 16 == 0;
+}
+
+// lanes per row for an n-column row of 16-byte slots (a power of two that divides the workgroup)
+int narrow_lpr(int n) {
+  const int slots = n / 4;
+  return (slots >= 1 && slots <= 64 && (slots & (slots - 1)) == 0) ? slots : 0;
+}
+
 // ---- host side ------------------------------------------------------------------------------------
 int build_operand(Operand& op, const collie_dense_operand* in, int64_t m, bool& vec,
                   const char* what) {
@@ -881,6 +982,21 @@ extern "C" int collie_dense_forward(const collie_dense_operand* x, int64_t m, co
   p.status = status;
   for (int i = 0; i < p.x.n_seg; ++i)
     if (p.x.s[i].act) p.has_act = 1;
+  const int lpr_in = narrow_lpr(n_in), lpr_out = narrow_lpr(n_out);
+  if (n_out == 1 && lpr_in && narrow_operand(p.x, n_in) && w_ld_in == 1 &&
+      reinterpret_cast<uintptr_t>(w) % 16 == 0) {
+    const int64_t rows_per_block = kNarrowBlock / lpr_in;
+    hipLaunchKernelGGL(narrow_gemv_kernel, dim3(static_cast<unsigned>((m + rows_per_block - 1) / rows_per_block)),
+                       dim3(kNarrowBlock), 0, stream, p, lpr_in);
+    return check_launch("narrow_gemv_kernel");
+  }
+  if (n_in == 1 && lpr_out && narrow_operand(p.x, 1) && !bias && !leaky && !p.user_bias &&
+      y_ld % 4 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0) {
+    const int64_t rows_per_block = kNarrowBlock / lpr_out;
+    hipLaunchKernelGGL(narrow_outer_kernel, dim3(static_cast<unsigned>((m + rows_per_block - 1) / rows_per_block)),
+                       dim3(kNarrowBlock), 0, stream, p, lpr_out);
+    return check_launch("narrow_outer_kernel");
+  }
   launch_fwd(p, vec, stream);
   return check_launch("dense_fwd_kernel");
 }
@@ -926,7 +1042,11 @@ extern "C" int collie_dense_weight_grad(const collie_dense_operand* dz,
   p.partial = static_cast<float*>(workspace);
   p.status = status;
   const unsigned gz = static_cast<unsigned>((n_out + kWgTile - 1) / kWgTile);
-  if (vec) {
+  const int lpr_x = narrow_lpr(n_in);
+  if (n_out == 1 && lpr_x && narrow_operand(p.dz, 1) && narrow_operand(p.x, n_in)) {
+    hipLaunchKernelGGL(narrow_wgrad_kernel, dim3(static_cast<unsigned>(nchunks)), dim3(kNarrowBlock), 0,
+                       stream, p, lpr_x);
+  } else if (vec) {
     const dim3 grid(static_cast<unsigned>((n_in + kWgTile - 1) / kWgTile), static_cast<unsigned>(nchunks), gz);
     if (p.dz_scalar) hipLaunchKernelGGL(dense_wgrad_fast_kernel<true>, grid, dim3(kWgBlock), 0, stream, p);
     else hipLaunchKernelGGL(dense_wgrad_fast_kernel<false>, grid, dim3(kWgBlock), 0, stream, p);

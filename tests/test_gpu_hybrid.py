@@ -63,6 +63,10 @@ FWD_CASES = [
     (700, [256], [True], [False], 130, False),
     (260, [64], [False], [True], 128, False),
     (129, [7, 9, 1, 2], [True, True, False, True], [False, False, True, False], 1, False),
+    # one output column over an identity operand: the memory-bound GEMV path
+    (5000, [32], [False], [False], 1, False),
+    (777, [256], [False], [False], 1, True),
+    (64, [4], [False], [False], 1, False),
 ]
 
 
@@ -93,6 +97,11 @@ def test_dense_forward_transposed_slice_and_row_bias(dev):
           dz @ w.astype(np.float64))
     close(ops.dense_forward(op, m, wt, None, False, transposed=True, col_range=(20, 61)).cpu().numpy(),
           dz @ w.astype(np.float64)[:, 20:61])
+    # data gradient of a one-column layer (outer product path): dz [m, 1], W [1, 32]
+    g_op, g = _operand_case(rng, m, [1], [False], [False], dev)
+    w32 = rng.normal(size=(1, 32)).astype(np.float32)
+    close(ops.dense_forward(g_op, m, torch.tensor(w32, device=dev), None, False,
+                            transposed=True).cpu().numpy(), g @ w32.astype(np.float64))
     # final layer: Linear(.., 1) + user bias + item bias
     users = rng.integers(0, 50, m)
     items = rng.integers(0, 70, m).astype(np.int32)
@@ -105,6 +114,20 @@ def test_dense_forward_transposed_slice_and_row_bias(dev):
                                     torch.tensor(items, device=dev), torch.tensor(ib, device=dev)))
     ref = dz @ w1.astype(np.float64).T + b1 + ub[users] + ib[items]
     close(y.cpu().numpy(), ref)
+    # the same on the GEMV path (identity operand without a mask), with one id out of range
+    h_op, h = _operand_case(rng, m, [32], [False], [False], dev)
+    w2 = rng.normal(size=(1, 32)).astype(np.float32)
+    bad = users.copy()
+    bad[7] = 50
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    y = ops.dense_forward(h_op, m, torch.tensor(w2, device=dev), torch.tensor(b1, device=dev), False,
+                          row_bias=(torch.tensor(bad, device=dev), torch.tensor(ub, device=dev),
+                                    torch.tensor(items, device=dev), torch.tensor(ib, device=dev)),
+                          status=status)
+    ref = h @ w2.astype(np.float64).T + b1 + ub[users] + ib[items]
+    ref[7] = h[7] @ w2[0].astype(np.float64) + b1
+    close(y.cpu().numpy(), ref)
+    assert int(status.item()) == 1
 
 
 def test_dense_forward_flags_out_of_range_rows(dev):
