@@ -117,6 +117,32 @@ class _FusedLoss(torch.autograd.Function):
         return (None, None, None) + (None,) * 4
 
 
+class _FusedLossTensor(torch.Tensor):
+    """The 0-d loss ``calculate_loss`` returns on the fused route.  It is an ordinary autograd
+    tensor (``grad_fn`` = ``_FusedLoss``: ``loss / 2`` then ``.backward()``, ``torch.autograd.grad``
+    ... go through the engine as usual); only the plain ``loss.backward()`` both trainers issue is
+    answered directly: for this node the engine would do nothing but hand ``grad = 1`` to
+    ``_FusedLoss.backward``, at ~40 us of engine and device-thread hand-off per call -- a third of
+    a launch-bound step at the reference's default batch size."""
+    __torch_function__ = torch._C._disabled_torch_function_impl
+
+    def backward(self, gradient=None, retain_graph=None, create_graph=False, inputs=None):
+        staged = self.__dict__.get('_collie_staged')
+        if (staged is not None and gradient is None and not create_graph and inputs is None
+                and self._backward_hooks is None and not staged.armed
+                and staged.model.__dict__.get('_staged_step') is staged):
+            staged.grad_scale = None        # d loss / d loss = 1: the kernels' default
+            staged.armed = True
+            return None
+        return super().backward(gradient, retain_graph, create_graph, inputs)
+
+
+def _fused_loss(model, staged, loss_value, weights):
+    out = _FusedLoss.apply(model, staged, loss_value, *weights).as_subclass(_FusedLossTensor)
+    out.__dict__['_collie_staged'] = staged
+    return out
+
+
 INTERACTIONS_LIKE_INPUT = Union[ApproximateNegativeSamplingInteractionsDataLoader, Interactions,
                                 InteractionsDataLoader]
 _TABLES = ('user_embeddings', 'item_embeddings', 'user_biases', 'item_biases')
@@ -383,21 +409,27 @@ class MatrixFactorizationModel(nn.Module):
         return groups
 
     # ------------------------------------------------------------------------------- arithmetic
+    def _weights(self):
+        """The four weight Parameters in ``_TABLES`` order, read straight from the module dicts
+        (``nn.Module.__getattr__`` costs more than the launches of a small batch allow)."""
+        m = self._modules
+        return tuple(m[n]._parameters['weight'] for n in _TABLES)
+
     def _tables(self):
         """The four tables as the C struct; rebuilt only when a parameter's storage moved."""
-        ws = (self.user_embeddings.weight, self.item_embeddings.weight, self.user_biases.weight,
-              self.item_biases.weight)
-        key = tuple(w.data_ptr() for w in ws)
-        cached = getattr(self, '_tables_cache', None)
+        ws = self._weights()
+        key = (ws[0].data_ptr(), ws[1].data_ptr(), ws[2].data_ptr(), ws[3].data_ptr())
+        cached = self.__dict__.get('_tables_cache')
         if cached is None or cached[0] != key:
             cached = (key, _lib.make_tables(*(w.data for w in ws)))
-            self._tables_cache = cached
+            self.__dict__['_tables_cache'] = cached
         return cached[1]
 
     def _table_slot(self, param):
-        for name, slot in _SLOTS.items():
-            if getattr(self, name).weight is param:
-                return slot
+        ws = self._weights()
+        for i, name in enumerate(_TABLES):
+            if ws[i] is param:
+                return _SLOTS[name]
         return None
 
     def _status_flag(self):
@@ -412,7 +444,7 @@ class MatrixFactorizationModel(nn.Module):
             raise IndexError('index out of range in self: a user or item id is outside the tables')
 
     def _drop_staged_step(self):
-        self._staged_step = None
+        self.__dict__['_staged_step'] = None    # a plain attribute: skip nn.Module.__setattr__
 
     def forward(self, users: torch.Tensor, items: torch.Tensor) -> torch.Tensor:
         """``matrix_factorization.py:120-159``."""
@@ -469,15 +501,15 @@ class MatrixFactorizationModel(nn.Module):
             raise ValueError(f'Unexpected format for batch: {batch}. See docs for expected format.')
 
     def _fused_calculate_loss(self, users, pos_items, neg_items):
-        dev = self.device
-        _lib.require_hip(self.user_embeddings.weight, 'MatrixFactorizationModel')
+        ws = self._weights()
+        dev = ws[0].device
+        _lib.require_hip(ws[0], 'MatrixFactorizationModel')
         for t in (users, pos_items, neg_items):
             _lib.require_hip(t, 'batch')
-        need_grad = torch.is_grad_enabled() and any(
-            getattr(self, n).weight.requires_grad for n in _TABLES)
+        need_grad = torch.is_grad_enabled() and any(w.requires_grad for w in ws)
         if self._workspace is None:
             self._workspace = ops.TrainWorkspace(dev)
-        self._staged_step = None        # the workspace is about to be overwritten
+        self.__dict__['_staged_step'] = None        # the workspace is about to be overwritten
         B, K = neg_items.shape
         buf = self._workspace.ensure(B, K, self.hparams.embedding_dim, self.hparams.num_users,
                                      self.hparams.num_items)
@@ -488,11 +520,11 @@ class MatrixFactorizationModel(nn.Module):
         codes, weights = self._meta_codes
         tables = self._tables()
         hbatch = ops.make_batch(users, pos_items, neg_items)
-        cfg = getattr(self, '_loss_cfg', None)
+        cfg = self.__dict__.get('_loss_cfg')
         if cfg is None or cfg._key != (self._loss_kind, self.hparams.num_items, id(codes)):
             cfg = ops.make_loss_cfg(self._loss_kind, self.hparams.num_items, codes, weights)
             cfg._key = (self._loss_kind, self.hparams.num_items, id(codes))
-            self._loss_cfg = cfg
+            self.__dict__['_loss_cfg'] = cfg
         loss_value = torch.empty(1, dtype=torch.float32, device=dev)
         step_id = self._workspace.next_step() if need_grad else max(self._workspace.step_id, 1)
         ops.train_forward(tables, hbatch, cfg, buf, need_grad, step_id, loss_value, None, None,
@@ -500,9 +532,8 @@ class MatrixFactorizationModel(nn.Module):
         if not need_grad:
             return loss_value.reshape(())
         staged = _FusedStep(self, tables, hbatch, buf, step_id)
-        self._staged_step = staged
-        weights_ = [getattr(self, n).weight for n in _TABLES]
-        return _FusedLoss.apply(self, staged, loss_value, *weights_)
+        self.__dict__['_staged_step'] = staged
+        return _fused_loss(self, staged, loss_value, ws)
 
     def _fused_explicit_loss(self, users, items, ratings):
         """``base_pipeline.py:635-650`` with ``loss='mse' | 'mae'``: one fused HIP kernel."""
@@ -535,8 +566,7 @@ class MatrixFactorizationModel(nn.Module):
         hbatch._keepalive = (users, items, col, ratings)
         staged = _FusedStep(self, tables, hbatch, buf, step_id, explicit=True)
         self._staged_step = staged
-        weights_ = [getattr(self, n).weight for n in _TABLES]
-        return _FusedLoss.apply(self, staged, loss_value, *weights_)
+        return _fused_loss(self, staged, loss_value, self._weights())
 
     # ------------------------------------------------------------------------------ conveniences
     def _get_item_embeddings(self) -> torch.Tensor:

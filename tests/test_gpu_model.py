@@ -132,6 +132,55 @@ def test_backward_honours_grad_output_and_validation_path(dev):
     assert torch.equal(before, m.item_embeddings.weight.detach())
 
 
+def test_direct_backward_equals_the_autograd_engine_route(dev):
+    """``loss.backward()`` on the fused loss arms the staged step without the autograd engine;
+    ``torch.autograd.backward(loss)`` / ``loss.backward(gradient=1)`` go through the engine.
+    Same tables afterwards, bit for bit; a loss tensor with a hook takes the engine route."""
+    from collie_amd.model import MatrixFactorizationModel
+
+    class Shape:
+        num_users, num_items, num_negative_samples = 100, 80, 5
+
+    rng = np.random.default_rng(4)
+    batch = ((torch.tensor(rng.integers(0, 100, 64), dtype=torch.int32, device=dev),
+              torch.tensor(rng.integers(0, 80, 64), dtype=torch.int32, device=dev)),
+             torch.tensor(rng.integers(0, 80, (64, 5)), device=dev))
+    seen = []
+
+    def run(how):
+        torch.manual_seed(0)
+        m = MatrixFactorizationModel(train=Shape(), embedding_dim=8, sparse=True, lr=1e-2,
+                                     optimizer='sparse_adam', bias_optimizer='sgd', loss='bpr',
+                                     lr_scheduler_func=None).to(dev).train()
+        opts = m.configure_optimizers()
+        for _ in range(3):
+            for o in opts:
+                o.zero_grad()
+            loss = m.calculate_loss(batch)
+            assert loss.requires_grad and loss.grad_fn is not None and loss.dim() == 0
+            if how == 'direct':
+                loss.backward()
+                assert m._staged_step.armed and m._staged_step.grad_scale is None
+            elif how == 'engine':
+                torch.autograd.backward(loss)
+                assert m._staged_step.armed and m._staged_step.grad_scale is not None
+            elif how == 'gradient':
+                loss.backward(gradient=torch.ones((), device=dev))
+                assert m._staged_step.grad_scale is not None
+            else:
+                loss.register_hook(lambda g: seen.append(float(g)))
+                loss.backward()
+            for i, o in enumerate(opts):
+                m.optimizer_step(optimizer=o, optimizer_idx=i)
+        return [getattr(m, n).weight.detach().clone() for n in NAMES]
+
+    want = run('direct')
+    for how in ('engine', 'gradient', 'hook'):
+        for a, b in zip(want, run(how)):
+            assert torch.equal(a, b), how
+    assert seen == [1.0, 1.0, 1.0]
+
+
 def test_generic_route_matches_fused_route(dev):
     """A custom callable loss goes through model(users, items) + autograd + torch's own
     SparseAdam.step (inherited); results must agree with the fused kernels."""
