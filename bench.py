@@ -291,6 +291,18 @@ def main_sharded(args, world, rank, device):
             },
             'roofline': None,
         }
+        fwd_ms = phases.get('forward_backward')
+        if fwd_ms:
+            # rank 0's K1 launch on its compact tables (the phase between the row exchange and the
+            # segment reduce: K1 + loss finalize), same algorithmic bytes as the single-GPU line
+            alg = fwd_algorithmic_bytes(args.batch)
+            achieved = alg / (fwd_ms * 1e-3) / 1e9
+            result['roofline'] = {
+                'kernel': 'mf_train_fwd_lds on rank 0 (sharded route: gathers from the compact row '
+                          'tables the lookup exchange filled), timed as the forward phase',
+                'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                'algorithmic_bytes_per_launch': alg, 'avg_launch_ms': fwd_ms}
         if ev is not None:
             result['eval'] = ev
         print(json.dumps(result))

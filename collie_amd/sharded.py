@@ -126,6 +126,9 @@ class HipEngine:
         cfg = ops.make_loss_cfg(kind, num_items, codes, weights)
         loss = torch.empty(1, dtype=torch.float32, device=self.device)
         ops.train_forward(tables, batch, cfg, buf, True, step_id, loss, None, None, self._status)
+        mark = getattr(self, 'phase_mark', None)
+        if mark is not None:
+            mark('segment_reduce')      # everything before this mark is K1 (+ its loss finalize)
         ops.train_build_segments(tables, batch, buf)
         gemb = torch.zeros(n, D, dtype=torch.float32, device=self.device)
         gbias = torch.zeros(n, dtype=torch.float32, device=self.device)
@@ -445,6 +448,7 @@ class ShardedMatrixFactorizationModel:
         ``phase_times()`` turns them into mean milliseconds per phase.  The only way to see where a
         multi-GPU step spends its time from inside the benchmark (rocprofv3 aside)."""
         self._phase_events = [] if enable else None
+        self.engine.phase_mark = self._phase_mark if enable else None
 
     def _phase_mark(self, name):
         ev = getattr(self, '_phase_events', None)
