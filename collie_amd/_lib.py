@@ -122,6 +122,12 @@ SIGNATURES = {
     'collie_mf_eval_rank_counts': (ctypes.c_int, [POINTER(Tables), c_void_p, c_int64, c_void_p,
                                                   c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                                   c_int64, c_int64, c_int64, c_void_p, c_void_p]),
+    'collie_mf_eval_topk_rank_counts': (ctypes.c_int, [POINTER(Tables), c_void_p, c_int64, c_int64,
+                                                       c_int64, c_int64, c_int64, c_int32, c_int32,
+                                                       c_float, c_float, c_void_p, c_void_p,
+                                                       c_void_p, c_void_p, c_void_p, c_void_p,
+                                                       c_void_p, c_void_p, c_void_p, c_size_t,
+                                                       c_void_p]),
     'collie_embedding_similarity': (ctypes.c_int, [c_void_p, c_int64, c_int32, c_int64, c_void_p,
                                                    c_void_p]),
     'collie_mf_explicit_forward': (ctypes.c_int, [POINTER(Tables), c_void_p, c_int32, c_void_p,

@@ -296,8 +296,11 @@ __device__ __forceinline__ void rank_subtile(const f32x16& acc, const float (&lo
   }
 }
 
+// MODE 2 = MODE 0 and MODE 1 in ONE pass over the catalogue (both epilogues on every sub-tile):
+// `[mapk, mrr, auc]` then costs one GEMM instead of two.
 template <int D8, int MODE>
 __global__ __launch_bounds__(kBlockDma) void eval_gemm_dma_kernel(const EvalParams p) {
+  constexpr bool TOPK = MODE != 1, RANK = MODE != 0;
   constexpr int D = D8 * 8;
   constexpr int CPR = D / 4;                     // 16-byte chunks per row
   constexpr int S = CPR < 16 ? CPR : 16;         // swizzle span
@@ -323,27 +326,30 @@ __global__ __launch_bounds__(kBlockDma) void eval_gemm_dma_kernel(const EvalPara
 #pragma unroll
   for (int q = 0; q < D8; ++q) ufrag[q] = *reinterpret_cast<const f32x4*>(urow + 8 * q + 4 * h);
 
-  float top_s[kCap];
+  float top_s[kCap];   // TOPK: the sorted candidate list
   int top_i[kCap];
+  float thr_l[kCap];   // RANK: (lo, hi) raw-score intervals of the user's first kCap positives
+  int thr_h[kCap];
   unsigned long long c_above = 0, c_lt = 0, c_le = 0, c_below_all = 0;
   int64_t e_begin = 0, e_end = 0;
   float bscore = 0.0f, lo_min = INFINITY, hi_max = -INFINITY;
   int bid = 0;
-  if (MODE == 0) {
+  if (TOPK) {
 #pragma unroll
     for (int i = 0; i < kCap; ++i) {
       top_s[i] = -INFINITY;
       top_i[i] = 0x7fffffff;
     }
-  } else {
-    // the first kThr (lo, hi) threshold pairs of the user's positives live in registers (they take
-    // the place of the top-k list); unused slots hold -inf, which no score is below.  The rare
-    // user with more positives walks the rest of its CSR row per score (lo_min / hi_max bound the
-    // scores that can differ from "below all" / "above all" of that remainder).
+  }
+  if (RANK) {
+    // the first kCap (lo, hi) threshold pairs of the user's positives live in registers; unused
+    // slots hold -inf, which no score is below.  The rare user with more positives walks the rest
+    // of its CSR row per score (lo_min / hi_max bound the scores that can differ from "below all" /
+    // "above all" of that remainder).
 #pragma unroll
     for (int i = 0; i < kCap; ++i) {
-      top_s[i] = -INFINITY;
-      top_i[i] = __float_as_int(-INFINITY);
+      thr_l[i] = -INFINITY;
+      thr_h[i] = __float_as_int(-INFINITY);
     }
     if (user_ok) {
       e_begin = p.indptr[uslot];
@@ -353,8 +359,8 @@ __global__ __launch_bounds__(kBlockDma) void eval_gemm_dma_kernel(const EvalPara
 #pragma unroll
       for (int i = 0; i < kCap; ++i) {
         if (e_begin + i < e_end) {
-          top_s[i] = p.thr_lo[e_begin + i];
-          top_i[i] = __float_as_int(p.thr_hi[e_begin + i]);
+          thr_l[i] = p.thr_lo[e_begin + i];
+          thr_h[i] = __float_as_int(p.thr_hi[e_begin + i]);
         }
       }
       for (int64_t e = e_begin + kCap; e < e_end; ++e) {
@@ -372,7 +378,7 @@ __global__ __launch_bounds__(kBlockDma) void eval_gemm_dma_kernel(const EvalPara
   n_thr = __builtin_amdgcn_readfirstlane(n_thr);
   const bool any_long = __ballot(e_end - e_begin > kCap) != 0ull;
   const int k = p.k;
-  float thr = -INFINITY;  // MODE 0: score of the k-th best candidate so far
+  float thr = -INFINITY;  // TOPK: score of the k-th best candidate so far
 
   const int64_t chunk_items = static_cast<int64_t>(p.tiles_per_chunk) * kTileItems;
   const int64_t chunk_begin = p.item_begin + static_cast<int64_t>(blockIdx.y) * chunk_items;
@@ -412,7 +418,7 @@ __global__ __launch_bounds__(kBlockDma) void eval_gemm_dma_kernel(const EvalPara
     const float* tile_bias = reinterpret_cast<const float*>(tile + kTileF4);
     const bool full = base + kTileItems <= chunk_end;
 
-    // MODE 1 keeps one sub-tile live at a time (its epilogue holds 32 threshold registers)
+    // RANK keeps one sub-tile live at a time (its epilogue holds 32 threshold registers)
 #pragma unroll MODE == 0 ? 2 : 1
     for (int sub = 0; sub < kTileItems / 32; ++sub) {
       f32x16 acc;
@@ -450,10 +456,11 @@ __global__ __launch_bounds__(kBlockDma) void eval_gemm_dma_kernel(const EvalPara
         for (int rr = 0; rr < 16; ++rr) {
           const int row = sub * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
           // masked rows: -inf never enters a top-k list; NaN fails every rank-count comparison
+          // (and every top-k comparison in the fused mode: fmaxf drops it, `> thr` is false)
           if (base + row >= chunk_end) acc[rr] = MODE == 0 ? -INFINITY : __builtin_nanf("");
         }
       }
-      if (MODE == 0) {
+      if (TOPK) {
 #pragma unroll
         for (int rr = 0; rr < 16; ++rr) smax = fmaxf(smax, acc[rr]);
         if (smax > thr) {
@@ -479,14 +486,15 @@ __global__ __launch_bounds__(kBlockDma) void eval_gemm_dma_kernel(const EvalPara
             }
           }
         }
-      } else {
+      }
+      if (RANK) {
         // 32-bit counters per sub-tile (at most 16 * kCap increments), folded into the 64-bit ones
         uint32_t t_above = 0, t_lt = 0, t_le = 0;
         const int64_t gid0 = (base + sub * 32 + 4 * h) * p.id_stride + p.id_offset;
-        if (n_thr <= 4) rank_subtile<4>(acc, top_s, top_i, bscore, bid, gid0, p.id_stride, t_above, t_lt, t_le);
-        else if (n_thr <= 8) rank_subtile<8>(acc, top_s, top_i, bscore, bid, gid0, p.id_stride, t_above, t_lt, t_le);
-        else if (n_thr <= 12) rank_subtile<12>(acc, top_s, top_i, bscore, bid, gid0, p.id_stride, t_above, t_lt, t_le);
-        else rank_subtile<kCap>(acc, top_s, top_i, bscore, bid, gid0, p.id_stride, t_above, t_lt, t_le);
+        if (n_thr <= 4) rank_subtile<4>(acc, thr_l, thr_h, bscore, bid, gid0, p.id_stride, t_above, t_lt, t_le);
+        else if (n_thr <= 8) rank_subtile<8>(acc, thr_l, thr_h, bscore, bid, gid0, p.id_stride, t_above, t_lt, t_le);
+        else if (n_thr <= 12) rank_subtile<12>(acc, thr_l, thr_h, bscore, bid, gid0, p.id_stride, t_above, t_lt, t_le);
+        else rank_subtile<kCap>(acc, thr_l, thr_h, bscore, bid, gid0, p.id_stride, t_above, t_lt, t_le);
         // the sub-tile counts stay 32-bit (without this the compiler accumulates every compare
         // straight into the 64-bit counters: a v_lshl_add_u64 per compare)
         asm volatile("" : "+v"(t_above), "+v"(t_lt), "+v"(t_le));
@@ -513,7 +521,7 @@ __global__ __launch_bounds__(kBlockDma) void eval_gemm_dma_kernel(const EvalPara
   }
 
   if (!user_ok) return;
-  if (MODE == 0) {
+  if (TOPK) {
     const int nslots = p.nchunks * 2;
     const int64_t slot = uslot * nslots + blockIdx.y * 2 + h;
 #pragma unroll
@@ -521,7 +529,8 @@ __global__ __launch_bounds__(kBlockDma) void eval_gemm_dma_kernel(const EvalPara
       p.cand_scores[slot * kCap + i] = i < k ? top_s[i] : -INFINITY;
       p.cand_ids[slot * kCap + i] = i < k ? top_i[i] : 0x7fffffff;
     }
-  } else {
+  }
+  if (RANK) {
     const unsigned long long npos =
         e_end - e_begin > kCap ? static_cast<unsigned long long>(e_end - e_begin - kCap) : 0ull;
     atomicAdd(&p.counts[uslot * 3 + 0], c_above);
@@ -778,6 +787,10 @@ int launch_gemm(hipStream_t stream, EvalParams& p) {
     }
     return check_launch("eval_gemm_dma_kernel");
   }
+  if constexpr (MODE == 2) {
+    set_error("the fused top-k + rank-count pass exists for the LDS-DMA kernel only");
+    return -1;
+  } else {
   const EvalGeom g = eval_geom(p.n_users, n_items, kUsersPerBlock);
   p.nchunks = g.nchunks;
   p.tiles_per_chunk = g.tiles_per_chunk;
@@ -795,6 +808,7 @@ int launch_gemm(hipStream_t stream, EvalParams& p) {
       return -1;
   }
   return check_launch("eval_gemm_kernel");
+  }
 }
 
 int check_range(const collie_mf_tables* t, int64_t n_users, int64_t item_begin, int64_t item_end) {
@@ -926,6 +940,54 @@ extern "C" int collie_mf_eval_rank_counts(const collie_mf_tables* t, const int64
   p.best_id = best_id;
   p.counts = reinterpret_cast<unsigned long long*>(counts);
   return launch_gemm<1>(stream, p);
+}
+
+extern "C" int collie_mf_eval_topk_rank_counts(
+    const collie_mf_tables* t, const int64_t* user_ids, int64_t n_users, int64_t item_begin,
+    int64_t item_end, int64_t id_stride, int64_t id_offset, int32_t k, int32_t has_y_range,
+    float y_lo, float y_hi, const int64_t* indptr, const float* thr_lo, const float* thr_hi,
+    const float* best_score, const int64_t* best_id, float* topk_scores, int64_t* topk_ids,
+    uint64_t* counts, void* workspace, size_t workspace_bytes, collie_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (validate_tables(t) || check_range(t, n_users, item_begin, item_end)) return -1;
+  COLLIE_REQUIRE(user_ids && topk_scores && topk_ids && indptr && thr_lo && thr_hi && best_score &&
+                     best_id && counts, "eval_topk_rank_counts: NULL pointer");
+  COLLIE_REQUIRE(k >= 1 && k <= kCap, "eval_topk: k must be in [1, %d] (got %d)", kCap, k);
+  COLLIE_REQUIRE(id_stride >= 1 && id_offset >= 0 &&
+                     (item_end - 1) * id_stride + id_offset < (int64_t{1} << 31),
+                 "eval_topk: bad global id mapping");
+  COLLIE_REQUIRE(k <= item_end - item_begin, "eval_topk: k (%d) exceeds the number of items", k);
+  EvalWs ws = carve_eval_ws(workspace, n_users, item_end - item_begin);
+  COLLIE_REQUIRE(workspace && workspace_bytes >= ws.bytes,
+                 "eval workspace too small: need %zu bytes, got %zu", ws.bytes, workspace_bytes);
+  EvalParams p;
+  memset(&p, 0, sizeof(p));
+  p.t = *t;
+  p.user_ids = user_ids;
+  p.n_users = n_users;
+  p.item_begin = item_begin;
+  p.item_end = item_end;
+  p.id_stride = id_stride;
+  p.id_offset = id_offset;
+  p.k = k;
+  p.cand_scores = ws.cand_scores;
+  p.cand_ids = ws.cand_ids;
+  p.indptr = indptr;
+  p.thr_lo = thr_lo;
+  p.thr_hi = thr_hi;
+  p.best_score = best_score;
+  p.best_id = best_id;
+  p.counts = reinterpret_cast<unsigned long long*>(counts);
+  if (dma_ok(&p.t)) {
+    if (launch_gemm<2>(stream, p)) return -1;     // one pass: both epilogues
+  } else {
+    if (launch_gemm<0>(stream, p)) return -1;     // register-staged kernel: two passes
+    if (launch_gemm<1>(stream, p)) return -1;
+  }
+  hipLaunchKernelGGL(merge_topk_kernel, dim3(static_cast<unsigned>((n_users + kWaves - 1) / kWaves)),
+                     dim3(kBlock), 0, stream, ws.cand_scores, ws.cand_ids, n_users, p.nchunks * 2,
+                     k, has_y_range, y_lo, y_hi, topk_scores, topk_ids);
+  return check_launch("merge_topk_kernel");
 }
 
 extern "C" int collie_mf_eval_metrics(const int64_t* topk_ids, int32_t k, int64_t n_users,

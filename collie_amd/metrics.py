@@ -87,16 +87,19 @@ def _per_user(tables, user_slots, indptr, indices, n_items, k, y_range, want, ws
     n = user_slots.shape[0]
     lo_i, hi_i = item_range if item_range is not None else (0, n_items)
     ws = ws or ops.EvalWorkspace(dev)
-    topk_ids = None
-    if want_ap:
-        _, topk_ids = ops.eval_topk(tables, user_slots, lo_i, hi_i, k, y_range, ws)
-    pos = counts = None
+    topk_ids = pos = counts = None
     if want_rr or want_auc:
         pos, lo, hi, best_s, best_id = ops.eval_pos_scores(tables, user_slots, indptr, indices,
                                                            y_range, True)
         counts = torch.zeros(n, 3, dtype=torch.int64, device=dev)
-        ops.eval_rank_counts(tables, user_slots, indptr, lo, hi, best_s, best_id, lo_i, hi_i,
-                             counts)
+        if want_ap:     # top-k and rank counts share one pass over the catalogue
+            _, topk_ids = ops.eval_topk_rank_counts(tables, user_slots, indptr, lo, hi, best_s,
+                                                    best_id, lo_i, hi_i, k, y_range, counts, ws)
+        else:
+            ops.eval_rank_counts(tables, user_slots, indptr, lo, hi, best_s, best_id, lo_i, hi_i,
+                                 counts)
+    elif want_ap:
+        _, topk_ids = ops.eval_topk(tables, user_slots, lo_i, hi_i, k, y_range, ws)
     return ops.eval_metrics(topk_ids, k, n, n_items, indptr, indices, pos, counts, y_range,
                             want_ap, want_rr, want_auc)
 

@@ -526,6 +526,24 @@ def eval_rank_counts(tables, user_ids, indptr, lo, hi, best_s, best_id, item_beg
         'collie_mf_eval_rank_counts')
 
 
+def eval_topk_rank_counts(tables, user_ids, indptr, lo, hi, best_s, best_id, item_begin, item_end,
+                          k, y_range, counts, ws, id_stride=1, id_offset=0):
+    """``eval_topk`` and ``eval_rank_counts`` in one pass over the items (one scoring GEMM)."""
+    require_hip(user_ids, 'user_ids')
+    assert user_ids.dtype == torch.int64 and user_ids.is_contiguous()
+    n = user_ids.shape[0]
+    dev = user_ids.device
+    buf = ws.ensure(n, item_end - item_begin)
+    scores = torch.empty(n, k, dtype=torch.float32, device=dev)
+    ids = torch.empty(n, k, dtype=torch.int64, device=dev)
+    has_y, ylo, yhi = _y(y_range)
+    check(load().collie_mf_eval_topk_rank_counts(
+        byref(tables), ptr(user_ids), n, item_begin, item_end, id_stride, id_offset, k, has_y, ylo,
+        yhi, ptr(indptr), ptr(lo), ptr(hi), ptr(best_s), ptr(best_id), ptr(scores), ptr(ids),
+        ptr(counts), ptr(buf), buf.numel(), stream_ptr()), 'collie_mf_eval_topk_rank_counts')
+    return scores, ids
+
+
 def eval_metrics(topk_ids, k, n_users, n_items, indptr, indices, pos_scores, counts, y_range,
                  want_ap, want_rr, want_auc):
     dev = indptr.device

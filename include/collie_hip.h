@@ -316,6 +316,21 @@ int collie_mf_eval_rank_counts(const collie_mf_tables* t, const int64_t* user_id
                                int64_t id_stride, int64_t id_offset, uint64_t* counts,
                                collie_stream_t stream);
 
+/* collie_mf_eval_topk and collie_mf_eval_rank_counts of the same users and item range in ONE pass
+ * over the catalogue: `evaluate_in_batches([mapk, mrr, auc], ...)` (metrics.py:379-384 calls every
+ * metric on the same score matrix) then pays for one scoring GEMM instead of two.  Same outputs,
+ * bit for bit, as the two calls; the thresholds come from collie_mf_eval_pos_scores, which needs no
+ * top-k.  Shapes the LDS-DMA kernel does not cover run the two passes internally. */
+int collie_mf_eval_topk_rank_counts(const collie_mf_tables* t, const int64_t* user_ids,
+                                    int64_t n_users, int64_t item_begin, int64_t item_end,
+                                    int64_t id_stride, int64_t id_offset, int32_t k,
+                                    int32_t has_y_range, float y_lo, float y_hi,
+                                    const int64_t* indptr, const float* thr_lo,
+                                    const float* thr_hi, const float* best_score,
+                                    const int64_t* best_id, float* topk_scores, int64_t* topk_ids,
+                                    uint64_t* counts, void* workspace, size_t workspace_bytes,
+                                    collie_stream_t stream);
+
 /* Per-user AP@k (float64, metrics.py:178-196), reciprocal rank (fp32, :237-238) and tie-averaged
  * AUC of sigmoid(preds) (:266-280) from the top-k ids and the rank counts.  Any of ap / rr / auc
  * may be NULL. */

@@ -168,6 +168,61 @@ def test_topk_ids_exact_on_exactly_representable_scores(dev, D, N, U, k):
     np.testing.assert_allclose(au.cpu().numpy(), O.auc_per_user(csr, users, preds), rtol=1e-6)
 
 
+@pytest.mark.parametrize('D,N,U,k,stride,y_range', [
+    (128, 70001, 600, 10, 1, None), (64, 5003, 300, 16, 1, None), (32, 4100, 700, 7, 1, (0.0, 5.0)),
+    (128, 3000, 130, 10, 3, None),           # a catalogue shard: global id = 3 * row + 1
+    (10, 1682, 943, 10, 1, None),            # not an LDS-DMA shape: two passes inside the call
+])
+def test_fused_topk_and_rank_counts_equal_the_two_passes(dev, D, N, U, k, stride, y_range):
+    """collie_mf_eval_topk_rank_counts against collie_mf_eval_topk + collie_mf_eval_rank_counts:
+    ids, scores and the three rank counters bit for bit (ragged last tile, users with 0 ... 40
+    positives, i.e. beyond the 16 register-resident threshold pairs)."""
+    from oracle import mf_oracle as O
+    from collie_amd import ops
+    from collie_amd.metrics import _csr_slice
+    rng = np.random.default_rng(D * 7 + N)
+    tables = O.init_tables(U, N, D, rng)
+    tables['item_biases'] = rng.normal(0, 0.01, (N, 1)).astype(np.float32)
+    tables['item_embeddings'] *= 20.0
+    model = make_model(tables, dev)
+    t = model._tables()
+    users = np.sort(rng.choice(U, min(U, 520), replace=False))
+    n = len(users)
+    slots = torch.tensor(users, dtype=torch.int64, device=dev)
+    off = 1 if stride > 1 else 0
+    n_global = N * stride + off
+    nnz_per_user = rng.integers(0, 41, n)
+    nnz_per_user[:3] = (0, 1, 40)
+    rows = np.repeat(users, nnz_per_user)
+    cols = np.concatenate([rng.choice(N, c, replace=False) * stride + off for c in nnz_per_user])
+    csr = sp.coo_matrix((np.ones(len(rows)), (rows, cols)), shape=(U, n_global)).tocsr()
+    indptr, indices = _csr_slice(csr, users, dev)
+    ws = ops.EvalWorkspace(dev)
+    pos, lo, hi, best_s, best_id = ops.eval_pos_scores(t, slots, indptr, indices, y_range, True,
+                                                       id_stride=stride, id_offset=off)
+    s_ref, i_ref = ops.eval_topk(t, slots, 0, N, k, y_range, ws, id_stride=stride, id_offset=off)
+    c_ref = torch.zeros(n, 3, dtype=torch.int64, device=dev)
+    ops.eval_rank_counts(t, slots, indptr, lo, hi, best_s, best_id, 0, N, c_ref, id_stride=stride,
+                         id_offset=off)
+    c_got = torch.zeros(n, 3, dtype=torch.int64, device=dev)
+    s_got, i_got = ops.eval_topk_rank_counts(t, slots, indptr, lo, hi, best_s, best_id, 0, N, k,
+                                             y_range, c_got, ws, id_stride=stride, id_offset=off)
+    assert torch.equal(i_got, i_ref)
+    assert torch.equal(s_got, s_ref)
+    assert torch.equal(c_got, c_ref)
+    assert int(c_ref.sum()) > 0
+    # a sub-range of the items (what one rank of a contiguous catalogue split would run)
+    a, b = N // 3, N - 5
+    s_ref, i_ref = ops.eval_topk(t, slots, a, b, k, y_range, ws, id_stride=stride, id_offset=off)
+    c_ref.zero_()
+    ops.eval_rank_counts(t, slots, indptr, lo, hi, best_s, best_id, a, b, c_ref, id_stride=stride,
+                         id_offset=off)
+    c_got.zero_()
+    s_got, i_got = ops.eval_topk_rank_counts(t, slots, indptr, lo, hi, best_s, best_id, a, b, k,
+                                             y_range, c_got, ws, id_stride=stride, id_offset=off)
+    assert torch.equal(i_got, i_ref) and torch.equal(s_got, s_ref) and torch.equal(c_got, c_ref)
+
+
 def test_positive_scores_are_bit_identical_to_gemm_scores(dev):
     """The fmaf-chain restatement of the MFMA order: each user's top-1 item scored as a
     'positive' must reproduce the GEMM's score bit for bit (random real-valued embeddings)."""
