@@ -189,6 +189,18 @@ class HipEngine:
                              stride, offset)
         return counts
 
+    def shard_topk_rank_counts(self, utile, ubias, iemb, ibias, stride, offset, k, indptr, thr):
+        """``shard_topk`` and ``shard_rank_counts`` in one pass over the shard."""
+        n = utile.shape[0]
+        slots = torch.arange(n, dtype=torch.int64, device=self.device)
+        t = self._eval_tables(utile, ubias, iemb, ibias)
+        counts = torch.zeros(n, 3, dtype=torch.int64, device=self.device)
+        lo, hi, best_s, best_id = thr
+        top = ops.eval_topk_rank_counts(t, slots, indptr, lo, hi, best_s, best_id, 0,
+                                        iemb.shape[0], k, None, counts, self._eval_ws, stride,
+                                        offset)
+        return top, counts
+
     def metrics(self, topk_ids, k, n_users, n_items, indptr, indices, pos, counts, y_range, want):
         return ops.eval_metrics(topk_ids, k, n_users, n_items, indptr, indices, pos, counts,
                                 y_range, *want)
@@ -585,10 +597,21 @@ class ShardedMatrixFactorizationModel:
         want_ap, want_rr, want_auc = want
         utile, ubias = self._user_tile(uids)
         iemb, ibias = self.item_embeddings, self.item_biases
-        topk_ids = None
+        topk_ids = pos = counts = shard_top = None
+        if want_rr or want_auc:
+            pos = eng.shard_pos_scores(utile, ubias, iemb, ibias, G, rank, indptr, indices)
+            comm.all_reduce(pos)
+            thr = eng.thresholds(utile, ubias, iemb, ibias, indptr, indices, pos, y)
+            fused = getattr(eng, 'shard_topk_rank_counts', None)
+            if want_ap and fused is not None:   # one pass over the shard for both
+                shard_top, counts = fused(utile, ubias, iemb, ibias, G, rank, k, indptr, thr)
+            else:
+                counts = eng.shard_rank_counts(utile, ubias, iemb, ibias, G, rank, indptr, thr)
+            comm.all_reduce(counts)
         if want_ap:
             cap = ops.eval_topk_capacity() if eng.name == 'hip' else 16
-            s, i = eng.shard_topk(utile, ubias, iemb, ibias, G, rank, k)
+            s, i = shard_top if shard_top is not None else eng.shard_topk(
+                utile, ubias, iemb, ibias, G, rank, k)
             parts_s, parts_i = comm.all_gather(s), comm.all_gather(i.to(torch.int32))
             cs = torch.full((n, G, cap), float('-inf'), dtype=torch.float32, device=self.device)
             ci = torch.full((n, G, cap), _I31, dtype=torch.int32, device=self.device)
@@ -596,13 +619,6 @@ class ShardedMatrixFactorizationModel:
                 cs[:, r, :k] = parts_s[r]
                 ci[:, r, :k] = parts_i[r]
             topk_ids = eng.merge_topk(cs, ci, k)
-        pos = counts = None
-        if want_rr or want_auc:
-            pos = eng.shard_pos_scores(utile, ubias, iemb, ibias, G, rank, indptr, indices)
-            comm.all_reduce(pos)
-            thr = eng.thresholds(utile, ubias, iemb, ibias, indptr, indices, pos, y)
-            counts = eng.shard_rank_counts(utile, ubias, iemb, ibias, G, rank, indptr, thr)
-            comm.all_reduce(counts)
         return eng.metrics(topk_ids, k, n, N, indptr, indices, pos, counts, y, want)
 
     def evaluate_in_batches(self, metric_list: Iterable, test_interactions, k: int = 10,
