@@ -491,10 +491,18 @@ __global__ __launch_bounds__(kBlockDma) void eval_gemm_dma_kernel(const EvalPara
         // 32-bit counters per sub-tile (at most 16 * kCap increments), folded into the 64-bit ones
         uint32_t t_above = 0, t_lt = 0, t_le = 0;
         const int64_t gid0 = (base + sub * 32 + 4 * h) * p.id_stride + p.id_offset;
-        if (n_thr <= 4) rank_subtile<4>(acc, thr_l, thr_h, bscore, bid, gid0, p.id_stride, t_above, t_lt, t_le);
-        else if (n_thr <= 8) rank_subtile<8>(acc, thr_l, thr_h, bscore, bid, gid0, p.id_stride, t_above, t_lt, t_le);
-        else if (n_thr <= 12) rank_subtile<12>(acc, thr_l, thr_h, bscore, bid, gid0, p.id_stride, t_above, t_lt, t_le);
-        else rank_subtile<kCap>(acc, thr_l, thr_h, bscore, bid, gid0, p.id_stride, t_above, t_lt, t_le);
+#define COLLIE_RANK_TIER(N_) \
+  rank_subtile<N_>(acc, thr_l, thr_h, bscore, bid, gid0, p.id_stride, t_above, t_lt, t_le)
+        // tiers of two threshold pairs: the counting is VALU-bound, every unused pair costs
+        if (n_thr <= 8) {
+          if (n_thr <= 4) { if (n_thr <= 2) COLLIE_RANK_TIER(2); else COLLIE_RANK_TIER(4); }
+          else { if (n_thr <= 6) COLLIE_RANK_TIER(6); else COLLIE_RANK_TIER(8); }
+        } else if (n_thr <= 12) {
+          if (n_thr <= 10) COLLIE_RANK_TIER(10); else COLLIE_RANK_TIER(12);
+        } else {
+          if (n_thr <= 14) COLLIE_RANK_TIER(14); else COLLIE_RANK_TIER(kCap);
+        }
+#undef COLLIE_RANK_TIER
         // the sub-tile counts stay 32-bit (without this the compiler accumulates every compare
         // straight into the 64-bit counters: a v_lshl_add_u64 per compare)
         asm volatile("" : "+v"(t_above), "+v"(t_lt), "+v"(t_le));
