@@ -16,6 +16,7 @@ The callables below then reduce that dense matrix with the same HIP kernels
 (``collie_dense_*``), so no stock torch arithmetic is involved there either.
 """
 import warnings
+from functools import partial
 from typing import Any, Callable, Iterable, List, Optional
 
 import numpy as np
@@ -81,13 +82,23 @@ def _dense_tables(preds: torch.Tensor):
 
 def _per_user(tables, user_slots, indptr, indices, n_items, k, y_range, want, ws=None,
               item_range=None):
-    """Per-user (ap, rr, auc) device tensors for one launch-sized group of users."""
+    """Per-user (ap, rr, auc) device tensors for one launch-sized group of users.  ``indptr`` may
+    be a callable returning ``(indptr, indices)``: MAP@k alone needs the CSR rows only after the
+    scoring pass, so the host slices them while the GPU scores."""
     want_ap, want_rr, want_auc = want
     dev = user_slots.device
     n = user_slots.shape[0]
     lo_i, hi_i = item_range if item_range is not None else (0, n_items)
     ws = ws or ops.EvalWorkspace(dev)
     topk_ids = pos = counts = None
+    if callable(indptr):
+        if want_ap and not (want_rr or want_auc):
+            _, topk_ids = ops.eval_topk(tables, user_slots, lo_i, hi_i, k, y_range, ws)
+            want_ap = False             # done; the launch is in flight while the CSR is sliced
+        indptr, indices = indptr()
+        if topk_ids is not None:
+            return ops.eval_metrics(topk_ids, k, n, n_items, indptr, indices, None, None, y_range,
+                                    True, False, False)
     if want_rr or want_auc:
         pos, lo, hi, best_s, best_id = ops.eval_pos_scores(tables, user_slots, indptr, indices,
                                                            y_range, True)
@@ -159,6 +170,28 @@ def _batch_mean(name, values):
     return float(values.astype(np.float32).mean(dtype=np.float32))      # fp32 tensors (:280-282)
 
 
+def _weighted_batch_sum(name, values, batch_size):
+    """``sum_b metric(batch b) * len(batch b)`` over consecutive batches of ``batch_size`` users,
+    i.e. the accumulation of ``metrics.py:379-384``, without a Python iteration per batch: row means
+    of the [batches, batch_size] view (numpy reduces each contiguous row exactly as it reduces the
+    1-d slice ``_batch_mean`` sees), scaled in float64 and added left to right (``cumsum``) like the
+    reference's ``+=``.  Bit-identical to the loop (tested)."""
+    n = len(values)
+    nb = n // batch_size
+    total = 0.0
+    if nb > 0:
+        head = values[:nb * batch_size]
+        if name == 'ap':
+            means = head.reshape(nb, batch_size).mean(axis=1)
+        else:
+            means = head.astype(np.float32).reshape(nb, batch_size).mean(axis=1, dtype=np.float32)
+        total = float(np.cumsum(means.astype(np.float64) * batch_size)[-1])
+    if nb * batch_size < n:
+        tail = values[nb * batch_size:]
+        total += _batch_mean(name, tail) * len(tail)
+    return total
+
+
 def evaluate_in_batches(
     metric_list: Iterable[Callable[..., float]],
     test_interactions: Interactions,
@@ -179,7 +212,6 @@ def evaluate_in_batches(
     model._move_any_external_data_to_device()
 
     test_users = _unique_users(test_interactions)
-    targets = test_interactions.mat.tocsr()
     n_items = test_interactions.num_items
     if len(test_users) < batch_size:
         batch_size = len(test_users)
@@ -201,25 +233,28 @@ def evaluate_in_batches(
         y = tuple(y) if y is not None else None
         ws = ops.EvalWorkspace(torch.device(device) if not isinstance(device, torch.device) else device)
         per_user = {n: [] for n in ('ap', 'rr', 'auc')}
+        csr = []                        # test_interactions.mat.tocsr(), built on first use
+
+        def csr_rows(group, dev):
+            if not csr:
+                csr.append(test_interactions.mat.tocsr())
+            return _csr_slice(csr[0], group, dev)
+
         with torch.no_grad():
             for s in range(0, len(test_users), USERS_PER_LAUNCH):
                 group = test_users[s:s + USERS_PER_LAUNCH]
                 slots = torch.from_numpy(group.astype(np.int64)).to(tables_device(model))
-                indptr, indices = _csr_slice(targets, group, slots.device)
-                ap, rr, au = _per_user(tables, slots, indptr, indices, n_items, k, y, want, ws)
+                ap, rr, au = _per_user(tables, slots, partial(csr_rows, group, slots.device), None,
+                                       n_items, k, y, want, ws)
                 for n, v in (('ap', ap), ('rr', rr), ('auc', au)):
                     if v is not None:
                         per_user[n].append(v)
         host = {n: torch.cat(v).cpu().numpy() for n, v in per_user.items() if v}
         if was_training:
             model.train()
-        accumulators = [0] * len(metric_list)
-        for i in range(int(np.ceil(len(test_users) / batch_size))):
-            sl = slice(i * batch_size, (i + 1) * batch_size)
-            for j, name in enumerate(names):
-                vals = host[name][sl]
-                accumulators[j] += _batch_mean(name, vals) * len(vals)
+        accumulators = [_weighted_batch_sum(name, host[name], batch_size) for name in names]
     else:
+        targets = test_interactions.mat.tocsr()
         accumulators = [0] * len(metric_list)
         for i in range(int(np.ceil(len(test_users) / batch_size))):
             user_range = test_users[i * batch_size:(i + 1) * batch_size]

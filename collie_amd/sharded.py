@@ -657,11 +657,6 @@ class ShardedMatrixFactorizationModel:
                 if v is not None:
                     per_user[nm].append(v)
         host = {nm: torch.cat(v).cpu().numpy() for nm, v in per_user.items() if v}
-        acc = [0] * len(metric_list)
-        for i in range(int(np.ceil(len(test_users) / batch_size))):
-            sl = slice(i * batch_size, (i + 1) * batch_size)
-            for j, nm in enumerate(names):
-                vals = host[nm][sl]
-                acc[j] += M._batch_mean(nm, vals) * len(vals)
+        acc = [M._weighted_batch_sum(nm, host[nm], batch_size) for nm in names]
         scores = [a / len(test_users) for a in acc]
         return scores[0] if len(scores) == 1 else scores

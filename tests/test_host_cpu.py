@@ -468,3 +468,23 @@ def test_ctypes_prototypes_match_the_header():
                 if not is_float:
                     wide = any(t in decl for t in ('int64_t', 'size_t', 'uint64_t'))
                     assert wide == (ctypes.sizeof(ct) == 8), f'{name}: "{decl}" vs {ct}'
+
+
+def test_vectorised_batch_accumulation_equals_the_reference_loop():
+    """evaluate_in_batches accumulates ``metric(batch) * len(batch)`` batch by batch
+    (metrics.py:379-384); ``_weighted_batch_sum`` must reproduce that loop bit for bit."""
+    from collie_amd.metrics import _batch_mean, _weighted_batch_sum
+    rng = np.random.default_rng(0)
+    for name in ('ap', 'rr', 'auc'):
+        for n in (1, 19, 20, 21, 400, 65536, 70001):
+            for bs in (1, 2, 7, 20, 33, 128, 200, 1000):
+                if bs > n:
+                    continue
+                v = rng.random(n)
+                if name == 'rr':
+                    v = v.astype(np.float32)
+                acc = 0
+                for i in range(int(np.ceil(n / bs))):
+                    vals = v[i * bs:(i + 1) * bs]
+                    acc += _batch_mean(name, vals) * len(vals)
+                assert _weighted_batch_sum(name, v, bs) == acc, (name, n, bs)
