@@ -598,6 +598,10 @@ class ShardedMatrixFactorizationModel:
         utile, ubias = self._user_tile(uids)
         iemb, ibias = self.item_embeddings, self.item_biases
         topk_ids = pos = counts = shard_top = None
+        if callable(indptr):    # lazy CSR rows: MAP@k alone needs them only after the scoring pass
+            if want_ap and not (want_rr or want_auc):
+                shard_top = eng.shard_topk(utile, ubias, iemb, ibias, G, rank, k)
+            indptr, indices = indptr()
         if want_rr or want_auc:
             pos = eng.shard_pos_scores(utile, ubias, iemb, ibias, G, rank, indptr, indices)
             comm.all_reduce(pos)
@@ -644,15 +648,21 @@ class ShardedMatrixFactorizationModel:
         if want[0] and (k > 16 or k > self.N_loc):
             raise ValueError(f'k={k} must not exceed 16 or the smallest item shard ({self.N_loc})')
         test_users = M._unique_users(test_interactions)
-        targets = test_interactions.mat.tocsr()
+        csr = []
+
+        def targets():                  # built on first use, i.e. under the first scoring launch
+            if not csr:
+                csr.append(test_interactions.mat.tocsr())
+            return csr[0]
+
         if len(test_users) < batch_size:
             batch_size = len(test_users)
         per_user = {nm: [] for nm in ('ap', 'rr', 'auc')}
         for s in range(0, len(test_users), users_per_launch):
             group = test_users[s:s + users_per_launch]
             uids = torch.from_numpy(group.astype(np.int64)).to(self.device)
-            indptr, indices = M._csr_slice(targets, group, self.device)
-            ap, rr, au = self.per_user_metrics(uids, indptr, indices, k, want)
+            ap, rr, au = self.per_user_metrics(
+                uids, lambda g=group: M._csr_slice(targets(), g, self.device), None, k, want)
             for nm, v in (('ap', ap), ('rr', rr), ('auc', au)):
                 if v is not None:
                     per_user[nm].append(v)
