@@ -287,10 +287,12 @@ __device__ __forceinline__ void rank_subtile(const f32x16& acc, const float (&lo
                                              const int (&hi)[kCap], float bscore, int bid,
                                              int64_t gid0, int64_t id_stride, uint32_t& t_above,
                                              uint32_t& t_lt, uint32_t& t_le) {
+  // global ids fit 31 bits (checked by the entry points): 32-bit id arithmetic for the tie-break
+  const int g0 = static_cast<int>(gid0), st = static_cast<int>(id_stride);
 #pragma unroll
   for (int rr = 0; rr < 16; ++rr) {
     const float s = acc[rr];
-    const int64_t gid = gid0 + ((rr & 3) + 8 * (rr >> 2)) * id_stride;
+    const int gid = g0 + ((rr & 3) + 8 * (rr >> 2)) * st;
     t_above += (s > bscore || (s == bscore && gid < bid)) ? 1u : 0u;
     count_thr<N>(s, lo, hi, t_lt, t_le);
   }
@@ -931,6 +933,9 @@ extern "C" int collie_mf_eval_rank_counts(const collie_mf_tables* t, const int64
   if (validate_tables(t) || check_range(t, n_users, item_begin, item_end)) return -1;
   COLLIE_REQUIRE(user_ids && indptr && thr_lo && thr_hi && best_score && best_id && counts,
                  "eval_rank_counts: NULL pointer");
+  COLLIE_REQUIRE(id_stride >= 1 && id_offset >= 0 &&
+                     (item_end - 1) * id_stride + id_offset < (int64_t{1} << 31),
+                 "eval_rank_counts: bad global id mapping");
   EvalParams p;
   memset(&p, 0, sizeof(p));
   p.t = *t;
