@@ -264,3 +264,34 @@ def test_evaluate_in_batches_vs_oracle_ml100k_shape(dev):
     got = evaluate_in_batches([mapk, mrr, auc], test, model, k=10, batch_size=64, verbose=False)
     ref = O.evaluate_in_batches([O.mapk, O.mrr, O.auc], test.mat, tables, k=10, batch_size=64)
     np.testing.assert_allclose(got, ref, rtol=1e-5)
+    # every subset of the metrics takes its own route through the evaluator (MAP alone: scoring
+    # launch before the CSR rows; MRR / AUC alone: rank counts only; together: the fused pass) and
+    # must return the same numbers
+    assert evaluate_in_batches([mapk], test, model, k=10, batch_size=64, verbose=False) == got[0]
+    assert evaluate_in_batches([mrr], test, model, k=10, batch_size=64, verbose=False) == got[1]
+    assert evaluate_in_batches([auc], test, model, k=10, batch_size=64, verbose=False) == got[2]
+    assert evaluate_in_batches([auc, mapk], test, model, k=10, batch_size=64,
+                               verbose=False) == [got[2], got[0]]
+
+
+def test_evaluate_in_batches_metric_subsets_agree_on_dma_shape(dev):
+    """The same on a shape the LDS-DMA kernel serves (D = 64), where the three-metric call is the
+    fused MODE 2 pass and MAP alone is MODE 0."""
+    from oracle import mf_oracle as O
+    from collie_amd.interactions import Interactions
+    from collie_amd.metrics import auc, evaluate_in_batches, mapk, mrr
+    rng = np.random.default_rng(2)
+    U, N, D = 700, 5003, 64
+    tables = O.init_tables(U, N, D, rng)
+    tables['user_embeddings'] *= 25
+    tables['item_embeddings'] *= 25
+    tables['item_biases'] = rng.normal(0, 0.3, (N, 1)).astype(np.float32)
+    model = make_model(tables, dev)
+    test = Interactions(users=rng.integers(0, U, 9000), items=rng.integers(0, N, 9000),
+                        num_users=U, num_items=N, allow_missing_ids=True,
+                        check_num_negative_samples_is_valid=False)
+    got = evaluate_in_batches([mapk, mrr, auc], test, model, k=10, batch_size=20, verbose=False)
+    ref = O.evaluate_in_batches([O.mapk, O.mrr, O.auc], test.mat, tables, k=10, batch_size=20)
+    np.testing.assert_allclose(got, ref, rtol=1e-5)
+    assert evaluate_in_batches([mapk], test, model, k=10, verbose=False) == got[0]
+    assert evaluate_in_batches([mrr, auc], test, model, k=10, verbose=False) == got[1:]
