@@ -120,7 +120,7 @@ class ColdStartModel(MatrixFactorizationModel):
     # ------------------------------------------------------------------------------------ stages
     def _reset_stage_caches(self):
         # the training workspace keeps per-item stamps laid out for ONE pair of item tables
-        self._workspace = None
+        self._retire_workspace()
         self._tables_cache = None
         self._staged_step = None
 

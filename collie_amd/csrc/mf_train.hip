@@ -883,22 +883,28 @@ __global__ __launch_bounds__(kBlock, (CH * NP <= 4 ? 8 : 4)) void mf_train_fwd_l
 #pragma unroll
     for (int q = 0; q < NP; ++q)
       if (lig == 0 && row_lane[q] && stamp[q] != p.step_id) p.touch_item[item[q]] = p.step_id;
-    if (live && lane < CH * LPR) {  // lane l stages 16-byte chunk l of the two rows
-      const int i = lane / LPR, l2 = lane % LPR;
-      const float4 uu = user_l[lane];
-      const float4 ip = items_l[i * kWave + l2];
-      const float4 is = items_l[qs * kPassF4 + i * kWave + sel_grp * LPR + l2];
-      float4 gu, gi;
-      gu.x = g * ip.x - g * is.x;
-      gu.y = g * ip.y - g * is.y;
-      gu.z = g * ip.z - g * is.z;
-      gu.w = g * ip.w - g * is.w;
-      gi.x = g * uu.x;
-      gi.y = g * uu.y;
-      gi.z = g * uu.z;
-      gi.w = g * uu.w;
-      *reinterpret_cast<float4*>(p.stage_u + b * D + lane * 4) = gu;
-      *reinterpret_cast<float4*>(p.stage_i + b * D + lane * 4) = gi;
+    if (live) {  // lane l stages 16-byte chunks l, l + 64, ... of the two rows (dim 512: two)
+#pragma unroll
+      for (int c0 = 0; c0 < CH * LPR; c0 += kWave) {
+        const int cidx = c0 + lane;
+        if (CH * LPR >= kWave || cidx < CH * LPR) {
+          const int i = cidx / LPR, l2 = cidx % LPR;
+          const float4 uu = user_l[cidx];
+          const float4 ip = items_l[i * kWave + l2];
+          const float4 is = items_l[qs * kPassF4 + i * kWave + sel_grp * LPR + l2];
+          float4 gu, gi;
+          gu.x = g * ip.x - g * is.x;
+          gu.y = g * ip.y - g * is.y;
+          gu.z = g * ip.z - g * is.z;
+          gu.w = g * ip.w - g * is.w;
+          gi.x = g * uu.x;
+          gi.y = g * uu.y;
+          gi.z = g * uu.z;
+          gi.w = g * uu.w;
+          *reinterpret_cast<float4*>(p.stage_u + b * D + cidx * 4) = gu;
+          *reinterpret_cast<float4*>(p.stage_i + b * D + cidx * 4) = gi;
+        }
+      }
     }
     collect(b, static_cast<uint32_t>(u), key_off + static_cast<uint32_t>(pos_item),
             key_off + static_cast<uint32_t>(best_item), live, g);
@@ -1179,11 +1185,8 @@ extern "C" int collie_mf_train_forward(const collie_mf_tables* t, const collie_m
                       (lds_ch == 1 || lds_ch == 2 || lds_ch == 4 || lds_ch == 8) &&
                       b->users_dtype == COLLIE_I32 && b->pos_dtype == COLLIE_I32 &&
                       b->neg_dtype == COLLIE_I64 && !s_pos_out && !s_neg_out;
-  // tuning knob for A/B profiling only: COLLIE_K1_VARIANT=regs keeps the rows in VGPRs
-  static const char* const variant = getenv("COLLIE_K1_VARIANT");
-  const bool lds_pick = lds_ok && !(variant && variant[0] == 'r');
   int rc;
-  if (lds_pick) rc = launch_fwd_lds(lds_lpr, lds_ch, lds_np, grid, stream, p);
+  if (lds_ok) rc = launch_fwd_lds(lds_lpr, lds_ch, lds_np, grid, stream, p);
   else if (fast) rc = launch_fwd_fast(lpr, np, grid, stream, p);
   else if (vec == 4) rc = launch_fwd<4>(lpr, grid, stream, p);
   else if (vec == 2) rc = launch_fwd<2>(lpr, grid, stream, p);

@@ -105,6 +105,16 @@ class Interactions:
                 pos = np.searchsorted(keys, k)
                 pos[pos >= len(keys)] = len(keys) - 1
                 clash = (keys[pos] == k).reshape(size)
+                if size[1] > 1:
+                    # a candidate already in the sample's negative list is rejected too
+                    # (``datasets.py:408-411``): mark every repeat after its first occurrence
+                    order = np.argsort(neg, axis=1, kind='stable')
+                    srt = np.take_along_axis(neg, order, axis=1)
+                    rep = np.zeros(size, dtype=bool)
+                    rep[:, 1:] = srt[:, 1:] == srt[:, :-1]
+                    dup = np.zeros(size, dtype=bool)
+                    np.put_along_axis(dup, order, rep, axis=1)
+                    clash |= dup
                 if not clash.any():
                     break
                 neg[clash] = self._rng.integers(0, self.num_items, size=int(clash.sum()))

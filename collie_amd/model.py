@@ -308,7 +308,7 @@ class MatrixFactorizationModel(nn.Module):
 
     def _apply(self, fn, *args, **kwargs):
         out = super()._apply(fn, *args, **kwargs)
-        self._workspace = None
+        self._retire_workspace()
         self._status = None
         self._meta_codes = None
         self._loss_cfg = None
@@ -443,6 +443,19 @@ class MatrixFactorizationModel(nn.Module):
             self._status.zero_()
             raise IndexError('index out of range in self: a user or item id is outside the tables')
 
+    def _retire_workspace(self):
+        """Drop the training workspace but keep its step counter: the optimizers' ``_row_stamp``
+        arrays outlive the workspace and are compared with the ids it hands out."""
+        ws = self.__dict__.get('_workspace')
+        if ws is not None:
+            self.__dict__['_step_seq'] = max(self.__dict__.get('_step_seq', 0), ws.step_id)
+        self._workspace = None
+
+    def _train_workspace(self, dev):
+        if self._workspace is None:
+            self._workspace = ops.TrainWorkspace(dev, self.__dict__.get('_step_seq', 0))
+        return self._workspace
+
     def _drop_staged_step(self):
         self.__dict__['_staged_step'] = None    # a plain attribute: skip nn.Module.__setattr__
 
@@ -507,8 +520,7 @@ class MatrixFactorizationModel(nn.Module):
         for t in (users, pos_items, neg_items):
             _lib.require_hip(t, 'batch')
         need_grad = torch.is_grad_enabled() and any(w.requires_grad for w in ws)
-        if self._workspace is None:
-            self._workspace = ops.TrainWorkspace(dev)
+        self._train_workspace(dev)
         self.__dict__['_staged_step'] = None        # the workspace is about to be overwritten
         B, K = neg_items.shape
         buf = self._workspace.ensure(B, K, self.hparams.embedding_dim, self.hparams.num_users,
@@ -546,8 +558,7 @@ class MatrixFactorizationModel(nn.Module):
         ratings = ratings.float().contiguous()
         need_grad = torch.is_grad_enabled() and any(
             getattr(self, n).weight.requires_grad for n in _TABLES)
-        if self._workspace is None:
-            self._workspace = ops.TrainWorkspace(dev)
+        self._train_workspace(dev)
         self._staged_step = None
         B = users.shape[0]
         buf = self._workspace.ensure(B, 1, self.hparams.embedding_dim, self.hparams.num_users,

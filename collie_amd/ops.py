@@ -61,10 +61,13 @@ class TrainWorkspace:
     on demand, reused every step.  ``next_step()`` hands out the step ids the stamps compare to.
     """
 
-    def __init__(self, device):
+    def __init__(self, device, start_step=0):
         self.device = device
         self.buf = None
-        self.step_id = 0
+        # Step ids only ever grow (also across buffer re-creation: a fresh zero-filled buffer is
+        # valid with any id >= 1).  Optimizer-owned ``_row_stamp`` arrays outlive the buffer and
+        # compare against the same ids, so a restart at 1 would make stale stamps look current.
+        self.step_id = int(start_step)
 
     def ensure(self, batch_size, num_neg, dim, num_users, num_items):
         key = (batch_size, num_neg, dim, num_users, num_items)
@@ -76,7 +79,6 @@ class TrainWorkspace:
             raise ValueError('empty batch')
         if self.buf is None or self.buf.numel() < need:
             self.buf = torch.zeros(need, dtype=torch.uint8, device=self.device)
-            self.step_id = 0
         return self.buf
 
     def next_step(self):

@@ -27,7 +27,12 @@ class _FusedMixin:
     def zero_grad(self, set_to_none: bool = True):
         model = getattr(self, '_collie_model', None)
         if model is not None:
-            model._drop_staged_step()
+            # Only a step that was already backward-ed (or consumed) is stale.  A step that is
+            # staged but not yet armed belongs to the ``loss = calculate_loss(); zero_grad();
+            # loss.backward(); step()`` order (Lightning's closure order) and must survive.
+            st = model.__dict__.get('_staged_step')
+            if st is not None and (st.armed or st.done):
+                model._drop_staged_step()
         # the fused route never materialises ``.grad``: nothing to clear in the usual case
         for group in self.param_groups:
             for p in group['params']:

@@ -645,8 +645,11 @@ class ShardedMatrixFactorizationModel:
             raise ValueError('test interactions and model disagree on the number of items')
         if k > n_items:
             raise ValueError(f'Ensure ``k`` ({k}) is less than the number of items ({n_items}):')
-        if want[0] and (k > 16 or k > self.N_loc):
-            raise ValueError(f'k={k} must not exceed 16 or the smallest item shard ({self.N_loc})')
+        # the smallest shard over ALL ranks (shards differ by one row): every rank raises or none
+        # does, so no rank is left waiting in a collective
+        min_shard = n_items // self.comm.world
+        if want[0] and (k > 16 or k > min_shard):
+            raise ValueError(f'k={k} must not exceed 16 or the smallest item shard ({min_shard})')
         test_users = M._unique_users(test_interactions)
         csr = []
 

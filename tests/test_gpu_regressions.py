@@ -1,0 +1,106 @@
+"""
+GPU regression tests (``-m gpu``) for host-side orderings around the fused step that the main
+trajectory tests do not walk: Lightning's closure order (forward, zero_grad, backward, step) and a
+train -> evaluate -> continue-training loop with dense Adam (whose per-row stamps outlive the
+training workspace).  Bars: bit-identical tables between the two orderings.
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+pytestmark = pytest.mark.gpu
+NAMES = ('user_embeddings', 'item_embeddings', 'user_biases', 'item_biases')
+
+
+class Shape:
+    num_users, num_items, num_negative_samples = 300, 200, 5
+
+
+def _model(dev, **kw):
+    from collie_amd.model import MatrixFactorizationModel
+    torch.manual_seed(0)
+    m = MatrixFactorizationModel(train=Shape(), embedding_dim=16, lr_scheduler_func=None, **kw)
+    with torch.no_grad():
+        m.user_embeddings.weight.mul_(10.0)
+        m.item_embeddings.weight.mul_(10.0)
+    return m.to(dev).train()
+
+
+def _batches(dev, n, B=96):
+    rng = np.random.default_rng(5)
+    out = []
+    for _ in range(n):
+        out.append(((torch.tensor(rng.integers(0, 300, B), dtype=torch.int32, device=dev),
+                     torch.tensor(rng.integers(0, 200, B), dtype=torch.int32, device=dev)),
+                    torch.tensor(rng.integers(0, 200, (B, 5)), device=dev)))
+    return out
+
+
+def _tables(m):
+    return [getattr(m, n).weight.detach().cpu().numpy().copy() for n in NAMES]
+
+
+@pytest.mark.parametrize('kw', [
+    dict(sparse=True, optimizer='sparse_adam', bias_optimizer='sgd', loss='bpr', lr=1e-2),
+    dict(sparse=False, optimizer='adam', bias_optimizer='sgd', loss='adaptive', lr=1e-2)])
+def test_zero_grad_between_forward_and_backward_still_trains(kw):
+    """``loss = calculate_loss(b); zero_grad(); loss.backward(); step()`` (Lightning's closure
+    order) updates the tables exactly as the trainer's order does."""
+    dev = torch.device('cuda:0')
+    batches = _batches(dev, 3)
+    results = []
+    for closure_order in (False, True):
+        m = _model(dev, **kw)
+        opts = m.configure_optimizers()
+        for b in batches:
+            if closure_order:
+                loss = m.calculate_loss(b)
+                for o in opts:
+                    o.zero_grad()
+            else:
+                for o in opts:
+                    o.zero_grad()
+                loss = m.calculate_loss(b)
+            loss.backward()
+            for o in opts:
+                o.step()
+        results.append(_tables(m))
+    moved = False
+    for a, b, n in zip(results[0], results[1], NAMES):
+        np.testing.assert_array_equal(a, b, err_msg=n)
+        moved |= n == 'item_embeddings'
+    m0 = _model(dev, **kw)
+    assert not np.array_equal(_tables(m0)[1], results[1][1])        # the tables did move
+
+
+def test_dense_adam_row_stamps_survive_workspace_recreation():
+    """Dense Adam across ``model.to(device)`` / ``evaluate_in_batches`` (both re-create the
+    training workspace, whose step counter the optimizer-owned row stamps are compared with):
+    the interrupted run equals the uninterrupted one bit for bit."""
+    from collie_amd.interactions import Interactions
+    from collie_amd.metrics import evaluate_in_batches, mapk
+    dev = torch.device('cuda:0')
+    batches = _batches(dev, 6)
+    rng = np.random.default_rng(1)
+    test = Interactions(users=rng.integers(0, 300, 500), items=rng.integers(0, 200, 500),
+                        num_users=300, num_items=200, allow_missing_ids=True,
+                        num_negative_samples=5, max_number_of_samples_to_consider=0, seed=0)
+    results = []
+    for interrupt in (False, True):
+        m = _model(dev, sparse=False, optimizer='adam', bias_optimizer='adam', loss='adaptive',
+                   lr=1e-2, bias_lr=1e-2)
+        opts = m.configure_optimizers()
+        for i, b in enumerate(batches):
+            if interrupt and i == 3:
+                evaluate_in_batches([mapk], test, m, k=5)
+                m.to(dev).train()
+            for o in opts:
+                o.zero_grad()
+            m.calculate_loss(b).backward()
+            for o in opts:
+                o.step()
+        results.append(_tables(m) + [opts[0].state[m.item_embeddings.weight]['exp_avg']
+                                     .cpu().numpy().copy()])
+    for a, b in zip(*results):
+        np.testing.assert_array_equal(a, b)

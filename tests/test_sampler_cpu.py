@@ -78,3 +78,19 @@ def test_stream_does_not_depend_on_batch_split_or_order_argument():
     other_epoch = S.sample_batch(rows, cols, None, 0, 50, csr.indptr, csr.indices, N, K, 200, 9,
                                  1000 + len(rows))
     assert not np.array_equal(whole[2], other_epoch[2])
+
+
+def test_host_loader_rejects_positives_and_within_row_repeats():
+    """``Interactions._negative_sample`` follows ``datasets.py:399-426``: a candidate is rejected if
+    it is one of the user's positives OR already in the sample's negative list (the device sampler
+    follows the same rule, tests/test_gpu_sampler.py)."""
+    from collie_amd.interactions import Interactions
+    rng = np.random.default_rng(0)
+    it = Interactions(users=rng.integers(0, 20, 200), items=rng.integers(0, 40, 200), num_users=20,
+                      num_items=40, allow_missing_ids=True, num_negative_samples=8,
+                      max_number_of_samples_to_consider=200, seed=1)
+    (u, _), neg = it[np.arange(len(it))]
+    assert neg.shape == (len(it), 8)
+    pos = set(zip(it.mat.row.tolist(), it.mat.col.tolist()))
+    assert all(len(set(r.tolist())) == len(r) for r in neg)
+    assert not any((uu, n) in pos for uu, r in zip(u.tolist(), neg.tolist()) for n in r)
