@@ -12,6 +12,8 @@
 // The MFMA result is bit-for-bit an fmaf chain in k order (MI355X guide, "FP32-input MFMA"), and
 // chain_score() below replays that exact chain for single (user, item) pairs, so the scores of
 // the positives (thresholds) are bit-identical to the scores the GEMM produces for the same pairs.
+#include <mutex>
+
 #include "common.h"
 
 namespace collie {
@@ -842,23 +844,13 @@ extern "C" size_t collie_mf_eval_workspace_bytes(int64_t n_users, int64_t n_item
   return carve_eval_ws(nullptr, n_users, n_items_shard).bytes;
 }
 
-extern "C" int collie_mf_eval_topk(const collie_mf_tables* t, const int64_t* user_ids,
-                                   int64_t n_users, int64_t item_begin, int64_t item_end,
-                                   int64_t id_stride, int64_t id_offset, int32_t k,
-                                   int32_t has_y_range, float y_lo, float y_hi,
-                                   float* topk_scores, int64_t* topk_ids, void* workspace,
-                                   size_t workspace_bytes, collie_stream_t stream_) {
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
-  if (validate_tables(t) || check_range(t, n_users, item_begin, item_end)) return -1;
-  COLLIE_REQUIRE(user_ids && topk_scores && topk_ids, "eval_topk: NULL pointer");
-  COLLIE_REQUIRE(k >= 1 && k <= kCap, "eval_topk: k must be in [1, %d] (got %d)", kCap, k);
-  COLLIE_REQUIRE(id_stride >= 1 && id_offset >= 0 &&
-                     (item_end - 1) * id_stride + id_offset < (int64_t{1} << 31),
-                 "eval_topk: bad global id mapping");
-  COLLIE_REQUIRE(k <= item_end - item_begin, "eval_topk: k (%d) exceeds the number of items", k);
-  EvalWs ws = carve_eval_ws(workspace, n_users, item_end - item_begin);
-  COLLIE_REQUIRE(workspace && workspace_bytes >= ws.bytes,
-                 "eval workspace too small: need %zu bytes, got %zu", ws.bytes, workspace_bytes);
+namespace {
+
+// shared body of collie_mf_eval_topk / collie_mf_eval_topk_static: `ws` is already carved
+int eval_topk_impl(const collie_mf_tables* t, const int64_t* user_ids, int64_t n_users,
+                   int64_t item_begin, int64_t item_end, int64_t id_stride, int64_t id_offset,
+                   int32_t k, int32_t has_y_range, float y_lo, float y_hi, float* topk_scores,
+                   int64_t* topk_ids, const collie::EvalWs& ws, hipStream_t stream) {
   EvalParams p;
   memset(&p, 0, sizeof(p));
   p.t = *t;
@@ -876,6 +868,93 @@ extern "C" int collie_mf_eval_topk(const collie_mf_tables* t, const int64_t* use
                      dim3(kBlock), 0, stream, ws.cand_scores, ws.cand_ids, n_users, p.nchunks * 2,
                      k, has_y_range, y_lo, y_hi, topk_scores, topk_ids);
   return check_launch("merge_topk_kernel");
+}
+
+int check_topk_args(const collie_mf_tables* t, const int64_t* user_ids, int64_t n_users,
+                    int64_t item_begin, int64_t item_end, int64_t id_stride, int64_t id_offset,
+                    int32_t k, const float* topk_scores, const int64_t* topk_ids) {
+  if (validate_tables(t) || check_range(t, n_users, item_begin, item_end)) return -1;
+  COLLIE_REQUIRE(user_ids && topk_scores && topk_ids, "eval_topk: NULL pointer");
+  COLLIE_REQUIRE(k >= 1 && k <= kCap, "eval_topk: k must be in [1, %d] (got %d)", kCap, k);
+  COLLIE_REQUIRE(id_stride >= 1 && id_offset >= 0 &&
+                     (item_end - 1) * id_stride + id_offset < (int64_t{1} << 31),
+                 "eval_topk: bad global id mapping");
+  COLLIE_REQUIRE(k <= item_end - item_begin, "eval_topk: k (%d) exceeds the number of items", k);
+  return 0;
+}
+
+// ---- the allocation-free variant's scratch --------------------------------------------------------
+// Candidate lists of collie_mf_eval_topk_static live in this file-scope device array instead of a
+// caller workspace.  In host code `scratch` is only a stand-in for the symbol: the per-device
+// address comes from hipGetSymbolAddress (each GPU holds its own copy at its own address) and is
+// what every kernel argument below uses.
+constexpr int64_t kStaticMaxUsers = 1024;
+constexpr size_t kStaticScratchBytes = (size_t{16} << 20) + 4096;  // 1024 users x 64 chunks x 2 halves
+constexpr int kMaxDevices = 64;
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+void* g_scratch_ptr[kMaxDevices];  // per device, filled on the first call on that device
+std::mutex g_scratch_mutex;
+
+// device address of `scratch` on the CURRENT device (looked up once per device)
+int static_scratch(void** out) {
+  int dev = -1;
+  COLLIE_CHECK_HIP(hipGetDevice(&dev));
+  COLLIE_REQUIRE(dev >= 0 && dev < kMaxDevices, "eval_topk_static: device index %d out of range",
+                 dev);
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (g_scratch_ptr[dev] == nullptr) {
+    void* ptr = nullptr;
+    COLLIE_CHECK_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+    COLLIE_REQUIRE(ptr != nullptr, "eval_topk_static: hipGetSymbolAddress returned NULL");
+    g_scratch_ptr[dev] = ptr;
+  }
+  *out = g_scratch_ptr[dev];
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int collie_mf_eval_topk(const collie_mf_tables* t, const int64_t* user_ids,
+                                   int64_t n_users, int64_t item_begin, int64_t item_end,
+                                   int64_t id_stride, int64_t id_offset, int32_t k,
+                                   int32_t has_y_range, float y_lo, float y_hi,
+                                   float* topk_scores, int64_t* topk_ids, void* workspace,
+                                   size_t workspace_bytes, collie_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (check_topk_args(t, user_ids, n_users, item_begin, item_end, id_stride, id_offset, k,
+                      topk_scores, topk_ids))
+    return -1;
+  EvalWs ws = carve_eval_ws(workspace, n_users, item_end - item_begin);
+  COLLIE_REQUIRE(workspace && workspace_bytes >= ws.bytes,
+                 "eval workspace too small: need %zu bytes, got %zu", ws.bytes, workspace_bytes);
+  return eval_topk_impl(t, user_ids, n_users, item_begin, item_end, id_stride, id_offset, k,
+                        has_y_range, y_lo, y_hi, topk_scores, topk_ids, ws, stream);
+}
+
+extern "C" int collie_mf_eval_topk_static(const collie_mf_tables* t, const int64_t* user_ids,
+                                          int64_t n_users, int64_t item_begin, int64_t item_end,
+                                          int64_t id_stride, int64_t id_offset, int32_t k,
+                                          int32_t has_y_range, float y_lo, float y_hi,
+                                          float* topk_scores, int64_t* topk_ids,
+                                          collie_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (check_topk_args(t, user_ids, n_users, item_begin, item_end, id_stride, id_offset, k,
+                      topk_scores, topk_ids))
+    return -1;
+  COLLIE_REQUIRE(n_users <= kStaticMaxUsers,
+                 "eval_topk_static: at most %lld users per call (got %lld); use collie_mf_eval_topk "
+                 "with a caller workspace for larger batches",
+                 static_cast<long long>(kStaticMaxUsers), static_cast<long long>(n_users));
+  void* base = nullptr;
+  if (static_scratch(&base)) return -1;
+  EvalWs ws = carve_eval_ws(base, n_users, item_end - item_begin);
+  COLLIE_REQUIRE(ws.bytes <= kStaticScratchBytes,
+                 "eval_topk_static: needs %zu bytes of scratch, the static buffer holds %zu",
+                 ws.bytes, kStaticScratchBytes);
+  // every candidate slot the merge reads is written by the scoring kernel of THIS call, so nothing
+  // of the previous call's contents has to be cleared
+  return eval_topk_impl(t, user_ids, n_users, item_begin, item_end, id_stride, id_offset, k,
+                        has_y_range, y_lo, y_hi, topk_scores, topk_ids, ws, stream);
 }
 
 extern "C" int collie_mf_eval_merge_topk(const float* cand_scores, const int32_t* cand_ids,

@@ -497,6 +497,18 @@ def eval_topk(tables, user_ids, item_begin, item_end, k, y_range, ws, id_stride=
     return scores, ids
 
 
+def eval_topk_static(tables, user_ids, item_begin, item_end, k, y_range, scores, ids,
+                     id_stride=1, id_offset=0):
+    """``eval_topk`` into caller-provided ``scores`` / ``ids`` [n, k] without any allocation: the
+    candidate lists live in the library's static device buffer (``collie_mf_eval_topk_static``;
+    at most 1024 users per call, calls on one GPU must not overlap)."""
+    has_y, lo, hi = _y(y_range)
+    check(load().collie_mf_eval_topk_static(
+        byref(tables), ptr(user_ids), user_ids.shape[0], item_begin, item_end, id_stride, id_offset,
+        k, has_y, lo, hi, ptr(scores), ptr(ids), stream_ptr()), 'collie_mf_eval_topk_static')
+    return scores, ids
+
+
 def eval_pos_scores(tables, user_ids, indptr, indices, y_range, want_thresholds, id_stride=1,
                     id_offset=0, given_scores=None):
     n = user_ids.shape[0]

@@ -280,6 +280,21 @@ int collie_mf_eval_topk(const collie_mf_tables* t, const int64_t* user_ids, int6
                         float* topk_scores, int64_t* topk_ids, void* workspace,
                         size_t workspace_bytes, collie_stream_t stream);
 
+/* The same call for callers that cannot allocate (code under HIP graph capture, tight serving
+ * loops that answer "top-k items for these users", harnesses that forbid hipMalloc).  It has no
+ * counterpart in the reference.  The candidate lists live in a file-scope device array inside the
+ * library (16 MiB per GPU, held until the process ends) instead of a caller workspace; the call
+ * itself allocates nothing.  Limits: n_users <= 1024 per call (larger batches are rejected with an
+ * error: use collie_mf_eval_topk).  All calls on one GPU share that GPU's array: calls that
+ * overlap on one GPU (different streams or threads) race; serialise them.  The first call on a
+ * device looks up the array's device address (hipGetSymbolAddress): make it outside graph
+ * capture.  Outputs are bit-identical to collie_mf_eval_topk's. */
+int collie_mf_eval_topk_static(const collie_mf_tables* t, const int64_t* user_ids, int64_t n_users,
+                               int64_t item_begin, int64_t item_end, int64_t id_stride,
+                               int64_t id_offset, int32_t k, int32_t has_y_range, float y_lo,
+                               float y_hi, float* topk_scores, int64_t* topk_ids,
+                               collie_stream_t stream);
+
 /* Catalog-sharded evaluation: merge per-shard top-k candidate lists (cand_* [n_users, nslots,
  * collie_mf_eval_topk_capacity()], unused entries = (-inf, INT32_MAX)) into the global top-k.
  * No counterpart in the reference (it has no sharded evaluation). */
