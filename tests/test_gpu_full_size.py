@@ -9,6 +9,12 @@ the oracle finishes in seconds):
 * configs[2] catalogue (1,000,000 items x 128): the top-k of the whole catalogue equals the merge
   of the top-k of its shards (ids bit-exact), and re-scoring the returned ids with a plain torch
   fp32 product reproduces the returned scores and torch's own top-k scores to 1e-5.
+* configs[3] (100,000,000 users x 10,000,000 items x 128 on ONE GPU, B = 1,048,576, K = 10: the
+  tables no cache holds, 169 GB with the SparseAdam moments): same properties as configs[1], with
+  per-row fingerprints instead of table clones (a second copy of the tables does not fit).
+* configs[4] (HybridPretrainedModel head, 10 M x 1 M x 128, 256-d item metadata, B = 65,536):
+  the step is bit-reproducible, frozen tables do not move, the loss is chunk-additive; unfrozen,
+  only looked-up embedding / bias rows move on the first Adam step.
 """
 import numpy as np
 import pytest
@@ -176,3 +182,230 @@ def test_configs2_catalogue_topk_shard_merge_and_rescoring(dev):
     clear = gaps > 4e-5 * scale
     assert int(clear.sum()) > n_eval // 2
     assert torch.equal(ids[clear], top_k1.indices[clear][:, :k])
+
+
+# ---- configs[3]: 100 M x 10 M x 128 on one GPU ---------------------------------------------------
+def _fingerprint(w, probe):
+    """One int64 per row: an exact integer hash of the row's bit patterns (sum of the 32-bit
+    patterns times fixed odd 64-bit weights, wrapping) -- unchanged rows give identical values and a
+    changed row collides with probability ~2^-60 (a float dot product with a probe vector did
+    collide for ~14 of 10^6 rows that moved by 1e-3).  Row chunks bound the temporaries."""
+    out = torch.empty(w.shape[0], dtype=torch.int64, device=w.device)
+    step = 1 << 22
+    for lo in range(0, w.shape[0], step):
+        bits = w[lo:lo + step].view(torch.int32).to(torch.int64)
+        torch.sum(bits * probe, dim=1, out=out[lo:lo + step])
+    return out
+
+
+def _row_any_nonzero(w):
+    out = torch.empty(w.shape[0], dtype=torch.bool, device=w.device)
+    step = 1 << 24
+    for lo in range(0, w.shape[0], step):
+        out[lo:lo + step] = (w[lo:lo + step] != 0).any(1)
+    return out
+
+
+def test_configs3_hbm_resident_tables_full_batch_properties(dev):
+    from collie_amd.model import MatrixFactorizationModel
+    U, N, D, K, B = 100_000_000, 10_000_000, 128, 10, 1_048_576
+    free, _ = torch.cuda.mem_get_info(dev)
+    if free < 200 * 2 ** 30:
+        pytest.skip(f'needs ~180 GB of free HBM, {free / 2 ** 30:.0f} GB available')
+
+    class Shape:
+        num_users, num_items, num_negative_samples = U, N, K
+
+    with torch.device(dev):
+        m = MatrixFactorizationModel(train=Shape(), embedding_dim=D, sparse=True, lr=1e-3,
+                                     optimizer='sparse_adam', bias_optimizer='sgd', bias_lr=1e-2,
+                                     loss='bpr', lr_scheduler_func=None)
+    m = m.to(dev).train()
+    assert m.user_embeddings.weight.device.type == 'cuda'
+    opts = m.configure_optimizers()
+    std = 1.0 / (2.5 * D)
+
+    def reset():
+        """Tables re-initialised in place from a fixed seed (ScaledEmbedding's N(0, 1/(2.5 D));
+        scaled up so that scores are O(1)), optimizer state cleared."""
+        g = torch.Generator(device=dev)
+        g.manual_seed(5)
+        with torch.no_grad():
+            m.user_embeddings.weight.normal_(0, std * 40, generator=g)
+            m.item_embeddings.weight.normal_(0, std * 40, generator=g)
+            m.user_biases.weight.zero_()
+            m.item_biases.weight.normal_(0, 0.01, generator=g)
+        for o in opts:
+            for st in o.state.values():
+                for key, v in st.items():
+                    if torch.is_tensor(v):
+                        v.zero_()
+                    else:
+                        st[key] = 0
+
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    users = torch.randint(0, U, (B,), device=dev, generator=g, dtype=torch.int32)
+    pos = torch.randint(0, N, (B,), device=dev, generator=g, dtype=torch.int32)
+    neg = torch.randint(0, N, (B, K), device=dev, generator=g)
+    neg = torch.where(neg == pos.long()[:, None], (neg + 1) % N, neg)
+    batch = ((users, pos), neg)
+    probe_u = torch.randint(-2 ** 62, 2 ** 62, (D,), device=dev, generator=g) * 2 + 1
+
+    def one_step():
+        reset()
+        fp0 = (_fingerprint(m.user_embeddings.weight.detach(), probe_u),
+               _fingerprint(m.item_embeddings.weight.detach(), probe_u))
+        bias0 = m.item_biases.weight.detach().clone()
+        with torch.no_grad():           # (1) chunk losses on the step's starting tables
+            total = 0.0
+            for lo in range(0, B, 131_072):
+                sl = slice(lo, lo + 131_072)
+                total += float(m.calculate_loss(((users[sl], pos[sl]), neg[sl]))) * 131_072
+        for o in opts:
+            o.zero_grad()
+        loss = m.calculate_loss(batch)
+        loss.backward()
+        for i, o in enumerate(opts):
+            m.optimizer_step(optimizer=o, optimizer_idx=i)
+        m.check_status()
+        fp1 = (_fingerprint(m.user_embeddings.weight.detach(), probe_u),
+               _fingerprint(m.item_embeddings.weight.detach(), probe_u))
+        return loss.detach().clone(), total / B, fp0, fp1, bias0
+
+    loss, chunked, fp0, fp1, bias0 = one_step()
+    # (1) loss = chunk losses recombined
+    assert abs(float(loss) - chunked) <= 1e-5 * abs(chunked)
+    assert 0.1 < float(loss) < 10.0
+
+    # (3) exactly the looked-up rows move
+    looked_u = torch.zeros(U, dtype=torch.bool, device=dev)
+    looked_u[users.long()] = True
+    looked_i = torch.zeros(N, dtype=torch.bool, device=dev)
+    looked_i[pos.long()] = True
+    pos_rows = looked_i.clone()
+    looked_i[neg.reshape(-1)] = True
+    moved_u = fp1[0] != fp0[0]
+    moved_i = fp1[1] != fp0[1]
+    assert int(looked_u.sum()) > 0.98 * B          # 1 M draws out of 100 M rows: few repeats
+    assert torch.equal(moved_u, looked_u), (int((moved_u & ~looked_u).sum()),
+                                            int((looked_u & ~moved_u).sum()))
+    assert not bool((moved_i & ~looked_i).any())
+    assert bool(moved_i[pos_rows].all())
+    assert int(moved_i.sum()) <= int(pos_rows.sum()) + B
+    # optimizer state: non-zero exactly on rows with a gradient; SparseAdam leaves every other row's
+    # moments at their initial zeros, also for looked-up rows with a zero gradient
+    emb_opt = opts[0]
+    st_u = emb_opt.state[m.user_embeddings.weight]
+    st_i = emb_opt.state[m.item_embeddings.weight]
+    assert torch.equal(_row_any_nonzero(st_u['exp_avg']), moved_u)
+    assert torch.equal(_row_any_nonzero(st_i['exp_avg']), moved_i)
+    assert torch.equal(_row_any_nonzero(st_u['exp_avg_sq']), moved_u)
+    # biases
+    assert float(m.user_biases.weight.detach().abs().max()) == 0.0
+    moved_b = (m.item_biases.weight.detach() != bias0).reshape(-1)
+    assert not bool((moved_b & ~moved_i).any()) and int(moved_b.sum()) > 0
+    # first Adam step: |delta| <= lr (1 + 1e-3), checked on the rows that moved
+    rows = torch.nonzero(moved_u).reshape(-1)[:200_000]
+    g2 = torch.Generator(device=dev)
+    g2.manual_seed(5)
+    del fp0, looked_u, looked_i, pos_rows
+    after_rows = m.user_embeddings.weight.detach()[rows].clone()
+    after_fp = fp1
+
+    # (2) bit-reproducible: the same step again from the same start
+    loss2, _, _, fp2, _ = one_step()
+    assert torch.equal(loss, loss2)
+    assert torch.equal(after_fp[0], fp2[0]) and torch.equal(after_fp[1], fp2[1])
+    assert torch.equal(after_rows, m.user_embeddings.weight.detach()[rows])
+    # |delta| of the first Adam step, against the re-initialised start values of those rows
+    reset()
+    delta = (after_rows - m.user_embeddings.weight.detach()[rows]).abs().max()
+    assert 0 < float(delta) <= 1e-3 * 1.001
+
+
+# ---- configs[4]: hybrid head at 10 M x 1 M, 256-d metadata ------------------------------------------
+def _hybrid_c4(dev, freeze):
+    from collie_amd.hybrid import HybridPretrainedModel
+    from collie_amd.model import MatrixFactorizationModel
+    U, N, D, K, MC = 10_000_000, 1_000_000, 128, 10, 256
+
+    class Shape:
+        num_users, num_items, num_negative_samples = U, N, K
+
+    torch.manual_seed(0)
+    with torch.device(dev):
+        mf = MatrixFactorizationModel(train=Shape(), embedding_dim=D, lr_scheduler_func=None)
+        with torch.no_grad():
+            mf.user_embeddings.weight.mul_(30.0)
+            mf.item_embeddings.weight.mul_(30.0)
+            mf.item_biases.weight.normal_(0, 0.01)
+        item_md = torch.randn(N, MC)
+    model = HybridPretrainedModel(train=Shape(), trained_model=mf, item_metadata=item_md,
+                                  item_metadata_layers_dims=[128], combined_layers_dims=[128, 64, 32],
+                                  freeze_embeddings=freeze, loss='bpr', optimizer='adam', lr=1e-3,
+                                  lr_scheduler_func=None).to(dev)
+    return model.train(), mf
+
+
+@pytest.mark.parametrize('freeze', [True, False])
+def test_configs4_hybrid_head_full_size_properties(dev, freeze):
+    U, N, K, B = 10_000_000, 1_000_000, 10, 65_536
+    g = torch.Generator(device=dev)
+    g.manual_seed(1)
+    users = torch.randint(0, U, (B,), device=dev, generator=g, dtype=torch.int32)
+    pos = torch.randint(0, N, (B,), device=dev, generator=g, dtype=torch.int32)
+    neg = torch.randint(0, N, (B, K), device=dev, generator=g)
+    batch = ((users, pos), neg)
+    runs = []
+    for rep in range(2):
+        model, mf = _hybrid_c4(dev, freeze)
+        before = {n: p.detach().clone() for n, p in model.named_parameters()}
+        if rep == 0:
+            with torch.no_grad():       # chunk-additive loss on the starting parameters
+                total = 0.0
+                for lo in range(0, B, 8192):
+                    sl = slice(lo, lo + 8192)
+                    total += float(model.calculate_loss(((users[sl], pos[sl]), neg[sl]))) * 8192
+        opt = model.configure_optimizers()
+        opt.zero_grad()
+        loss = model.calculate_loss(batch)
+        loss.backward()
+        opt.step()
+        model.check_status()
+        runs.append((loss.detach().clone(),
+                     {n: p.detach().clone() for n, p in model.named_parameters()}))
+        if rep == 0:
+            assert abs(float(loss) - total / B) <= 1e-5 * abs(total / B)
+            after = runs[0][1]
+            looked_u = torch.zeros(U, dtype=torch.bool, device=dev)
+            looked_u[users.long()] = True
+            looked_i = torch.zeros(N, dtype=torch.bool, device=dev)
+            looked_i[pos.long()] = True
+            looked_i[neg.reshape(-1)] = True
+            moved_any = False
+            for n, p in after.items():
+                changed = (p != before[n])
+                is_table = n.startswith('embeddings.') or n.startswith('biases.')
+                if is_table and 'embeddings' in n and freeze:
+                    assert not bool(changed.any()), n           # frozen tables do not move
+                elif is_table:
+                    # Adam's first step with a zero gradient is the identity (m = v = 0): only
+                    # looked-up rows may move
+                    rows = changed.reshape(changed.shape[0], -1).any(1)
+                    looked = looked_u if n.split('.')[1] == '0' else looked_i
+                    assert not bool((rows & ~looked).any()), n
+                    if 'embeddings' in n:
+                        assert int(rows.sum()) > 0, n
+                else:
+                    moved_any |= bool(changed.any())            # the head's Linear layers train
+            assert moved_any
+            # the source MF model's tables are untouched either way (the hybrid model owns copies)
+            assert torch.equal(mf.user_embeddings.weight, before['embeddings.0.weight'])
+            del looked_u, looked_i
+        del model, mf, opt, before
+        torch.cuda.empty_cache()
+    # bit-reproducible step
+    assert torch.equal(runs[0][0], runs[1][0])
+    for n in runs[0][1]:
+        assert torch.equal(runs[0][1][n], runs[1][1][n]), n
