@@ -131,6 +131,14 @@ SIGNATURES = {
                                                        c_void_p, c_void_p, c_void_p, c_void_p,
                                                        c_void_p, c_void_p, c_void_p, c_size_t,
                                                        c_void_p]),
+    'collie_preds_topk': (ctypes.c_int, [c_void_p, c_int64, c_int64, c_int64, c_int32, c_void_p,
+                                         c_void_p, c_void_p]),
+    'collie_preds_pos_scores': (ctypes.c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p,
+                                               c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+                                               c_void_p, c_void_p, c_void_p, c_void_p]),
+    'collie_preds_rank_counts': (ctypes.c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p,
+                                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                c_void_p]),
     'collie_embedding_similarity': (ctypes.c_int, [c_void_p, c_int64, c_int32, c_int64, c_void_p,
                                                    c_void_p]),
     'collie_mf_explicit_forward': (ctypes.c_int, [POINTER(Tables), c_void_p, c_int32, c_void_p,

@@ -84,6 +84,10 @@ struct EvalParams {
   const float* best_score; // [n_users] raw score of the user's best positive
   const int64_t* best_id;  // [n_users]
   unsigned long long* counts;  // [n_users, 3]: above_best, sum_e #(sig<), sum_e #(sig<=)
+  // top-k rounds beyond the first (k > kCap): only items strictly AFTER (cut_s, cut_i) in
+  // (score desc, id asc) order are candidates; NULL in the first round
+  const float* cut_s;    // [n_users] raw score of the last entry already emitted
+  const int32_t* cut_i;  // [n_users] its global id
 };
 
 // MODE 0: top-k candidates.  MODE 1: rank counts.
@@ -141,6 +145,9 @@ __global__ __launch_bounds__(kBlock) void eval_gemm_kernel(const EvalParams p) {
     bid = static_cast<int>(p.best_id[uslot]);
   }
   const int k = p.k;
+  const bool has_cut = MODE == 0 && p.cut_s != nullptr;  // uniform
+  const float cut_s = has_cut && user_ok ? p.cut_s[uslot] : INFINITY;
+  const int cut_i = has_cut && user_ok ? p.cut_i[uslot] : -1;
 
   const int64_t chunk_items = static_cast<int64_t>(p.tiles_per_chunk) * kTileItems;
   const int64_t chunk_begin = p.item_begin + static_cast<int64_t>(blockIdx.y) * chunk_items;
@@ -195,7 +202,12 @@ __global__ __launch_bounds__(kBlock) void eval_gemm_kernel(const EvalParams p) {
         for (int r = 0; r < 16; ++r) {
           const int row = sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
           const float s = finish_score(acc[r], ub, tile_bias[row]);
-          acc[r] = base + row < chunk_end ? s : -INFINITY;
+          bool ok = base + row < chunk_end;
+          if (has_cut) {
+            const int gid = static_cast<int>((base + row) * p.id_stride + p.id_offset);
+            ok = ok && (s < cut_s || (s == cut_s && gid > cut_i));
+          }
+          acc[r] = ok ? s : -INFINITY;
           smax = fmaxf(smax, acc[r]);
         }
         if (smax > top_s[kCap - 1]) {
@@ -383,6 +395,9 @@ __global__ __launch_bounds__(kBlockDma) void eval_gemm_dma_kernel(const EvalPara
   const bool any_long = __ballot(e_end - e_begin > kCap) != 0ull;
   const int k = p.k;
   float thr = -INFINITY;  // TOPK: score of the k-th best candidate so far
+  const bool has_cut = MODE == 0 && p.cut_s != nullptr;  // uniform (later rounds of k > kCap)
+  const float cut_s = has_cut && user_ok ? p.cut_s[uslot] : INFINITY;
+  const int cut_i = has_cut && user_ok ? p.cut_i[uslot] : -1;
 
   const int64_t chunk_items = static_cast<int64_t>(p.tiles_per_chunk) * kTileItems;
   const int64_t chunk_begin = p.item_begin + static_cast<int64_t>(blockIdx.y) * chunk_items;
@@ -462,6 +477,16 @@ __global__ __launch_bounds__(kBlockDma) void eval_gemm_dma_kernel(const EvalPara
           // masked rows: -inf never enters a top-k list; NaN fails every rank-count comparison
           // (and every top-k comparison in the fused mode: fmaxf drops it, `> thr` is false)
           if (base + row >= chunk_end) acc[rr] = MODE == 0 ? -INFINITY : __builtin_nanf("");
+        }
+      }
+      if (MODE == 0 && has_cut) {
+        const int g0 = static_cast<int>((base + sub * 32 + 4 * h) * p.id_stride + p.id_offset);
+        const int st = static_cast<int>(p.id_stride);
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+          const int gid = g0 + ((rr & 3) + 8 * (rr >> 2)) * st;
+          const bool ok = acc[rr] < cut_s || (acc[rr] == cut_s && gid > cut_i);
+          acc[rr] = ok ? acc[rr] : -INFINITY;
         }
       }
       if (TOPK) {
@@ -557,7 +582,10 @@ __global__ __launch_bounds__(kBlock) void merge_topk_kernel(const float* __restr
                                                             int64_t n_users, int nslots, int k,
                                                             int has_y, float y_lo, float y_hi,
                                                             float* __restrict__ out_scores,
-                                                            int64_t* __restrict__ out_ids) {
+                                                            int64_t* __restrict__ out_ids,
+                                                            int out_ld, int col0,
+                                                            float* __restrict__ cut_s_out,
+                                                            int32_t* __restrict__ cut_i_out) {
   const int lane = lane_id();
   const int64_t user = static_cast<int64_t>(blockIdx.x) * kWaves + threadIdx.x / kWave;
   if (user >= n_users) return;
@@ -589,11 +617,15 @@ __global__ __launch_bounds__(kBlock) void merge_topk_kernel(const float* __restr
       }
     }
     if (lane == 0) {
-      out_scores[user * k + round] = yr(bs, has_y, y_lo, y_hi);
-      out_ids[user * k + round] = bi == 0x7fffffff ? -1 : bi;
+      out_scores[user * out_ld + col0 + round] = yr(bs, has_y, y_lo, y_hi);
+      out_ids[user * out_ld + col0 + round] = bi == 0x7fffffff ? -1 : bi;
     }
     last_s = bs;
     last_i = bi;
+  }
+  if (cut_s_out && lane == 0) {  // where the next round of a k > kCap query resumes
+    cut_s_out[user] = last_s;
+    cut_i_out[user] = last_i;
   }
 }
 
@@ -765,6 +797,8 @@ bool dma_ok(const collie_mf_tables* t) {
 struct EvalWs {
   float* cand_scores;
   int32_t* cand_ids;
+  float* cut_s;      // [n_users] resume point between the rounds of a k > kCap query
+  int32_t* cut_i;
   size_t bytes;
 };
 
@@ -777,6 +811,8 @@ EvalWs carve_eval_ws(void* base, int64_t n_users, int64_t n_items_shard) {
   const size_t n = static_cast<size_t>(n_users) * (a > b ? a : b) * 2 * kCap;
   w.cand_scores = c.take<float>(n);
   w.cand_ids = c.take<int32_t>(n);
+  w.cut_s = c.take<float>(static_cast<size_t>(n_users));
+  w.cut_i = c.take<int32_t>(static_cast<size_t>(n_users));
   w.bytes = align_up(c.off, 256);
   return w;
 }
@@ -833,6 +869,31 @@ int check_range(const collie_mf_tables* t, int64_t n_users, int64_t item_begin, 
 }
 
 }  // namespace
+
+// thresholds (sigmoid-space tie intervals) and best positive per user from GIVEN positive scores;
+// shared with the dense-preds route (preds_metrics.hip)
+int launch_pos_thresholds(const int64_t* indptr, const int64_t* indices, int64_t n_users,
+                          int64_t nnz, float* pos_scores, float* thr_lo, float* thr_hi,
+                          float* best_score, int64_t* best_id, hipStream_t stream) {
+  if (nnz > 0 && thr_lo && thr_hi) {
+    int64_t blocks = (nnz + kBlock - 1) / kBlock;
+    if (blocks > 4096) blocks = 4096;
+    collie_mf_tables none;
+    memset(&none, 0, sizeof(none));
+    hipLaunchKernelGGL(pos_scores_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0,
+                       stream, none, static_cast<const int64_t*>(nullptr), n_users, indptr, indices,
+                       1, 0, 0.0f, 0.0f, 0, int64_t{1}, int64_t{0}, pos_scores, thr_lo, thr_hi);
+    if (check_launch("pos_scores_kernel")) return -2;
+  }
+  if (best_score && best_id) {
+    hipLaunchKernelGGL(best_pos_kernel, dim3(static_cast<unsigned>((n_users + kBlock - 1) / kBlock)),
+                       dim3(kBlock), 0, stream, indptr, indices, pos_scores, n_users, best_score,
+                       best_id);
+    return check_launch("best_pos_kernel");
+  }
+  return 0;
+}
+
 }  // namespace collie
 
 using namespace collie;
@@ -845,6 +906,31 @@ extern "C" size_t collie_mf_eval_workspace_bytes(int64_t n_users, int64_t n_item
 }
 
 namespace {
+
+// Rounds [first_round, ceil(k / kCap)) of a top-k query: a round scores the catalogue (MODE 0),
+// keeping per slot the kCap best items that come strictly after the previous round's last entry,
+// and merges them into columns [16 r, 16 r + 16) of the output.  Round 0 has no cut; a caller that
+// already produced round 0's candidates (the fused top-k + rank-count pass) starts at its merge.
+int topk_rounds(EvalParams& p, int gemm_done_rounds, int32_t k, int32_t has_y_range, float y_lo,
+                float y_hi, float* topk_scores, int64_t* topk_ids, const collie::EvalWs& ws,
+                hipStream_t stream) {
+  const int rounds = (k + kCap - 1) / kCap;
+  for (int r = 0; r < rounds; ++r) {
+    const int kr = k - r * kCap < kCap ? k - r * kCap : kCap;
+    p.k = kr;
+    p.cut_s = r == 0 ? nullptr : ws.cut_s;
+    p.cut_i = r == 0 ? nullptr : ws.cut_i;
+    if (r >= gemm_done_rounds && launch_gemm<0>(stream, p)) return -1;
+    const bool more = r + 1 < rounds;
+    hipLaunchKernelGGL(merge_topk_kernel,
+                       dim3(static_cast<unsigned>((p.n_users + kWaves - 1) / kWaves)), dim3(kBlock),
+                       0, stream, ws.cand_scores, ws.cand_ids, p.n_users, p.nchunks * 2, kr,
+                       has_y_range, y_lo, y_hi, topk_scores, topk_ids, k, r * kCap,
+                       more ? ws.cut_s : nullptr, more ? ws.cut_i : nullptr);
+    if (check_launch("merge_topk_kernel")) return -1;
+  }
+  return 0;
+}
 
 // shared body of collie_mf_eval_topk / collie_mf_eval_topk_static: `ws` is already carved
 int eval_topk_impl(const collie_mf_tables* t, const int64_t* user_ids, int64_t n_users,
@@ -863,11 +949,7 @@ int eval_topk_impl(const collie_mf_tables* t, const int64_t* user_ids, int64_t n
   p.k = k;
   p.cand_scores = ws.cand_scores;
   p.cand_ids = ws.cand_ids;
-  if (launch_gemm<0>(stream, p)) return -1;
-  hipLaunchKernelGGL(merge_topk_kernel, dim3(static_cast<unsigned>((n_users + kWaves - 1) / kWaves)),
-                     dim3(kBlock), 0, stream, ws.cand_scores, ws.cand_ids, n_users, p.nchunks * 2,
-                     k, has_y_range, y_lo, y_hi, topk_scores, topk_ids);
-  return check_launch("merge_topk_kernel");
+  return topk_rounds(p, 0, k, has_y_range, y_lo, y_hi, topk_scores, topk_ids, ws, stream);
 }
 
 int check_topk_args(const collie_mf_tables* t, const int64_t* user_ids, int64_t n_users,
@@ -875,7 +957,7 @@ int check_topk_args(const collie_mf_tables* t, const int64_t* user_ids, int64_t 
                     int32_t k, const float* topk_scores, const int64_t* topk_ids) {
   if (validate_tables(t) || check_range(t, n_users, item_begin, item_end)) return -1;
   COLLIE_REQUIRE(user_ids && topk_scores && topk_ids, "eval_topk: NULL pointer");
-  COLLIE_REQUIRE(k >= 1 && k <= kCap, "eval_topk: k must be in [1, %d] (got %d)", kCap, k);
+  COLLIE_REQUIRE(k >= 1, "eval_topk: k must be >= 1 (got %d)", k);
   COLLIE_REQUIRE(id_stride >= 1 && id_offset >= 0 &&
                      (item_end - 1) * id_stride + id_offset < (int64_t{1} << 31),
                  "eval_topk: bad global id mapping");
@@ -889,7 +971,7 @@ int check_topk_args(const collie_mf_tables* t, const int64_t* user_ids, int64_t 
 // address comes from hipGetSymbolAddress (each GPU holds its own copy at its own address) and is
 // what every kernel argument below uses.
 constexpr int64_t kStaticMaxUsers = 1024;
-constexpr size_t kStaticScratchBytes = (size_t{16} << 20) + 4096;  // 1024 users x 64 chunks x 2 halves
+constexpr size_t kStaticScratchBytes = (size_t{16} << 20) + (size_t{64} << 10);  // 1024 users x 64 chunks x 2 halves
 constexpr int kMaxDevices = 64;
 static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
 void* g_scratch_ptr[kMaxDevices];  // per device, filled on the first call on that device
@@ -966,7 +1048,8 @@ extern "C" int collie_mf_eval_merge_topk(const float* cand_scores, const int32_t
   COLLIE_REQUIRE(n_users >= 1 && nslots >= 1 && k >= 1 && k <= kCap, "merge_topk: bad sizes");
   hipLaunchKernelGGL(merge_topk_kernel, dim3(static_cast<unsigned>((n_users + kWaves - 1) / kWaves)),
                      dim3(kBlock), 0, stream, cand_scores, cand_ids, n_users, nslots, k, 0, 0.0f,
-                     0.0f, topk_scores, topk_ids);
+                     0.0f, topk_scores, topk_ids, k, 0, static_cast<float*>(nullptr),
+                     static_cast<int32_t*>(nullptr));
   return check_launch("merge_topk_kernel");
 }
 
@@ -1044,7 +1127,7 @@ extern "C" int collie_mf_eval_topk_rank_counts(
   if (validate_tables(t) || check_range(t, n_users, item_begin, item_end)) return -1;
   COLLIE_REQUIRE(user_ids && topk_scores && topk_ids && indptr && thr_lo && thr_hi && best_score &&
                      best_id && counts, "eval_topk_rank_counts: NULL pointer");
-  COLLIE_REQUIRE(k >= 1 && k <= kCap, "eval_topk: k must be in [1, %d] (got %d)", kCap, k);
+  COLLIE_REQUIRE(k >= 1, "eval_topk: k must be >= 1 (got %d)", k);
   COLLIE_REQUIRE(id_stride >= 1 && id_offset >= 0 &&
                      (item_end - 1) * id_stride + id_offset < (int64_t{1} << 31),
                  "eval_topk: bad global id mapping");
@@ -1061,7 +1144,7 @@ extern "C" int collie_mf_eval_topk_rank_counts(
   p.item_end = item_end;
   p.id_stride = id_stride;
   p.id_offset = id_offset;
-  p.k = k;
+  p.k = k < kCap ? k : kCap;
   p.cand_scores = ws.cand_scores;
   p.cand_ids = ws.cand_ids;
   p.indptr = indptr;
@@ -1070,16 +1153,14 @@ extern "C" int collie_mf_eval_topk_rank_counts(
   p.best_score = best_score;
   p.best_id = best_id;
   p.counts = reinterpret_cast<unsigned long long*>(counts);
+  int gemm_done = 0;
   if (dma_ok(&p.t)) {
-    if (launch_gemm<2>(stream, p)) return -1;     // one pass: both epilogues
+    if (launch_gemm<2>(stream, p)) return -1;     // one pass: both epilogues (top-k round 0)
+    gemm_done = 1;
   } else {
-    if (launch_gemm<0>(stream, p)) return -1;     // register-staged kernel: two passes
-    if (launch_gemm<1>(stream, p)) return -1;
+    if (launch_gemm<1>(stream, p)) return -1;     // register-staged kernel: separate passes
   }
-  hipLaunchKernelGGL(merge_topk_kernel, dim3(static_cast<unsigned>((n_users + kWaves - 1) / kWaves)),
-                     dim3(kBlock), 0, stream, ws.cand_scores, ws.cand_ids, n_users, p.nchunks * 2,
-                     k, has_y_range, y_lo, y_hi, topk_scores, topk_ids);
-  return check_launch("merge_topk_kernel");
+  return topk_rounds(p, gemm_done, k, has_y_range, y_lo, y_hi, topk_scores, topk_ids, ws, stream);
 }
 
 extern "C" int collie_mf_eval_metrics(const int64_t* topk_ids, int32_t k, int64_t n_users,

@@ -12,8 +12,10 @@ divided by the number of test users (metrics.py:367-386).
 
 Generic route (any other model object or metric callable): ``get_preds`` materialises the score
 matrix through ``model(users, items)`` and each metric callable receives it, as in the reference.
-The callables below then reduce that dense matrix with the same HIP kernels
-(``collie_dense_*``), so no stock torch arithmetic is involved there either.
+The callables below then reduce that dense matrix -- any catalogue size, any ``k`` -- with the
+``collie_preds_*`` HIP kernels (radix-select top-k, streaming rank counts), so no stock torch
+arithmetic is involved there either.  ``k`` above the MFMA kernel's 16 register-resident
+candidates costs one more scoring pass per 16 entries on the fast route.
 """
 import warnings
 from functools import partial
@@ -65,21 +67,6 @@ def _csr_slice(targets: csr_matrix, user_ids, device):
     return indptr, indices
 
 
-def _dense_tables(preds: torch.Tensor):
-    """
-    A dense [n, N] score matrix as MF tables: U = preds (dim N), I = identity would be O(N^2);
-    instead the dense callables run the reduction kernels on one-hot-free inputs by treating every
-    row of ``preds`` as a user whose "embedding" is the row itself against a unit item basis.
-    Only used for small generic-route matrices (the reference's default batch is 20 users).
-    """
-    n, N = preds.shape
-    dev = preds.device
-    eye = torch.eye(N, dtype=torch.float32, device=dev)
-    zeros_u = torch.zeros(n, 1, dtype=torch.float32, device=dev)
-    zeros_i = torch.zeros(N, 1, dtype=torch.float32, device=dev)
-    return _lib.make_tables(preds.contiguous().float(), eye, zeros_u, zeros_i), (eye, zeros_u, zeros_i)
-
-
 def _per_user(tables, user_slots, indptr, indices, n_items, k, y_range, want, ws=None,
               item_range=None):
     """Per-user (ap, rr, auc) device tensors for one launch-sized group of users.  ``indptr`` may
@@ -118,25 +105,23 @@ def _per_user(tables, user_slots, indptr, indices, n_items, k, y_range, want, ws
 def _check_k(k, n_items):
     if k > n_items:
         raise ValueError(f'Ensure ``k`` ({k}) is less than the number of items ({n_items}):')
-    if k > ops.eval_topk_capacity():
-        raise ValueError(f'k={k} exceeds the register-resident top-k capacity '
-                         f'({ops.eval_topk_capacity()}) of the HIP evaluator')
 
 
 def _dense_metric(which, targets, user_ids, preds, k):
+    """One metric over a materialised ``preds [users, items]`` (any catalogue size, any ``k``):
+    the ``collie_preds_*`` kernels stream the rows once per pass; nothing is sorted."""
     _lib.require_hip(preds, 'preds')
     n, N = preds.shape
-    if N > 256:
-        raise _lib.CollieHipError(
-            'the dense metric callables are meant for small score matrices; use '
-            '``evaluate_in_batches`` with a MatrixFactorizationModel for full catalogs')
-    tables, keep = _dense_tables(preds)
-    slots = torch.arange(n, dtype=torch.int64, device=preds.device)
     indptr, indices = _csr_slice(targets, user_ids, preds.device)
-    want = (which == 'ap', which == 'rr', which == 'auc')
-    out = _per_user(tables, slots, indptr, indices, N, k, None, want)
-    del keep
-    return out
+    if which == 'ap':
+        _, ids = ops.preds_topk(preds, k)
+        return ops.eval_metrics(ids, k, n, N, indptr, indices, None, None, None,
+                                True, False, False)
+    pos, lo, hi, best_s, best_id = ops.preds_pos_scores(preds, indptr, indices)
+    counts = torch.zeros(n, 3, dtype=torch.int64, device=preds.device)
+    ops.preds_rank_counts(preds, indptr, lo, hi, best_s, best_id, counts)
+    return ops.eval_metrics(None, 1, n, N, indptr, indices, pos, counts, None,
+                            False, which == 'rr', which == 'auc')
 
 
 def mapk(targets: csr_matrix, user_ids, preds, k: int = 10) -> float:
@@ -219,7 +204,6 @@ def evaluate_in_batches(
     from collie_amd.model import MatrixFactorizationModel
     fast = (isinstance(model, MatrixFactorizationModel) and model._mf_eval_fast
             and all(m in _FAST for m in metric_list)
-            and k <= ops.eval_topk_capacity()
             and model.hparams.embedding_dim <= 256)
 
     if fast:

@@ -572,6 +572,52 @@ def eval_metrics(topk_ids, k, n_users, n_items, indptr, indices, pos_scores, cou
     return ap, rr, auc
 
 
+# ---- metric reductions over a materialised score matrix (generic route) ---------------------------
+def _preds_arg(preds):
+    require_hip(preds, 'preds')
+    if preds.dim() != 2:
+        raise ValueError('preds must be a [users, items] matrix')
+    if preds.dtype != torch.float32 or preds.stride(1) != 1:
+        preds = preds.float().contiguous()
+    ld = preds.stride(0) if preds.shape[0] > 1 else preds.shape[1]
+    return preds, ld
+
+
+def preds_topk(preds, k):
+    """``preds.topk(k, dim=1)`` with ties in ascending id order (``collie_preds_topk``)."""
+    preds, ld = _preds_arg(preds)
+    n, N = preds.shape
+    scores = torch.empty(n, k, dtype=torch.float32, device=preds.device)
+    ids = torch.empty(n, k, dtype=torch.int64, device=preds.device)
+    check(load().collie_preds_topk(ptr(preds), n, N, ld, k, ptr(scores), ptr(ids), stream_ptr()),
+          'collie_preds_topk')
+    return scores, ids
+
+
+def preds_pos_scores(preds, indptr, indices, status=None):
+    preds, ld = _preds_arg(preds)
+    n, N = preds.shape
+    nnz = indices.shape[0]
+    dev = preds.device
+    pos = torch.empty(max(nnz, 1), dtype=torch.float32, device=dev)
+    lo = torch.empty(max(nnz, 1), dtype=torch.float32, device=dev)
+    hi = torch.empty(max(nnz, 1), dtype=torch.float32, device=dev)
+    best_s = torch.empty(n, dtype=torch.float32, device=dev)
+    best_id = torch.empty(n, dtype=torch.int64, device=dev)
+    check(load().collie_preds_pos_scores(ptr(preds), n, N, ld, ptr(indptr), ptr(indices), nnz,
+                                         ptr(pos), ptr(lo), ptr(hi), ptr(best_s), ptr(best_id),
+                                         ptr(status), stream_ptr()), 'collie_preds_pos_scores')
+    return pos, lo, hi, best_s, best_id
+
+
+def preds_rank_counts(preds, indptr, lo, hi, best_s, best_id, counts):
+    preds, ld = _preds_arg(preds)
+    n, N = preds.shape
+    check(load().collie_preds_rank_counts(ptr(preds), n, N, ld, ptr(indptr), ptr(lo), ptr(hi),
+                                          ptr(best_s), ptr(best_id), ptr(counts), stream_ptr()),
+          'collie_preds_rank_counts')
+
+
 def eval_merge_topk(cand_scores, cand_ids, k):
     n, nslots, cap = cand_scores.shape
     assert cap == eval_topk_capacity() and cand_ids.dtype == torch.int32

@@ -354,6 +354,35 @@ int collie_mf_eval_metrics(const int64_t* topk_ids, int32_t k, int64_t n_users, 
                            const uint64_t* counts, int32_t has_y_range, float y_lo, float y_hi,
                            double* ap, float* rr, double* auc, collie_stream_t stream);
 
+/* ---- metric callables on a materialised score matrix (generic route) ----------------------------
+ * mapk / mrr / auc(targets, user_ids, preds, k) (collie/metrics.py:144-282) receive
+ * preds [n_rows, n_cols] from get_preds (metrics.py:77-107) for ANY model and catalogue size.
+ * preds is row-major with row stride ld (elements); n_cols < 2^31.
+ *
+ * collie_preds_topk: preds.topk(k, dim=1) (metrics.py:171) for any 1 <= k <= n_cols: topk_scores /
+ * topk_ids [n_rows, k], descending score, ascending column on exact ties (-0.0 == +0.0; NaN above
+ * +inf, as torch.topk).  No workspace. */
+int collie_preds_topk(const float* preds, int64_t n_rows, int64_t n_cols, int64_t ld, int32_t k,
+                      float* topk_scores, int64_t* topk_ids, collie_stream_t stream);
+
+/* The positives' scores gathered from preds (CSR over the rows: indptr [n_rows+1], indices [nnz]
+ * ascending inside a row, metrics.py:135-141) plus what collie_mf_eval_pos_scores derives from
+ * them: thr_lo / thr_hi [nnz] (raw-score interval with the same fp32 sigmoid, metrics.py:277) and
+ * the best positive per row (metrics.py:224-238).  Column ids outside [0, n_cols) set bit 0 of
+ * *status and score 0. */
+int collie_preds_pos_scores(const float* preds, int64_t n_rows, int64_t n_cols, int64_t ld,
+                            const int64_t* indptr, const int64_t* indices, int64_t nnz,
+                            float* pos_scores, float* thr_lo, float* thr_hi, float* best_score,
+                            int64_t* best_id, int32_t* status, collie_stream_t stream);
+
+/* Rank counters of collie_mf_eval_rank_counts (same three definitions) over preds, ADDED into
+ * counts [n_rows, 3] (uint64, zero before the call): what mrr (metrics.py:224-240: full descending
+ * order) and auc (metrics.py:266-282) need, without sorting the rows. */
+int collie_preds_rank_counts(const float* preds, int64_t n_rows, int64_t n_cols, int64_t ld,
+                             const int64_t* indptr, const float* thr_lo, const float* thr_hi,
+                             const float* best_score, const int64_t* best_id, uint64_t* counts,
+                             collie_stream_t stream);
+
 /* item_item_similarity / user_user_similarity (base_pipeline.py:785-864): cosine similarity of every
  * row of one embedding table [rows, dim] with row `id`; out [rows]. */
 int collie_embedding_similarity(const float* emb, int64_t rows, int32_t dim, int64_t id, float* out,
