@@ -239,7 +239,7 @@ __global__ __launch_bounds__(kBlock) void mf_train_fwd_kernel(const FwdParams p)
     const bool live = g != 0.0f;
     const int sel_item = __shfl(item, sel, kWave);
     const int pos_item_b = __shfl(item, 0, kWave);
-    if (lane <= K) p.ws.touch_item[item] = p.step_id;
+    if (lane <= K) p.ws.touch_item[item] = touch_tag(p.step_id);
     if (lane < 3) {  // lane 0: user entry, lane 1: positive item, lane 2: selected negative
       const int64_t slot = lane == 0 ? b : B + 2 * b + (lane - 1);
       const uint32_t key =
@@ -532,7 +532,7 @@ __global__ __launch_bounds__(kBlock) void mf_train_fwd_fast(const FwdParams p) {
     }
 #pragma unroll
     for (int pass = 0; pass < NPASS; ++pass)
-      if (lig == 0 && pass * RPW + grp <= K) p.ws.touch_item[item[pass]] = p.step_id;
+      if (lig == 0 && pass * RPW + grp <= K) p.ws.touch_item[item[pass]] = touch_tag(p.step_id);
     if (lane < 3) {  // lane 0: user entry, lane 1: positive item, lane 2: selected negative
       const int64_t slot = lane == 0 ? b : B + 2 * b + (lane - 1);
       const uint32_t key =
@@ -608,7 +608,7 @@ struct LdsParams {
   int64_t batch;
   int32_t num_users, num_items;
   int32_t num_neg, dim;
-  int32_t* touch_item;
+  uint8_t* touch_item;
   uint32_t* ekeys;
   uint32_t* ecodes;
   float* gcoef;
@@ -691,6 +691,7 @@ __global__ __launch_bounds__(kBlock, (CH * NP <= 4 ? 8 : 4)) void mf_train_fwd_l
   const int D = p.dim;
   const int64_t B = p.batch;
   const uint32_t key_off = static_cast<uint32_t>(p.num_users);
+  const int tag = touch_tag(p.step_id);
   float4* const items_l = &park[wave_in_block][0];
   float4* const user_l = &park[wave_in_block][kItemF4];
   bool row_lane[NP], neg_lane[NP];
@@ -882,7 +883,7 @@ __global__ __launch_bounds__(kBlock, (CH * NP <= 4 ? 8 : 4)) void mf_train_fwd_l
     const bool live = g != 0.0f;
 #pragma unroll
     for (int q = 0; q < NP; ++q)
-      if (lig == 0 && row_lane[q] && stamp[q] != p.step_id) p.touch_item[item[q]] = p.step_id;
+      if (lig == 0 && row_lane[q] && stamp[q] != tag) p.touch_item[item[q]] = static_cast<uint8_t>(tag);
     if (live) {  // lane l stages 16-byte chunks l, l + 64, ... of the two rows (dim 512: two)
 #pragma unroll
       for (int c0 = 0; c0 < CH * LPR; c0 += kWave) {
@@ -1149,6 +1150,9 @@ extern "C" int collie_mf_train_forward(const collie_mf_tables* t, const collie_m
   TrainWs ws = carve_train_ws(workspace, b->batch, b->num_neg, t->dim, t->num_users, t->num_items);
   COLLIE_REQUIRE(workspace != nullptr && workspace_bytes >= ws.bytes,
                  "workspace too small: need %zu bytes, got %zu", ws.bytes, workspace_bytes);
+  // the 8-bit stamp tags start a new cycle: forget the previous cycle's stamps (train_ws.h)
+  if (need_grad && step_id % kTouchCycle == 0)
+    COLLIE_CHECK_HIP(hipMemsetAsync(ws.touch_item, 0, static_cast<size_t>(t->num_items), stream));
 
   FwdParams p;
   p.t = *t;

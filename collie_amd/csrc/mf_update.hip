@@ -415,7 +415,7 @@ __global__ __launch_bounds__(kBlock) void dense_sweep_kernel(float* __restrict__
 __global__ __launch_bounds__(kBlock) void touched_sweep_kernel(float* __restrict__ table,
                                                                float* __restrict__ s1p,
                                                                float* __restrict__ s2p,
-                                                               const int32_t* __restrict__ touch,
+                                                               const uint8_t* __restrict__ touch,
                                                                const int32_t* __restrict__ seg,
                                                                int64_t rows, int D, int step,
                                                                const Hyper h) {
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(kBlock) void touched_sweep_kernel(float* __restrict
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < total;
        i += stride) {
     const int64_t row = i / D;
-    if (touch[row] != step || seg[row] == step) continue;
+    if (touch[row] != touch_tag(step) || seg[row] == step) continue;
     float s1 = s1p[i];
     float s2 = s2p[i];
     table[i] = apply_update(h, table[i], 0.0f, s1, s2);
@@ -441,7 +441,7 @@ template <int LPR>
 __global__ __launch_bounds__(kBlock) void touched_rows_kernel(float* __restrict__ table,
                                                               float* __restrict__ s1p,
                                                               float* __restrict__ s2p,
-                                                              const int32_t* __restrict__ touch,
+                                                              const uint8_t* __restrict__ touch,
                                                               const int32_t* __restrict__ seg,
                                                               int64_t rows, int D, int step,
                                                               const Hyper h) {
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(kBlock) void touched_rows_kernel(float* __restrict_
   for (int64_t base = (static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave) * kWave;
        base < rows; base += nwaves * kWave) {
     const int64_t r = base + lane;
-    const bool need = r < rows && touch[r] == step && seg[r] != step;
+    const bool need = r < rows && touch[r] == touch_tag(step) && seg[r] != step;
     const unsigned long long mask = __ballot(need);
     if (mask == 0ull) continue;
     const int n = __popcll(mask);
@@ -499,11 +499,11 @@ __global__ __launch_bounds__(kBlock) void touched_rows_kernel(float* __restrict_
   }
 }
 
-__global__ __launch_bounds__(kBlock) void export_touched_kernel(const int32_t* __restrict__ touch,
+__global__ __launch_bounds__(kBlock) void export_touched_kernel(const uint8_t* __restrict__ touch,
                                                                 int64_t rows, int step,
                                                                 uint8_t* __restrict__ out) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
-  if (i < rows) out[i] = touch[i] == step ? 1 : 0;
+  if (i < rows) out[i] = touch[i] == touch_tag(step) ? 1 : 0;
 }
 
 // entries of a stand-alone sparse gradient: key = row id (clamped), code = position in vals

@@ -155,8 +155,9 @@ int64_t collie_loss_partials(int64_t batch);
  * s_pos_out [B] and s_neg_out [K,B] (reference layout) are optional (NULL to skip).
  *
  * The workspace belongs to ONE model: it must be zero-filled when created and is then reused by
- * every step.  step_id (>= 1, increasing by one per forward with need_grad) tags the per-item
- * "looked up in this step" stamps kept inside it.
+ * every step.  step_id (>= 1, increasing by EXACTLY one per forward with need_grad on a workspace)
+ * tags the per-item "looked up in this step" stamps kept inside it (one byte per item, cleared by
+ * this call every 255 steps).
  * ------------------------------------------------------------------------------------------- */
 size_t collie_mf_train_workspace_bytes(int64_t batch, int32_t num_neg, int32_t dim,
                                        int64_t num_users, int64_t num_items);

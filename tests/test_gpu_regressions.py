@@ -104,3 +104,46 @@ def test_dense_adam_row_stamps_survive_workspace_recreation():
                                      .cpu().numpy().copy()])
     for a, b in zip(*results):
         np.testing.assert_array_equal(a, b)
+
+
+def test_byte_stamps_survive_their_255_step_cycle():
+    """The per-item "looked up in this step" stamps are 8-bit tags that repeat every 255 steps
+    (csrc/train_ws.h); the forward call clears them when a cycle restarts.  300 SparseAdam steps on
+    one workspace must equal, bit for bit, the same steps with the workspace re-created (fresh
+    zero stamps, same step numbering) after step 200: without the clear, items stamped at step 1
+    would count as looked up at step 256 and have their moments decayed."""
+    dev = torch.device('cuda:0')
+    from collie_amd.model import MatrixFactorizationModel
+
+    class Wide:
+        num_users, num_items, num_negative_samples = 60, 2000, 5
+
+    rng = np.random.default_rng(11)
+    batches = [((torch.tensor(rng.integers(0, 60, 8), dtype=torch.int32, device=dev),
+                 torch.tensor(rng.integers(0, 2000, 8), dtype=torch.int32, device=dev)),
+                torch.tensor(rng.integers(0, 2000, (8, 5)), device=dev)) for _ in range(300)]
+    results = []
+    for recreate in (False, True):
+        torch.manual_seed(0)
+        m = MatrixFactorizationModel(train=Wide(), embedding_dim=16, lr_scheduler_func=None,
+                                     sparse=True, optimizer='sparse_adam', bias_optimizer='sgd',
+                                     loss='adaptive_bpr', lr=1e-2)
+        with torch.no_grad():
+            m.item_embeddings.weight.mul_(10.0)
+            m.user_embeddings.weight.mul_(10.0)
+        m.to(dev).train()
+        opts = m.configure_optimizers()
+        for i, b in enumerate(batches):
+            if recreate and i == 200:
+                m._retire_workspace()
+            for o in opts:
+                o.zero_grad()
+            m.calculate_loss(b).backward()
+            for o in opts:
+                o.step()
+        assert m._workspace.step_id == 300
+        st = opts[0].state[m.item_embeddings.weight]
+        results.append(_tables(m) + [st['exp_avg'].cpu().numpy().copy(),
+                                     st['exp_avg_sq'].cpu().numpy().copy()])
+    for a, b in zip(*results):
+        np.testing.assert_array_equal(a, b)
