@@ -1177,10 +1177,15 @@ extern "C" int collie_mf_train_forward(const collie_mf_tables* t, const collie_m
   if (nblocks > kMaxLossBlocks) nblocks = kMaxLossBlocks;
   dim3 grid(static_cast<unsigned>(nblocks));
   // LDS-parked variant: the widest lane groups that give every row of the sample its own group in
-  // ONE pass (measured: at K = 10 one pass of 4-lane groups beats two passes of 8-lane groups by 15 %
-  // on cache-resident tables and ties on HBM-resident ones); two passes only when K needs them
+  // ONE pass; two passes only when K needs them.  Rows of >= 512 bytes (dim >= 128) are taken in
+  // 128-byte pieces (8-lane groups) even when that costs a second pass: a 64-byte piece is half an
+  // L2 line, and random rows gathered in half lines read 22 % slower from HBM
+  // (profiles/r02_fetch_size_calibration.json; this kernel on the 100 M x 10 M shape: -4 %, the same
+  // time on cache-resident tables).  At dim 64 one pass of 4-lane groups stays (two passes of
+  // 8-lane groups measured 15 % slower on the cache-resident ML-20M shape).
   int lds_lpr = 16;
   while (lds_lpr > 4 && (lds_lpr > p.nchunks || kWave / lds_lpr < b->num_neg + 1)) lds_lpr /= 2;
+  if (lds_lpr == 4 && p.nchunks >= 32 && b->num_neg + 1 <= 2 * (kWave / 8)) lds_lpr = 8;
   const int lds_groups = kWave / lds_lpr;
   const int lds_np = (b->num_neg + 1 + lds_groups - 1) / lds_groups;
   const int lds_ch = p.nchunks / lds_lpr;

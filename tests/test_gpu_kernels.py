@@ -268,7 +268,8 @@ def test_fused_step_vs_oracle_seeded(dev, B, K, D, U, N):
                                         (1500, 5, 32, 'warp'), (1000, 30, 128, 'adaptive_bpr'),
                                         (1200, 17, 256, 'warp'), (900, 3, 16, 'adaptive_hinge'),
                                         (800, 1, 512, 'bpr'), (800, 3, 512, 'adaptive_bpr'),
-                                        (700, 3, 512, 'warp')])
+                                        (700, 3, 512, 'warp'), (1000, 10, 256, 'adaptive_bpr'),
+                                        (1100, 15, 128, 'warp'), (900, 12, 256, 'adaptive_hinge')])
 def test_fused_step_lds_parked_variants_vs_oracle(dev, B, K, D, kind):
     """The LDS-parked forward variants (one and two gather passes; picked when no score outputs
     are requested): loss, coalesced gradients and the updated tables vs the numpy oracle."""
