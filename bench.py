@@ -10,13 +10,17 @@ A "step" is one pass of the hot path over one batch that is already resident in 
 segment-reduce/row-update kernels), all through the product API.  Negative sampling is done on the
 device before the timed region.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): the same workload with the four
-tables row-sharded over the ranks (``collie_amd/sharded.py``: all-to-all row lookup, fused forward on
-the compact tables, all-to-all of the gradient rows, owner-side update).  Every rank trains on its
-own batch of ``--batch`` positives per step (weak scaling); ``value`` counts all ranks' interactions.
+N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): BASELINE configs[3], the config
+north_star's scaling target is stated on -- 100M users x 10M items x 128 with the four tables
+row-sharded over the ranks (``collie_amd/sharded.py``: all-to-all row lookup, fused forward on the
+compact tables, all-to-all of the gradient rows, owner-side update).  The GLOBAL batch (``--batch``
+positives) is split evenly over the ranks: strong scaling; ``value`` counts all ranks' interactions.
+The same tables and batch on ONE GPU are the ``c4`` object of the N = 1 line.
 
-A second, untimed-by-the-contract leg reports the other half of BASELINE.json's metric, "eval
-users/sec MAP@10", on configs[2]'s shape (1M x 1M, dim 128; a sample of the users) under ``eval``.
+Further objects of the N = 1 line: ``c4`` (above: the step on tables no cache holds, with its own
+K1 roofline and whole-step fraction), ``eval`` (the other half of BASELINE.json's metric, "eval
+users/sec MAP@10", on configs[2]'s shape: 1M x 1M, dim 128, a sample of the users) and ``hybrid``
+(configs[4], the MLP head).
 
 Contract: ``python bench.py --gpus N --steps K --warmup W`` prints ONE JSON line on rank 0.
 """
@@ -39,10 +43,23 @@ WORKLOAD = ('BASELINE configs[1]: synthetic ML-20M shape 138493 users x 26744 it
             'adaptive BPR + 10 negatives, SparseAdam + SGD bias')
 
 
+C4_WORKLOAD = ('BASELINE configs[3] tables: synthetic 100M users x 10M items, MF dim=128, adaptive '
+               'BPR + 10 negatives, SparseAdam + SGD bias')
+SHAPES = {'c2': (138_493, 26_744, 20_000_263, 64, WORKLOAD),
+          'c4': (100_000_000, 10_000_000, 0, 128, C4_WORKLOAD)}
+
+
 class _Shape:
     """What the model constructor reads from a train loader (sizes only: data is synthetic)."""
     num_users, num_items, num_negative_samples = NUM_USERS, NUM_ITEMS, NUM_NEG
     num_interactions = NUM_INTERACTIONS
+
+
+def set_shape(name):
+    global NUM_USERS, NUM_ITEMS, NUM_INTERACTIONS, DIM, WORKLOAD
+    NUM_USERS, NUM_ITEMS, NUM_INTERACTIONS, DIM, WORKLOAD = SHAPES[name]
+    _Shape.num_users, _Shape.num_items = NUM_USERS, NUM_ITEMS
+    _Shape.num_interactions = NUM_INTERACTIONS
 
 
 def build_model(device):
@@ -115,20 +132,21 @@ def step_algorithmic_bytes(batch_tensors):
 def pmc_traffic(shape, batch):
     """
     HBM-side bytes per launch of the forward kernel, from the committed rocprofv3 --pmc passes of
-    this same command (profiles/r01_pmc_traffic.json, written by tools/summarize_profiles.py:
+    this same command (profiles/rNN_pmc_traffic.json, written by tools/summarize_profiles.py:
     FETCH_SIZE and WRITE_SIZE collected in separate runs, KiB -> bytes, FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for gfx950).  A PMC pass cannot run inside the timed benchmark,
     so the number is read, not measured live; None when no pass was recorded for this workload.
     """
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
-    try:
-        with open(path) as f:
-            per_kernel = json.load(f).get(f'{shape}_B{batch}', {})
-    except (OSError, ValueError):
-        return None
-    for name, rec in per_kernel.items():
-        if name.startswith('mf_train_fwd_lds'):
-            return rec['hbm_bytes_per_launch']
+    for rnd in ('r02', 'r01'):              # the newest committed passes of this command
+        path = os.path.join(ROOT, 'profiles', f'{rnd}_pmc_traffic.json')
+        try:
+            with open(path) as f:
+                per_kernel = json.load(f).get(f'{shape}_B{batch}', {})
+        except (OSError, ValueError):
+            continue
+        for name, rec in per_kernel.items():
+            if name.startswith('mf_train_fwd_lds'):
+                return rec['hbm_bytes_per_launch']
     return None
 
 
@@ -235,19 +253,23 @@ def hybrid_leg(steps, warmup, batch=65536, cpu_seconds=0.0):
 
 
 def main_sharded(args, world, rank, device):
-    """N > 1: row-sharded tables, one rank per GPU, RCCL all-to-all each way."""
+    """N > 1: BASELINE configs[3] -- the 100M x 10M x 128 tables row-sharded over the ranks, one
+    rank per GPU, RCCL all-to-all each way; the GLOBAL batch is fixed and split evenly over the
+    ranks (strong scaling)."""
     import torch.distributed as dist
     from collie_amd.sharded import ShardedMatrixFactorizationModel
+    set_shape(args.sharded_shape)
     backend = os.environ.get('COLLIE_BENCH_BACKEND', 'nccl')   # 'gloo': rehearsal on one GPU
     if backend == 'nccl':
         dist.init_process_group('nccl', device_id=device)
     else:
         dist.init_process_group(backend)
+    local_batch = args.batch // world
     model = ShardedMatrixFactorizationModel(NUM_USERS, NUM_ITEMS, NUM_NEG, embedding_dim=DIM,
                                             lr=1e-3, bias_lr=1e-2, optimizer='sparse_adam',
                                             bias_optimizer='sgd', loss='bpr', device=device, seed=0)
-    n_distinct = min(args.steps + args.warmup, 32)
-    batches = synthetic_batches(n_distinct, args.batch, device, args.dist, seed=1234 + rank)
+    n_distinct = min(args.steps + args.warmup, 16)
+    batches = synthetic_batches(n_distinct, local_batch, device, args.dist, seed=1234 + rank)
     for i in range(args.warmup):
         model.train_step(batches[i % n_distinct])
     dist.barrier()
@@ -268,23 +290,23 @@ def main_sharded(args, world, rank, device):
     t = torch.tensor([elapsed], device=device, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    ev = None
-    if args.eval_users > 0:
-        ev = eval_leg(device, args.eval_users, world, rank)
     if rank == 0:
-        per_step = args.batch * (1 + NUM_NEG)
+        per_step = local_batch * world * (1 + NUM_NEG)
         result = {
             'metric': 'train interactions/sec (pos+negs)',
-            'value': world * per_step * args.steps / elapsed, 'unit': 'interactions/s',
+            'value': per_step * args.steps / elapsed, 'unit': 'interactions/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {
-                'workload': WORKLOAD,
-                'batch_per_gpu': args.batch, 'global_batch': args.batch * world,
+                'workload': WORKLOAD + f'; global batch {local_batch * world} positives split evenly '
+                            f'over {world} GPUs (strong scaling)',
+                'batch_per_gpu': local_batch, 'global_batch': local_batch * world,
                 'id_distribution': args.dist,
                 'parallelism': f'tables row-sharded over {world} GPUs (owner = row mod {world}), '
                                'RCCL all-to-all lookup + gradient exchange',
+                'single_gpu_same_workload': "the 'c4' object of the N=1 line (python bench.py): "
+                                            'same tables and global batch on one GPU, fused route',
                 'final_loss': float(loss.item()),
                 'rows_exchanged_per_rank_per_step': model.last_exchange.get('rows_requested'),
                 'phase_ms_rank0': phases,
@@ -294,8 +316,9 @@ def main_sharded(args, world, rank, device):
         fwd_ms = phases.get('forward_backward')
         if fwd_ms:
             # rank 0's K1 launch on its compact tables (the phase between the row exchange and the
-            # segment reduce: K1 + loss finalize), same algorithmic bytes as the single-GPU line
-            alg = fwd_algorithmic_bytes(args.batch)
+            # gradient exchange: K1 + loss finalize + segment export), same algorithmic bytes per
+            # positive as the single-GPU line
+            alg = fwd_algorithmic_bytes(local_batch)
             achieved = alg / (fwd_ms * 1e-3) / 1e9
             result['roofline'] = {
                 'kernel': 'mf_train_fwd_lds on rank 0 (sharded route: gathers from the compact row '
@@ -303,10 +326,70 @@ def main_sharded(args, world, rank, device):
                 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
                 'algorithmic_bytes_per_launch': alg, 'avg_launch_ms': fwd_ms}
-        if ev is not None:
-            result['eval'] = ev
         print(json.dumps(result))
     dist.destroy_process_group()
+
+
+def train_leg(shape, args, device, steps, warmup):
+    """One single-GPU training measurement on ``shape``: the step through the product API with HIP
+    events around calculate_loss (K1 + loss finalize) on torch's current stream (the stream the
+    library launches on)."""
+    set_shape(shape)
+    model = build_model(device)
+    optimizers = model.configure_optimizers()
+    n_distinct = min(steps + warmup, 32 if shape == 'c2' else 8)
+    batches = synthetic_batches(n_distinct, args.batch, device, args.dist, seed=1234)
+    for i in range(warmup):
+        train_step(model, optimizers, batches[i % n_distinct])
+    fwd_events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                  for _ in range(steps)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        batch = batches[(warmup + i) % n_distinct]
+        for opt in optimizers:
+            opt.zero_grad()
+        fwd_events[i][0].record()
+        loss = model.calculate_loss(batch)
+        fwd_events[i][1].record()
+        loss.backward()
+        for opt in optimizers:
+            opt.step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    model.check_status()
+    final_loss = float(loss.item())
+    step_bytes, u_star, i_star = step_algorithmic_bytes(batches[0])
+    fwd_ms = float(np.mean([a.elapsed_time(b) for a, b in fwd_events]))
+    per_step = args.batch * (1 + NUM_NEG)
+    alg = fwd_algorithmic_bytes(args.batch)
+    achieved = alg / (fwd_ms * 1e-3) / 1e9
+    lds_variant = {64: 'CH=4,LPR=4,NP=1', 128: 'CH=4,LPR=8,NP=2'}.get(DIM, '?')
+    out = {
+        'value': per_step * steps / elapsed, 'unit': 'interactions/s', 'steps': steps,
+        'warmup': warmup, 'ms_per_step': elapsed / steps * 1e3,
+        'config': {'workload': WORKLOAD, 'batch_per_gpu': args.batch, 'global_batch': args.batch,
+                   'id_distribution': args.dist, 'parallelism': 'single GPU',
+                   'final_loss': final_loss},
+        'roofline': {
+            'kernel': f'mf_train_fwd_lds<{lds_variant},KIND=bpr,META=0> (+ loss_finalize_kernel, '
+                      '5 us): calculate_loss = fused gather + dot + loss + backward staging',
+            'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic(shape, args.batch),
+            'algorithmic_bytes_per_launch': alg, 'avg_launch_ms': fwd_ms,
+            'whole_step': {
+                'note': 'all kernels of the step (forward + coalesce + optimizer row updates): '
+                        'SURVEY.md 8d bytes_step = idx + fwd + opt over wall time per step',
+                'algorithmic_bytes_per_step': step_bytes, 'unique_user_rows': u_star,
+                'unique_item_rows': i_star,
+                'achieved': step_bytes / (elapsed / steps) / 1e9, 'unit': 'GB/s',
+                'frac': step_bytes / (elapsed / steps) / 1e9 / HBM_PEAK_GBS,
+            },
+        },
+    }
+    del model, optimizers, batches
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -315,18 +398,24 @@ def main():
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=1048576,
-                    help='positives per step per GPU (SURVEY.md 8d lists 1024, 65536, 1048576)')
+                    help='positives per step (SURVEY.md 8d lists 1024, 65536, 1048576); with '
+                         '--gpus N > 1 the GLOBAL batch, split evenly over the ranks')
     ap.add_argument('--dist', choices=['uniform', 'zipf'], default='uniform')
     ap.add_argument('--shape', choices=['c2', 'c4', 'c5'], default='c2',
                     help="c2 = BASELINE configs[1] (the headline line); c4 = configs[3]'s tables "
                          '(100M users x 10M items, dim 128) on ONE GPU: the shape no cache holds; '
                          'c5 = configs[4], the hybrid MLP head (tools/hybrid_bench.py)')
+    ap.add_argument('--sharded-shape', choices=['c2', 'c4'], default='c4',
+                    help="tables of the N > 1 run (default: configs[3], north_star's scaling config)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--eval-users', type=int, default=65536,
                     help='users in the eval leg (0 = skip it)')
     ap.add_argument('--hybrid-steps', type=int, default=10,
                     help="steps of the configs[4] leg (hybrid MLP head, reported under 'hybrid'; "
                          '0 = skip it; single-GPU runs only)')
+    ap.add_argument('--c4-steps', type=int, default=10,
+                    help="steps of the configs[3]-tables-on-one-GPU leg reported under 'c4' (the "
+                         'HBM-resident shape; 0 = skip it; default shape only)')
     args = ap.parse_args()
 
     if args.shape == 'c5':
@@ -334,12 +423,6 @@ def main():
                                     args.batch if args.batch != 1048576 else 65536,
                                     0.0 if args.no_cpu_baseline else 12.0)))
         return
-    if args.shape == 'c4':
-        global NUM_USERS, NUM_ITEMS, NUM_INTERACTIONS, DIM, WORKLOAD
-        NUM_USERS, NUM_ITEMS, NUM_INTERACTIONS, DIM = 100_000_000, 10_000_000, 0, 128
-        _Shape.num_users, _Shape.num_items = NUM_USERS, NUM_ITEMS
-        WORKLOAD = ('BASELINE configs[3] tables on one GPU: synthetic 100M users x 10M items, MF '
-                    'dim=128, adaptive BPR + 10 negatives, SparseAdam + SGD bias')
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -351,104 +434,36 @@ def main():
     device = torch.device('cuda', local_rank)
     if world > 1:
         return main_sharded(args, world, rank, device)
-    dist_on = False
 
-    model = build_model(device)
-    optimizers = model.configure_optimizers()
-    n_distinct = min(args.steps + args.warmup, 32)
-    batches = synthetic_batches(n_distinct, args.batch, device, args.dist, seed=1234 + rank)
-
-    for i in range(args.warmup):
-        train_step(model, optimizers, batches[i % n_distinct])
-
-    fwd_events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                  for _ in range(args.steps)]
-    if dist_on:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        batch = batches[(args.warmup + i) % n_distinct]
-        for opt in optimizers:
-            opt.zero_grad()
-        fwd_events[i][0].record()
-        loss = model.calculate_loss(batch)
-        fwd_events[i][1].record()
-        loss.backward()
-        for opt in optimizers:
-            opt.step()
-    if dist_on:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    model.check_status()
-    final_loss = float(loss.item())
-
-    if dist_on:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    if rank == 0:
-        step_bytes, u_star, i_star = step_algorithmic_bytes(batches[0])
-        fwd_ms = float(np.mean([a.elapsed_time(b) for a, b in fwd_events]))
-        per_step = args.batch * (1 + NUM_NEG)
-        value = world * per_step * args.steps / elapsed
-        alg = fwd_algorithmic_bytes(args.batch)
-        achieved = alg / (fwd_ms * 1e-3) / 1e9
-        result = {
-            'metric': 'train interactions/sec (pos+negs)',
-            'value': value,
-            'unit': 'interactions/s',
-            'n_gpus': world,
-            'steps': args.steps,
-            'warmup': args.warmup,
-            'ms_per_step': elapsed / args.steps * 1e3,
-            'higher_is_better': True,
-            'scaling': 'weak',
-            'vs_baseline': None,
-            'dtype': 'f32',
-            'data': 'synthetic',
-            'config': {
-                'workload': WORKLOAD,
-                'batch_per_gpu': args.batch, 'global_batch': args.batch * world,
-                'id_distribution': args.dist,
-                'parallelism': 'single GPU' if world == 1 else f'{world} independent replicas',
-                'final_loss': final_loss,
-            },
-            'roofline': {
-                'kernel': ('mf_train_fwd_lds<CH=4,LPR=4,NP=1,KIND=bpr,META=0>' if DIM == 64 else
-                           'mf_train_fwd_lds<CH=8,LPR=4,NP=1,KIND=bpr,META=0>') +
-                          ' (+ loss_finalize_kernel, 5 us): calculate_loss = '
-                          'fused gather + dot + loss + backward staging',
-                'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic(args.shape, args.batch),
-                'algorithmic_bytes_per_launch': alg, 'avg_launch_ms': fwd_ms,
-                'whole_step': {
-                    'note': 'all kernels of the step (forward + coalesce + optimizer row updates): '
-                            'SURVEY.md 8d bytes_step = idx + fwd + opt over wall time per step',
-                    'algorithmic_bytes_per_step': step_bytes, 'unique_user_rows': u_star,
-                    'unique_item_rows': i_star,
-                    'achieved': step_bytes / (elapsed / args.steps) / 1e9, 'unit': 'GB/s',
-                    'frac': step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
-                },
-            },
-        }
-        if not args.no_cpu_baseline and world == 1:
-            result['cpu_baseline'] = cpu_baseline()
-        if args.eval_users > 0:
-            del model, optimizers, batches
-            torch.cuda.empty_cache()
-            result['eval'] = eval_leg(device, args.eval_users)
-        if args.hybrid_steps > 0 and args.shape == 'c2':
-            model = optimizers = batches = None
-            torch.cuda.empty_cache()
-            leg = hybrid_leg(args.hybrid_steps, 3)
-            result['hybrid'] = {k: leg[k] for k in ('metric', 'value', 'unit', 'ms_per_step',
-                                                    'config', 'roofline')}
-        print(json.dumps(result))
-    if dist_on:
-        dist.destroy_process_group()
+    leg = train_leg(args.shape, args, device, args.steps, args.warmup)
+    result = {
+        'metric': 'train interactions/sec (pos+negs)', 'value': leg['value'],
+        'unit': 'interactions/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': leg['ms_per_step'], 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic', 'config': leg['config'],
+        'roofline': leg['roofline'],
+    }
+    if not args.no_cpu_baseline:
+        set_shape(args.shape)
+        result['cpu_baseline'] = cpu_baseline()
+    if args.c4_steps > 0 and args.shape == 'c2':
+        free, _ = torch.cuda.mem_get_info(device)
+        if free >= 190 * 2 ** 30:
+            # the same step on tables no cache holds (169 GB with the SparseAdam moments): the
+            # headline's 42 MB tables live in L2 / the Infinity Cache, these in HBM
+            c4 = train_leg('c4', args, device, args.c4_steps, 3)
+            result['c4'] = {k: c4[k] for k in ('value', 'unit', 'steps', 'warmup', 'ms_per_step',
+                                               'config', 'roofline')}
+        else:
+            result['c4'] = {'skipped': f'{free / 2 ** 30:.0f} GiB of HBM free, the leg needs 190'}
+    if args.eval_users > 0:
+        result['eval'] = eval_leg(device, args.eval_users)
+    if args.hybrid_steps > 0 and args.shape == 'c2':
+        torch.cuda.empty_cache()
+        leg = hybrid_leg(args.hybrid_steps, 3)
+        result['hybrid'] = {k: leg[k] for k in ('metric', 'value', 'unit', 'ms_per_step',
+                                                'config', 'roofline')}
+    print(json.dumps(result))
 
 
 if __name__ == '__main__':
