@@ -277,6 +277,8 @@ def main_sharded(args, world, rank, device):
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = model.train_step(batches[(args.warmup + i) % n_distinct])
+        if args.plan_ahead and i + 1 < args.steps:  # size the next step's exchanges meanwhile
+            model.plan_ahead(batches[(args.warmup + i + 1) % n_distinct])
     dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -407,6 +409,10 @@ def main():
                          'c5 = configs[4], the hybrid MLP head (tools/hybrid_bench.py)')
     ap.add_argument('--sharded-shape', choices=['c2', 'c4'], default='c4',
                     help="tables of the N > 1 run (default: configs[3], north_star's scaling config)")
+    ap.add_argument('--plan-ahead', action='store_true',
+                    help='N > 1: plan step t + 1 on a side stream while step t computes '
+                         '(ShardedMatrixFactorizationModel.plan_ahead; at G = 1 it measured 2-14 %% '
+                         'slower, see DESIGN.md 6)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--eval-users', type=int, default=65536,
                     help='users in the eval leg (0 = skip it)')

@@ -222,10 +222,60 @@ __global__ __launch_bounds__(kBlock) void plan_translate_kernel(
   }
 }
 
+// owner side of the lookup exchange: out_emb[j, :] = emb[rows[j], :], out_bias[j] = bias[rows[j]].
+// One 16-lane group per requested row (16-byte pieces when the rows allow it).
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void serve_rows_kernel(
+    const float* __restrict__ emb, const float* __restrict__ bias, int64_t num_rows, int dim,
+    const int64_t* __restrict__ rows, int64_t m, float* __restrict__ out_emb,
+    float* __restrict__ out_bias, int32_t* __restrict__ status) {
+  constexpr int LPR = 16;
+  const int lig = threadIdx.x % LPR;
+  const int64_t ngroups = static_cast<int64_t>(gridDim.x) * (kBlock / LPR);
+  for (int64_t j = static_cast<int64_t>(blockIdx.x) * (kBlock / LPR) + threadIdx.x / LPR; j < m;
+       j += ngroups) {
+    const int64_t r = rows[j];
+    const bool ok = r >= 0 && r < num_rows;
+    if (!ok && lig == 0 && status) atomicOr(status, 1);
+    const float* src = emb + (ok ? r : 0) * dim;
+    float* dst = out_emb + j * dim;
+    if (VEC == 4) {
+      for (int c = lig; c < dim / 4; c += LPR) {
+        float4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ok) v = reinterpret_cast<const float4*>(src)[c];
+        reinterpret_cast<float4*>(dst)[c] = v;
+      }
+    } else {
+      for (int c = lig; c < dim; c += LPR) dst[c] = ok ? src[c] : 0.0f;
+    }
+    if (lig == 0) out_bias[j] = ok ? bias[r] : 0.0f;
+  }
+}
+
 }  // namespace
 }  // namespace collie
 
 using namespace collie;
+
+extern "C" int collie_shard_serve_rows(const float* emb, const float* bias, int64_t num_rows,
+                                       int32_t dim, const int64_t* rows, int64_t m, float* out_emb,
+                                       float* out_bias, int32_t* status, collie_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  COLLIE_REQUIRE(emb && bias && num_rows >= 1 && dim >= 1, "serve_rows: bad table");
+  COLLIE_REQUIRE(m >= 0, "serve_rows: bad row count");
+  if (m == 0) return 0;
+  COLLIE_REQUIRE(rows && out_emb && out_bias, "serve_rows: NULL pointer");
+  int64_t blocks = (m + kBlock / 16 - 1) / (kBlock / 16);
+  if (blocks > 65536) blocks = 65536;
+  auto al16 = [](const void* q) { return reinterpret_cast<uintptr_t>(q) % 16 == 0; };
+  if (dim % 4 == 0 && al16(emb) && al16(out_emb))
+    hipLaunchKernelGGL(serve_rows_kernel<4>, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0,
+                       stream, emb, bias, num_rows, dim, rows, m, out_emb, out_bias, status);
+  else
+    hipLaunchKernelGGL(serve_rows_kernel<1>, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0,
+                       stream, emb, bias, num_rows, dim, rows, m, out_emb, out_bias, status);
+  return check_launch("serve_rows_kernel");
+}
 
 extern "C" size_t collie_shard_plan_workspace_bytes(int64_t num_users, int64_t num_items,
                                                     int32_t world) {

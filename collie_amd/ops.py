@@ -458,6 +458,21 @@ class ShardPlanner:
         return cu, cp, cn, send_rows, counts
 
 
+def shard_serve_rows(emb, bias, rows, status=None):
+    """Owner side of the lookup exchange: (emb[rows], bias[rows]) (``collie_shard_serve_rows``)."""
+    require_hip(emb, 'table')
+    m = rows.shape[0]
+    out_e = torch.empty(m, emb.shape[1], dtype=torch.float32, device=emb.device)
+    out_b = torch.empty(m, dtype=torch.float32, device=emb.device)
+    if m:
+        rows = rows.contiguous()
+        assert rows.dtype == torch.int64
+        check(load().collie_shard_serve_rows(ptr(emb), ptr(bias), emb.shape[0], emb.shape[1],
+                                             ptr(rows), m, ptr(out_e), ptr(out_b), ptr(status),
+                                             stream_ptr()), 'collie_shard_serve_rows')
+    return out_e, out_b
+
+
 # ---- evaluation -----------------------------------------------------------------------------------
 def eval_topk_capacity():
     return int(load().collie_mf_eval_topk_capacity())

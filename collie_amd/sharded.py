@@ -114,6 +114,10 @@ class HipEngine:
                                              model.comm.world, self.device)
         return self._planner.plan(users, pos_items, neg_items)
 
+    # owner side of the lookup exchange: (emb[rows], bias[rows]) in one launch
+    def serve_rows(self, emb, bias, rows):
+        return ops.shard_serve_rows(emb, bias, rows, self._status)
+
     # compact tables + compact ids -> (loss[1], grad rows [n, D], grad bias [n]), both * scale
     def train_grads(self, cemb, cbias, cu, cp, cn, kind, num_items, codes, weights, scale):
         n, D = cemb.shape
@@ -367,6 +371,8 @@ class ShardedMatrixFactorizationModel:
         self._codes, self._weights = loss_mod.metadata_to_codes(
             metadata_for_loss, metadata_for_loss_weights, dev)
         self.last_exchange = {}
+        self._ahead = None          # (batch tensors, plan, ready event) of plan_ahead()
+        self._plan_stream = None
 
     @staticmethod
     def _new_state(algo, table):
@@ -502,7 +508,9 @@ class ShardedMatrixFactorizationModel:
         meta[:, 2] = B
         meta[:, 3] = counts[2 * G + 1]
         got = comm.all_to_all(meta, [1] * G, [1] * G)
-        meta_h, got_h = torch.stack([meta, got]).cpu().tolist()        # the step's one host sync
+        # The split sizes of the row exchanges must be known to the host: the one read-back of the
+        # step.  With plan_ahead() it happens on a side stream while the previous step computes.
+        meta_h, got_h = torch.stack([meta, got]).cpu().tolist()
         if any(row[3] for row in got_h):
             raise IndexError('index out of range in self: a user or item id is outside the tables')
         send_splits = [r[0] + r[1] for r in meta_h]
@@ -513,6 +521,52 @@ class ShardedMatrixFactorizationModel:
         crow = comm.all_to_all(send_rows[:n], send_splits, recv_splits)
         return dict(n=n, B=B, K=K, B_global=B_global, crow=crow, send_splits=send_splits,
                     recv_splits=recv_splits, cu=cu, cp=cp, cn=cn)
+
+    def plan_ahead(self, batch) -> None:
+        """
+        Optional: plan (steps 1-2) the NEXT ``train_step``'s batch now, on a side stream.  Call it
+        right after ``train_step(t)`` returns with the batch of step t + 1: the planner kernels, the
+        count exchange and the host read-back of the split sizes then overlap step t's kernels, and
+        ``train_step(t + 1)`` enqueues its work without the host ever waiting for the main stream
+        (without it the host waits for step t to drain before it can size step t + 1's exchanges:
+        the GPU idles for the launch latency of a whole step).  Collective: every rank must call it,
+        with its own slice, in the same order as the ``train_step`` calls.  The batch tensors must be
+        complete when this is called (a loader's output, or produced before the last host
+        synchronisation): the side stream does not wait for work still queued on the main stream --
+        waiting for it would serialise the plan behind step t again.
+        """
+        (users, pos_items), neg_items = batch
+        if neg_items.dim() == 1:
+            neg_items = neg_items.reshape(-1, 1)
+        if self.device.type != 'cuda':
+            self._ahead = ((users, pos_items, neg_items), self._plan(users, pos_items, neg_items),
+                           None)
+            return
+        if self._plan_stream is None:
+            self._plan_stream = torch.cuda.Stream(device=self.device)
+        main = torch.cuda.current_stream(self.device)
+        side = self._plan_stream
+        with torch.cuda.stream(side):
+            p = self._plan(users, pos_items, neg_items)
+            ready = torch.cuda.Event()
+            ready.record(side)
+        for t in (p['crow'], p['cu'], p['cp'], p['cn']):
+            t.record_stream(main)       # allocated on the side stream, consumed on the main one
+        self._ahead = ((users, pos_items, neg_items), p, ready)
+
+    def _take_plan(self, users, pos_items, neg_items):
+        ahead, self._ahead = self._ahead, None
+        if ahead is not None:
+            same = all(a.data_ptr() == b.data_ptr() and a.shape == b.shape
+                       for a, b in zip(ahead[0], (users, pos_items, neg_items)))
+            _, plan, ready = ahead
+            if same:
+                if ready is not None:
+                    torch.cuda.current_stream(self.device).wait_event(ready)
+                return plan
+            raise RuntimeError('plan_ahead() was called with a different batch than the next '
+                               'train_step()')
+        return self._plan(users, pos_items, neg_items)
 
     def train_step(self, batch) -> torch.Tensor:
         """
@@ -527,13 +581,17 @@ class ShardedMatrixFactorizationModel:
         D = self.hparams['embedding_dim']
         mark = self._phase_mark
         mark('plan')
-        p = self._plan(users, pos_items, neg_items)
+        p = self._take_plan(users, pos_items, neg_items)
         n, crow = p['n'], p['crow']
         # 3. owners serve the rows
         mark('lookup_exchange')
-        cemb = comm.all_to_all(self.emb.index_select(0, crow), p['recv_splits'], p['send_splits'])
-        cbias = comm.all_to_all(self.bias.index_select(0, crow), p['recv_splits'],
-                                p['send_splits'])
+        serve = getattr(eng, 'serve_rows', None)
+        if serve is not None:
+            served_e, served_b = serve(self.emb, self.bias, crow)
+        else:
+            served_e, served_b = self.emb.index_select(0, crow), self.bias.index_select(0, crow)
+        cemb = comm.all_to_all(served_e, p['recv_splits'], p['send_splits'])
+        cbias = comm.all_to_all(served_b, p['recv_splits'], p['send_splits'])
         # 4. fused forward + segment reduce on the compact tables
         mark('forward_backward')
         codes = []

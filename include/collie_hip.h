@@ -253,6 +253,15 @@ int collie_shard_plan(const collie_mf_batch* b, int64_t num_users, int64_t num_i
                       int64_t* send_rows, int64_t send_capacity, int64_t* route_counts,
                       collie_stream_t stream);
 
+/* Row-sharded training, owner side of the lookup exchange (no counterpart in the reference): the
+ * rows a peer requested out of this rank's combined table -- the nn.Embedding lookups of
+ * matrix_factorization.py:143-150 executed where the rows live: out_emb [m, dim] = emb[rows, :],
+ * out_bias [m] = bias[rows].  rows [m] int64 (rows of the combined table, as collie_shard_plan
+ * numbers them); a row outside [0, num_rows) reads as zeros and sets bit 0 of *status. */
+int collie_shard_serve_rows(const float* emb, const float* bias, int64_t num_rows, int32_t dim,
+                            const int64_t* rows, int64_t m, float* out_emb, float* out_bias,
+                            int32_t* status, collie_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * A13-A17  get_preds + mapk / mrr / auc   collie/metrics.py:77-107,144-282
  *

@@ -63,6 +63,7 @@ def check_training(rank, world, loss, optimizer, bias_optimizer, K, metadata=Non
                        bias_lr=1e-2, sparse=True)
     kind = model._loss_kind
     rng = np.random.default_rng(7)
+    host, slices = [], []
     for step in range(steps):
         users = rng.integers(0, U, B)
         pos = rng.integers(0, N, B)
@@ -70,12 +71,18 @@ def check_training(rank, world, loss, optimizer, bias_optimizer, K, metadata=Non
         if step == 1:
             users[:8] = users[0]                      # duplicates across the two slices
             pos[B // 2:B // 2 + 4] = pos[0]
+        host.append((users, pos, neg))
+        batch = ((dev(users.astype(np.int32)), dev(pos.astype(np.int32))), dev(neg))
+        slices.append(shard_batch(batch, rank, world))
+    for step in range(steps):
+        users, pos, neg = host[step]
         kw = {}
         if metadata is not None:
             kw = dict(metadata={'genre': metadata['genre'].cpu().numpy()}, metadata_weights=weights)
         out = ref.step(users, pos, neg, kind, num_items=N, **kw)
-        batch = ((dev(users.astype(np.int32)), dev(pos.astype(np.int32))), dev(neg))
-        got = model.train_step(shard_batch(batch, rank, world))
+        got = model.train_step(slices[step])
+        if step % 2 == 0 and step + 1 < steps:        # every other step is planned one step ahead
+            model.plan_ahead(slices[step + 1])
         np.testing.assert_allclose(got.item(), out['loss'], rtol=2e-5, atol=1e-7)
     sd = model.state_dict()
     for name, want in ref.t.items():

@@ -26,6 +26,15 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
 print(f'B={B}: {dt * 1e3:.3f} ms/step, {B * 11 / dt / 1e9:.3f} G interactions/s, '
       f'rows/step {m.last_exchange}')
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for i in range(steps):
+    m.train_step(batches[i % 8])
+    if i + 1 < steps:
+        m.plan_ahead(batches[(i + 1) % 8])
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / steps
+print(f'B={B} with plan_ahead: {dt * 1e3:.3f} ms/step, {B * 11 / dt / 1e9:.3f} G interactions/s')
 m.profile_phases(True)
 for i in range(10):
     m.train_step(batches[i % 8])
