@@ -169,7 +169,8 @@ __global__ __launch_bounds__(kBlock) void mf_explicit_fwd_kernel(const ExplicitP
 
 // loss = sum / B  (reduction='mean'); fixed-order reduction of the per-block partials
 __global__ __launch_bounds__(kBlock) void explicit_finalize_kernel(const float* partials, int nblocks,
-                                                                   float inv_b, float* loss_out) {
+                                                                   float inv_b, float* loss_out,
+                                                                   int32_t* status) {
   __shared__ double sh[kWavesPerBlock];
   double a = 0.0;
   for (int i = threadIdx.x; i < nblocks; i += kBlock) a += partials[i];
@@ -179,7 +180,9 @@ __global__ __launch_bounds__(kBlock) void explicit_finalize_kernel(const float* 
   if (threadIdx.x == 0) {
     double t = 0.0;
     for (int w = 0; w < kWavesPerBlock; ++w) t += sh[w];
-    *loss_out = static_cast<float>(t * static_cast<double>(inv_b));
+    const float loss = static_cast<float>(t * static_cast<double>(inv_b));
+    *loss_out = loss;
+    if (status && !isfinite(loss)) atomicOr(status, 2);  // detect_anomaly's flag (trainer.py:333)
   }
 }
 
@@ -250,6 +253,6 @@ extern "C" int collie_mf_explicit_forward(const collie_mf_tables* t, const void*
   else launch_explicit<1>(lpr, grid, stream, p);
   if (check_launch("mf_explicit_fwd_kernel")) return -2;
   hipLaunchKernelGGL(explicit_finalize_kernel, dim3(1), dim3(kBlock), 0, stream, ws.loss_partials,
-                     static_cast<int>(nblocks), p.inv_b, loss_out);
+                     static_cast<int>(nblocks), p.inv_b, loss_out, status);
   return check_launch("explicit_finalize_kernel");
 }

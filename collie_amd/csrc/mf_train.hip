@@ -931,7 +931,8 @@ __global__ __launch_bounds__(kBlock, (CH * NP <= 4 ? 8 : 4)) void mf_train_fwd_l
 
 // loss = (sum l + sum l^2) / B   (bpr.py:89, hinge.py:85, warp.py:133); fixed-order reduction
 __global__ __launch_bounds__(kBlock) void loss_finalize_kernel(const float* partials, int nblocks,
-                                                               float inv_b, float* loss_out) {
+                                                               float inv_b, float* loss_out,
+                                                               int32_t* status) {
   __shared__ double sh[2][kWavesPerBlock];
   double a = 0.0, c = 0.0;
   for (int i = threadIdx.x; i < nblocks; i += kBlock) {
@@ -953,7 +954,12 @@ __global__ __launch_bounds__(kBlock) void loss_finalize_kernel(const float* part
       ta += sh[0][w];
       tc += sh[1][w];
     }
-    *loss_out = static_cast<float>((ta + tc) * static_cast<double>(inv_b));
+    const float loss = static_cast<float>((ta + tc) * static_cast<double>(inv_b));
+    *loss_out = loss;
+    // a non-finite loss term makes the sum non-finite: the flag detect_anomaly polls
+    // (trainer.py:333 wraps the fit in torch.autograd.set_detect_anomaly; the fused step has no
+    // autograd graph, so the kernel reports it)
+    if (status && !isfinite(loss)) atomicOr(status, 2);
   }
 }
 
@@ -1202,6 +1208,6 @@ extern "C" int collie_mf_train_forward(const collie_mf_tables* t, const collie_m
   else rc = launch_fwd<1>(lpr, grid, stream, p);
   if (rc) return rc;
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(kBlock), 0, stream, ws.loss_partials,
-                     static_cast<int>(nblocks), p.inv_b, loss_out);
+                     static_cast<int>(nblocks), p.inv_b, loss_out, status);
   return check_launch("loss_finalize_kernel");
 }

@@ -354,59 +354,60 @@ class MatrixFactorizationModel(nn.Module):
             raise ValueError('{} is not a valid loss function.'.format(self.loss))
         self.loss_function = loss_mod.LOSS_FUNCTIONS[self._loss_kind]
 
-    def configure_optimizers(self):
-        """``base_pipeline.py:342-404``: same return shapes; string optimizers become fused ones."""
-        if self.bias_optimizer is not None:
-            if self.bias_optimizer == 'infer':
-                self.bias_optimizer = self.optimizer
-            if self.hparams.bias_lr == 'infer':
-                self.hparams.bias_lr = self.hparams.lr
-            bias_optimizer = self._get_optimizer(self.bias_optimizer, optimizer_type='bias')
-            optimizer = self._get_optimizer(self.optimizer, optimizer_type='all_but_bias')
-        else:
-            optimizer = self._get_optimizer(self.optimizer, optimizer_type='all')
+    # Which parameters an optimizer role owns: the substring 'bias' in the parameter NAME decides
+    # (``base_pipeline.py:450-467``), and which learning-rate hyper-parameter it reads.
+    _ROLES = {'bias': (lambda name: 'bias' in name, 'bias_lr'),
+              'all_but_bias': (lambda name: 'bias' not in name, 'lr'),
+              'all': (lambda name: True, 'lr')}
 
-        if self.lr_scheduler_func is not None:
-            monitor = 'val_loss_epoch' if self.val_loader is not None else 'train_loss_epoch'
-            optimizer_list = [optimizer]
-            scheduler_list = [{'scheduler': self.lr_scheduler_func(optimizer), 'monitor': monitor}]
-            if self.bias_optimizer is not None:
-                optimizer_list.append(bias_optimizer)
-                scheduler_list.append({'scheduler': self.lr_scheduler_func(bias_optimizer),
-                                       'monitor': monitor})
-            return (optimizer_list, scheduler_list)
-        if self.bias_optimizer is not None:
-            return [optimizer, bias_optimizer]
-        return optimizer
+    def configure_optimizers(self):
+        """Contract of ``base_pipeline.py:342-404``: one optimizer over every parameter, or -- when
+        a ``bias_optimizer`` is configured -- a main optimizer over the non-bias parameters followed
+        by a bias optimizer (``'infer'`` copies the main optimizer / learning rate).  Returns the
+        optimizer, the list of both, or ``(optimizers, scheduler dicts)`` when an
+        ``lr_scheduler_func`` is set; string optimizers become the fused HIP ones."""
+        if self.bias_optimizer == 'infer':
+            self.bias_optimizer = self.optimizer
+        if self.bias_optimizer is not None and self.hparams.bias_lr == 'infer':
+            self.hparams.bias_lr = self.hparams.lr
+        plan = ([(self.optimizer, 'all')] if self.bias_optimizer is None else
+                [(self.optimizer, 'all_but_bias'), (self.bias_optimizer, 'bias')])
+        optimizers = [self._get_optimizer(spec, optimizer_type=role) for spec, role in plan]
+        if self.lr_scheduler_func is None:
+            return optimizers if len(optimizers) > 1 else optimizers[0]
+        monitor = 'train_loss_epoch' if self.val_loader is None else 'val_loss_epoch'
+        return (optimizers, [{'scheduler': self.lr_scheduler_func(opt), 'monitor': monitor}
+                             for opt in optimizers])
 
     def _get_optimizer(self, optimizer, **kwargs):
-        """``base_pipeline.py:406-437``."""
+        """One optimizer from a name (``'sgd' | 'adagrad' | 'adam' | 'sparse_adam'``, built as the
+        fused subclass of that torch optimizer and attached to this model) or from any callable
+        ``torch.optim`` class (``base_pipeline.py:406-437``; a class that rejects ``weight_decay``
+        is retried without it; ``sparse_adam`` never receives it)."""
         if callable(optimizer):
-            try:
-                return optimizer(self._get_optimizer_parameters(include_weight_decay=True, **kwargs))
-            except TypeError:
-                return optimizer(self._get_optimizer_parameters(include_weight_decay=False, **kwargs))
-        if optimizer not in FUSED_OPTIMIZERS:
+            for with_decay in (True, False):
+                try:
+                    return optimizer(self._get_optimizer_parameters(
+                        include_weight_decay=with_decay, **kwargs))
+                except TypeError:
+                    if not with_decay:
+                        raise
+        fused = FUSED_OPTIMIZERS.get(optimizer) if isinstance(optimizer, str) else None
+        if fused is None:
             raise ValueError('{} is not a valid optimizer!'.format(optimizer))
-        params = self._get_optimizer_parameters(
-            include_weight_decay=(optimizer != 'sparse_adam'), **kwargs)
-        return FUSED_OPTIMIZERS[optimizer](params).attach(self)
+        groups = self._get_optimizer_parameters(
+            include_weight_decay=optimizer != 'sparse_adam', **kwargs)
+        return fused(groups).attach(self)
 
     def _get_optimizer_parameters(self, include_weight_decay=True, optimizer_type='all', **kwargs):
-        """``base_pipeline.py:439-479``: the substring 'bias' in the parameter NAME routes it."""
+        """The single parameter group of one optimizer role (``base_pipeline.py:439-479``)."""
         assert optimizer_type in ['bias', 'all_but_bias', 'all'], f'{optimizer_type} not valid!'
-        if optimizer_type == 'bias':
-            groups = [{'params': [p for n, p in self.named_parameters() if 'bias' in n],
-                       'lr': self.hparams.bias_lr}]
-        elif optimizer_type == 'all_but_bias':
-            groups = [{'params': [p for n, p in self.named_parameters() if 'bias' not in n],
-                       'lr': self.hparams.lr}]
-        else:
-            groups = [{'params': list(self.parameters()), 'lr': self.hparams.lr}]
+        owns, lr_key = self._ROLES[optimizer_type]
+        group = {'params': [p for name, p in self.named_parameters() if owns(name)],
+                 'lr': self.hparams[lr_key]}
         if include_weight_decay:
-            for g in groups:
-                g['weight_decay'] = self.hparams.weight_decay
-        return groups
+            group['weight_decay'] = self.hparams.weight_decay
+        return [group]
 
     # ------------------------------------------------------------------------------- arithmetic
     def _weights(self):
@@ -439,9 +440,20 @@ class MatrixFactorizationModel(nn.Module):
 
     def check_status(self):
         """Raise ``IndexError`` if any kernel saw an out-of-range id since the last check (syncs)."""
-        if self._status is not None and int(self._status.item()) != 0:
+        if self._status is not None and int(self._status.item()) & 1:
             self._status.zero_()
             raise IndexError('index out of range in self: a user or item id is outside the tables')
+
+    def check_anomaly(self):
+        """``detect_anomaly`` on the fused route (``trainer.py:333``): raise ``RuntimeError`` if a
+        fused loss kernel produced a non-finite loss since the last check (syncs; the trainers call
+        it once per step only when ``detect_anomaly`` is set).  The autograd route is covered by
+        ``torch.autograd.set_detect_anomaly`` itself."""
+        if self._status is not None and int(self._status.item()) & 2:
+            self._status.bitwise_and_(1)
+            self._drop_staged_step()        # the staged gradients are poisoned: never apply them
+            raise RuntimeError("Function 'CollieFusedLossBackward' returned nan values in its 0th "
+                               'output.')
 
     def _retire_workspace(self):
         """Drop the training workspace but keep its step counter: the optimizers' ``_row_stamp``

@@ -18,7 +18,9 @@
  *   - tables are row-major contiguous fp32: embeddings [rows, dim], biases [rows] ([rows,1]);
  *   - index arrays are int32 or int64, selected by a `COLLIE_I32/I64` tag;
  *   - out-of-range ids never fault: the sample is skipped and bit 0 of `*status` (device int32,
- *     may be NULL) is set.
+ *     may be NULL) is set; the fused loss entry points (collie_mf_train_forward,
+ *     collie_mf_explicit_forward) also set bit 1 when the loss they wrote is not finite (what
+ *     trainer.py:333's detect_anomaly looks for on the autograd route).
  */
 #ifndef COLLIE_HIP_H
 #define COLLIE_HIP_H
