@@ -17,8 +17,8 @@ What is the real reference here, and what is not (be precise):
     unmodified, base_pipeline.py:418-433).
   * Metric vectors are the reference's own known answers (tests/test_metrics.py,
     tests/fixtures/metrics_fixtures.py) re-expressed as JSON, plus sklearn ``roc_auc_score``
-    values (the reference's own AUC oracle).  The larger eval case's per-user AP / RR are
-    produced by ``oracle/mf_oracle.py`` and are therefore labelled "restatement" in the file.
+    values (the reference's own AUC oracle).  The larger eval case's per-user AP / RR / AUC come
+    from the reference's own ``collie/metrics.py`` (``make_golden_ref_pipeline.py``).
 """
 import json
 import os
@@ -365,15 +365,13 @@ def eval_case():
     preds = preds.numpy()
     coo = sp.coo_matrix((np.ones(len(rows)), (rows, cols)), shape=(U, N))
     csr = coo.tocsr()
-    ap, ids = mf_oracle.mapk_per_user(csr, np.array(test_users), preds, 10)
-    rr = mf_oracle.mrr_per_user(csr, np.array(test_users), preds)
-    au = mf_oracle.auc_per_user(csr, np.array(test_users), preds)
     sig = torch.sigmoid(torch.tensor(preds)).numpy()
     au_sk = np.array([roc_auc_score(csr[u].toarray()[0], sig[i]) for i, u in enumerate(test_users)])
     out = {f't|{k}': v for k, v in tables.items()}
     out.update(rows=np.array(rows), cols=np.array(cols), test_users=np.array(test_users),
-               preds_torch=preds, top10_ids_restatement=ids, ap_restatement=ap,
-               rr_restatement=rr, auc_restatement=au, auc_sklearn_on_torch_sigmoid=au_sk)
+               preds_torch=preds, auc_sklearn_on_torch_sigmoid=au_sk)
+    # per-user AP / RR / AUC and top-k ids of this case come from the reference's own
+    # collie/metrics.py: tests/golden/make_golden_ref_pipeline.py -> ref_pipeline.npz
     np.savez_compressed(os.path.join(HERE, 'eval_case.npz'), **out)
 
 

@@ -94,29 +94,47 @@ def test_eval_case_with_engineered_ties(golden_dir, dev):
     slots = torch.tensor(users, dtype=torch.int64, device=dev)
     ws = ops.EvalWorkspace(dev)
     scores, ids = ops.eval_topk(t, slots, 0, N, 10, None, ws)
-    # ids: exact against the stable (score desc, id asc) order of the torch-computed scores,
-    # wherever those scores are not within rounding of each other
-    ref_ids = z['top10_ids_restatement']
-    ref_scores = np.take_along_axis(z['preds_torch'], ref_ids, axis=1)
+    # ids: exact against torch's own ``preds.topk(10)`` of the REFERENCE'S ``get_preds``
+    # (ref_pipeline.npz, from collie/metrics.py run in the build container) wherever the leading
+    # scores hold neither an exact tie (torch's tie order is implementation-defined) nor a
+    # near-tie inside the rounding difference of the two summation orders
+    r = np.load(os.path.join(golden_dir, 'ref_pipeline.npz'))
+    np.testing.assert_array_equal(r['eval|users'], users)
+    ref_preds = r['eval|preds_reference']
+    ref_ids = r['eval|top10_ids_reference']
     got = ids.cpu().numpy()
+    checked = 0
     for i in range(len(users)):
-        full = np.sort(z['preds_torch'][i])[::-1]
-        gaps_ok = np.all((np.abs(np.diff(full[:12])) > 1e-6) | (np.diff(full[:12]) == 0))
-        if gaps_ok:
+        lead = np.sort(ref_preds[i])[::-1][:12]
+        if np.all(-np.diff(lead) > 1e-6):
             np.testing.assert_array_equal(got[i], ref_ids[i])
-    np.testing.assert_allclose(scores.cpu().numpy(), ref_scores, rtol=1e-5, atol=1e-6)
+            checked += 1
+    assert checked >= 3
+    stable = O.topk_ids(ref_preds, 10)
+    np.testing.assert_allclose(scores.cpu().numpy(), np.take_along_axis(ref_preds, stable, axis=1),
+                               rtol=1e-5, atol=1e-6)
     # tie groups come out in ascending id order
     s = scores.cpu().numpy()
     for i in range(len(users)):
         same = np.nonzero(np.diff(s[i]) == 0)[0]
         assert np.all(got[i][same] < got[i][same + 1])
-    # per-user metrics
+    # per-user metrics against the reference's own mapk / mrr / auc, one user at a time
     from collie_amd.metrics import _csr_slice, _per_user
+    from tests.test_oracle_golden import rr_tie_interval
     indptr, indices = _csr_slice(csr, users, dev)
     ap, rr, au = _per_user(t, slots, indptr, indices, N, 10, None, (True, True, True), ws)
-    np.testing.assert_allclose(ap.cpu().numpy(), z['ap_restatement'], rtol=1e-5)
-    np.testing.assert_allclose(rr.cpu().numpy(), z['rr_restatement'], rtol=1e-5)
+    np.testing.assert_allclose(ap.cpu().numpy(), r['eval|ap_reference'], rtol=1e-5)
+    np.testing.assert_allclose(au.cpu().numpy(), r['eval|auc_reference'], rtol=1e-5)
     np.testing.assert_allclose(au.cpu().numpy(), z['auc_sklearn_on_torch_sigmoid'], rtol=1e-5)
+    rr = rr.cpu().numpy()
+    for i, u in enumerate(users):
+        lo, hi = rr_tie_interval(ref_preds[i], csr[u].indices)
+        if lo == hi:
+            np.testing.assert_allclose(rr[i], r['eval|rr_reference'][i], rtol=1e-5)
+        else:   # an exact tie with the best positive: the build ranks tied items by ascending id
+            assert lo - 1e-9 <= rr[i] <= hi + 1e-9
+            np.testing.assert_allclose(rr[i], O.mrr_per_user(csr, users[i:i + 1],
+                                                             ref_preds[i:i + 1])[0], rtol=1e-6)
 
 
 @pytest.mark.parametrize('D,N,U,k', [(64, 5003, 300, 10), (10, 1682, 943, 10), (128, 2048, 70, 16),

@@ -201,7 +201,13 @@ def test_optimizer_trajectories_vs_torch(golden_dir, dev):
                 f.update(is_bias, not sparse, per_side)
             for n in NAMES:
                 if n == 'user_biases':
-                    assert float(td[n].abs().max()) == 0.0   # exact zero gradient, see above
+                    # d loss / d user_bias is analytically 0: exactly 0 here; torch holds fp32
+                    # cancellation residue, which SGD scales by lr and Adam / Adagrad normalise
+                    # into steps of up to lr each -- assert that bound on the reference values
+                    assert float(td[n].abs().max()) == 0.0
+                    balgo, brate = (bopt, blr) if bopt is not None else (opt, lr)
+                    bound = 1e-6 if balgo == 'sgd' else (s + 1) * brate * 1.01
+                    assert np.abs(z[f'{tag}|s{s}|t|{n}']).max() <= bound + wd * (s + 1) * brate
                     continue
                 try:
                     close(td[n].cpu().numpy(), z[f'{tag}|s{s}|t|{n}'], rtol=2e-5)

@@ -213,6 +213,93 @@ def test_eval_case(golden_dir):
         assert np.all(ids[i][same] < ids[i][same + 1])
 
 
+def rr_tie_interval(preds_row, positives):
+    """[lowest, highest] reciprocal rank a user can get when items tie exactly with the best
+    positive: ``Tensor.topk``'s order inside a tie group is implementation-defined (SURVEY.md
+    Appendix B), the build's rule is ascending id."""
+    best = preds_row[positives].max()
+    above = int((preds_row > best).sum())
+    tied = np.nonzero(preds_row == best)[0]
+    tied_other = len(set(tied.tolist()) - set(positives.tolist()))
+    return 1.0 / (above + 1 + tied_other), 1.0 / (above + 1)
+
+
+def test_oracle_metrics_vs_reference_metrics_per_user(golden_dir):
+    """Per-user AP@10 / RR / AUC of the eval case from the REFERENCE'S OWN ``collie/metrics.py``
+    (``tests/golden/make_golden_ref_pipeline.py``: ``mapk`` / ``mrr`` / ``auc`` called one user at a
+    time on ``get_preds`` of the reference's ``MatrixFactorizationModel``) pin the oracle."""
+    z = np.load(os.path.join(golden_dir, 'eval_case.npz'))
+    r = np.load(os.path.join(golden_dir, 'ref_pipeline.npz'))
+    names = ('user_embeddings', 'item_embeddings', 'user_biases', 'item_biases')
+    tables = {n: z[f't|{n}'] for n in names}
+    N = tables['item_embeddings'].shape[0]
+    users = r['eval|users']
+    np.testing.assert_array_equal(users, z['test_users'])
+    csr = sp.coo_matrix((np.ones(len(z['rows'])), (z['rows'], z['cols'])), shape=(9, N)).tocsr()
+    preds = r['eval|preds_reference']
+    close(O.get_preds(tables, users, N), preds)
+    ap, ids = O.mapk_per_user(csr, users, preds, 10)
+    np.testing.assert_allclose(ap, r['eval|ap_reference'], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(O.auc_per_user(csr, users, preds), r['eval|auc_reference'], rtol=1e-6)
+    rr = O.mrr_per_user(csr, users, preds)
+    n_tie_users = 0
+    for i, u in enumerate(users):
+        lo, hi = rr_tie_interval(preds[i], csr[u].indices)
+        assert lo - 1e-9 <= r['eval|rr_reference'][i] <= hi + 1e-9
+        assert lo - 1e-9 <= rr[i] <= hi + 1e-9
+        if lo == hi:
+            np.testing.assert_allclose(rr[i], r['eval|rr_reference'][i], rtol=1e-6)
+        else:
+            n_tie_users += 1
+        # top-k ids equal torch's wherever the first 11 scores hold no exact tie
+        top = np.sort(preds[i])[::-1][:11]
+        if np.all(np.diff(top) < 0):
+            np.testing.assert_array_equal(ids[i], r['eval|top10_ids_reference'][i])
+    assert n_tie_users >= 1          # the engineered tie case is in the fixture
+
+
+def reference_trainer_case(golden_dir, tag):
+    r = np.load(os.path.join(golden_dir, 'ref_pipeline.npz'))
+    names = ('user_embeddings', 'item_embeddings', 'user_biases', 'item_biases')
+    t0 = {n: r[f'{tag}|t0|{n}'].copy() for n in names}
+    t1 = {n: r[f'{tag}|t1|{n}'] for n in names}
+    nb = int(r[f'{tag}|n_batches'])
+    batches = [(r[f'{tag}|b{i}|users'], r[f'{tag}|b{i}|pos'], r[f'{tag}|b{i}|neg']) for i in range(nb)]
+    return t0, t1, batches, r[f'{tag}|step_losses'], r[f'{tag}|epoch_losses']
+
+
+REF_TRAINER_CASES = {
+    'sparse_adam_bpr': dict(optimizer='sparse_adam', bias_optimizer='sgd', lr=1e-2, bias_lr=1e-2,
+                            sparse=True, kind='adaptive_bpr'),
+    'default_adam_hinge': dict(optimizer='adam', bias_optimizer='sgd', lr=1e-2, bias_lr=1e-2,
+                               sparse=False, kind='adaptive_hinge'),
+}
+
+
+@pytest.mark.parametrize('tag', sorted(REF_TRAINER_CASES))
+def test_oracle_steps_vs_reference_trainer_epochs(golden_dir, tag):
+    """F6: two epochs of the REFERENCE'S OWN ``CollieMinimalTrainer`` +
+    ``MatrixFactorizationModel`` on fixed batches: per-step losses, epoch losses and final tables
+    pin the oracle's whole training step (forward, loss, sparse / dense gradients, optimizers)."""
+    cfg = dict(REF_TRAINER_CASES[tag])
+    kind = cfg.pop('kind')
+    t0, t1, batches, step_losses, epoch_losses = reference_trainer_case(golden_dir, tag)
+    st = O.TrainState(t0, **cfg)
+    got = []
+    for epoch in range(2):
+        for users, pos, neg in batches:
+            got.append(st.step(users, pos, neg, kind)['loss'])
+    np.testing.assert_allclose(got, step_losses, rtol=2e-5)
+    nb = len(batches)
+    np.testing.assert_allclose([np.mean(got[:nb]), np.mean(got[nb:])], epoch_losses, rtol=2e-5)
+    for n in t1:
+        if n == 'user_biases':
+            # analytically zero gradient: the reference holds fp32 cancellation residue times lr
+            assert np.abs(t1[n]).max() <= 1e-6 and np.abs(st.t[n]).max() <= 1e-6
+        else:
+            close(st.t[n], t1[n], rtol=2e-4)
+
+
 def test_hybrid_numpy_oracle_matches_torch_restatement():
     """oracle/hybrid_oracle.py (numpy) against oracle/torch_path.py:TorchHybrid (the reference's
     torch calls, hybrid_pretrained_matrix_factorization.py:327-464) run by torch here: scores and
