@@ -76,6 +76,15 @@ SIGNATURES = {
                                                 c_int32, c_int64, c_int32, c_float, c_float,
                                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                 c_void_p]),
+    'collie_mf_score_dropout': (ctypes.c_int, [POINTER(Tables), c_void_p, c_int32, c_void_p, c_int32,
+                                               c_int64, c_int32, c_float, c_float, c_float,
+                                               ctypes.c_uint64, ctypes.c_uint64, c_void_p, c_void_p,
+                                               c_void_p]),
+    'collie_mf_score_dropout_backward': (ctypes.c_int, [POINTER(Tables), c_void_p, c_int32, c_void_p,
+                                                        c_int32, c_int64, c_int32, c_float, c_float,
+                                                        c_float, ctypes.c_uint64, ctypes.c_uint64,
+                                                        c_void_p, c_void_p, c_void_p, c_void_p,
+                                                        c_void_p, c_void_p]),
     'collie_loss_forward_backward': (ctypes.c_int, [POINTER(LossCfg), c_void_p, c_void_p, c_int64,
                                                     c_int32, c_void_p, c_void_p, c_void_p,
                                                     c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -76,6 +76,30 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Philox4x32-10 (Salmon et al., SC'11): the counter-based generator of the device sampler and of
+// the dropout masks; known-answer vectors are checked through oracle/sampler_oracle.py.
+struct Philox {
+  uint32_t c[4];
+};
+
+__device__ __forceinline__ Philox philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = static_cast<uint64_t>(0xD2511F53u) * c0;
+    const uint64_t p1 = static_cast<uint64_t>(0xCD9E8D57u) * c2;
+    const uint32_t n0 = static_cast<uint32_t>(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n2 = static_cast<uint32_t>(p0 >> 32) ^ c3 ^ k1;
+    c1 = static_cast<uint32_t>(p1);
+    c3 = static_cast<uint32_t>(p0);
+    c0 = n0;
+    c2 = n2;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return Philox{{c0, c1, c2, c3}};
+}
+
 // torch.sigmoid in fp32: 1 / (1 + exp(-x))
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 

@@ -40,10 +40,29 @@ struct ScoreParams {
   float* gbias;
   int32_t* status;
   int nchunks;
+  // nn.Dropout on both gathered rows (matrix_factorization.py:143-147), training mode only
+  uint64_t drop_thr;   // an element is kept iff its 32 random bits >= drop_thr (= p * 2^32); 0 = off
+  float keep_scale;    // 1 / (1 - p)
+  uint64_t drop_seed, drop_call;
 };
 
+// Multipliers nn.Dropout applies to element d of the user row / item row of pair q in forward
+// call `drop_call`: 0 or 1 / (1 - p), independent for the two rows (two of the four words of one
+// Philox4x32-10 block: counter = (q, d, call low word), key = seed ^ call high word).
+__device__ __forceinline__ void drop_mult(const ScoreParams& p, int64_t q, int d, float& mu,
+                                          float& mi) {
+  const Philox r = philox4x32_10(static_cast<uint32_t>(q), static_cast<uint32_t>(q >> 32),
+                                 static_cast<uint32_t>(d), static_cast<uint32_t>(p.drop_call),
+                                 static_cast<uint32_t>(p.drop_seed),
+                                 static_cast<uint32_t>(p.drop_seed >> 32) ^
+                                     static_cast<uint32_t>(p.drop_call >> 32));
+  mu = static_cast<uint64_t>(r.c[0]) >= p.drop_thr ? p.keep_scale : 0.0f;
+  mi = static_cast<uint64_t>(r.c[1]) >= p.drop_thr ? p.keep_scale : 0.0f;
+}
+
 // BWD = false: scores.  BWD = true: values of the uncoalesced sparse gradients.
-template <int VEC, int LPR, bool BWD>
+// DROP: rows pass through nn.Dropout before the product (and its backward after it).
+template <int VEC, int LPR, bool BWD, bool DROP = false>
 __global__ __launch_bounds__(kBlock) void mf_score_kernel(const ScoreParams p) {
   constexpr int GPW = kWave / LPR;  // pairs per wave
   const int lane = lane_id();
@@ -69,7 +88,17 @@ __global__ __launch_bounds__(kBlock) void mf_score_kernel(const ScoreParams p) {
     const float* urow = p.t.user_emb + u * D;
     const float* irow = p.t.item_emb + it * D;
     float part = 0.0f;
-    if (valid && (!BWD || p.has_y)) part = row_dot<VEC>(urow, irow, lig, LPR, p.nchunks);
+    if (valid && (!BWD || p.has_y)) {
+      if (!DROP) {
+        part = row_dot<VEC>(urow, irow, lig, LPR, p.nchunks);
+      } else {
+        for (int d = lig; d < D; d += LPR) {
+          float mu, mi;
+          drop_mult(p, q, d, mu, mi);
+          part = fmaf(urow[d] * mu, irow[d] * mi, part);
+        }
+      }
+    }
     part = group_sum<LPR>(part);
     float s = (part + p.t.user_bias[u]) + p.t.item_bias[it];
     if (!BWD) {
@@ -84,7 +113,16 @@ __global__ __launch_bounds__(kBlock) void mf_score_kernel(const ScoreParams p) {
       if (bad) g = 0.0f;
       if (valid) {
         if (lig == 0) p.gbias[q] = g;
-        for (int c = lig; c < p.nchunks; c += LPR) {
+        if (DROP) {
+          // d/d(row) of dropout(row): the dropped partner's value times this row's own multiplier
+          for (int d = lig; d < D; d += LPR) {
+            float mu, mi;
+            drop_mult(p, q, d, mu, mi);
+            p.gu_rows[q * D + d] = (g * (irow[d] * mi)) * mu;
+            p.gi_rows[q * D + d] = (g * (urow[d] * mu)) * mi;
+          }
+        }
+        for (int c = lig; !DROP && c < p.nchunks; c += LPR) {
 #pragma unroll
           for (int i = 0; i < VEC; ++i) {
             const int d = c * VEC + i;
@@ -95,6 +133,20 @@ __global__ __launch_bounds__(kBlock) void mf_score_kernel(const ScoreParams p) {
       }
     }
   }
+}
+
+template <bool BWD>
+int launch_score_drop(int lpr, dim3 grid, hipStream_t stream, const ScoreParams& p) {
+  switch (lpr) {
+    case 1: hipLaunchKernelGGL((mf_score_kernel<1, 1, BWD, true>), grid, dim3(kBlock), 0, stream, p); break;
+    case 2: hipLaunchKernelGGL((mf_score_kernel<1, 2, BWD, true>), grid, dim3(kBlock), 0, stream, p); break;
+    case 4: hipLaunchKernelGGL((mf_score_kernel<1, 4, BWD, true>), grid, dim3(kBlock), 0, stream, p); break;
+    case 8: hipLaunchKernelGGL((mf_score_kernel<1, 8, BWD, true>), grid, dim3(kBlock), 0, stream, p); break;
+    case 16: hipLaunchKernelGGL((mf_score_kernel<1, 16, BWD, true>), grid, dim3(kBlock), 0, stream, p); break;
+    case 32: hipLaunchKernelGGL((mf_score_kernel<1, 32, BWD, true>), grid, dim3(kBlock), 0, stream, p); break;
+    default: hipLaunchKernelGGL((mf_score_kernel<1, 64, BWD, true>), grid, dim3(kBlock), 0, stream, p); break;
+  }
+  return check_launch("mf_score_kernel<dropout>");
 }
 
 template <int VEC, bool BWD>
@@ -113,7 +165,7 @@ int launch_score(int lpr, dim3 grid, hipStream_t stream, const ScoreParams& p) {
 
 template <bool BWD>
 int run_score(ScoreParams& p, hipStream_t stream) {
-  const int vec = pick_vec(&p.t);
+  const int vec = p.drop_thr ? 1 : pick_vec(&p.t);   // the dropout route works element-wise
   p.nchunks = (p.t.dim + vec - 1) / vec;
   int lpr = 1;
   while (lpr < p.nchunks && lpr < kWave) lpr *= 2;
@@ -121,6 +173,7 @@ int run_score(ScoreParams& p, hipStream_t stream) {
   int64_t blocks = (p.m + pairs_per_block - 1) / pairs_per_block;
   if (blocks > 8192) blocks = 8192;
   dim3 grid(static_cast<unsigned>(blocks));
+  if (p.drop_thr) return launch_score_drop<BWD>(lpr, grid, stream, p);
   if (vec == 4) return launch_score<4, BWD>(lpr, grid, stream, p);
   if (vec == 2) return launch_score<2, BWD>(lpr, grid, stream, p);
   return launch_score<1, BWD>(lpr, grid, stream, p);
@@ -328,6 +381,75 @@ extern "C" int collie_mf_score_backward(const collie_mf_tables* t, const void* u
   p.gi_rows = grad_item_rows;
   p.gbias = grad_bias;
   p.status = status;
+  return run_score<true>(p, static_cast<hipStream_t>(stream));
+}
+
+namespace {
+int set_dropout(ScoreParams& p, float drop_p, uint64_t seed, uint64_t call) {
+  COLLIE_REQUIRE(drop_p > 0.0f && drop_p <= 1.0f, "dropout: p must be in (0, 1] (got %g)", drop_p);
+  p.drop_thr = static_cast<uint64_t>(static_cast<double>(drop_p) * 4294967296.0);
+  if (p.drop_thr == 0) p.drop_thr = 1;
+  p.keep_scale = drop_p < 1.0f ? 1.0f / (1.0f - drop_p) : 0.0f;
+  p.drop_seed = seed;
+  p.drop_call = call;
+  return 0;
+}
+}  // namespace
+
+extern "C" int collie_mf_score_dropout(const collie_mf_tables* t, const void* users,
+                                       int32_t users_dtype, const void* items,
+                                       int32_t items_dtype, int64_t m, int32_t has_y_range,
+                                       float y_lo, float y_hi, float dropout_p, uint64_t seed,
+                                       uint64_t call, float* scores, int32_t* status,
+                                       collie_stream_t stream) {
+  if (validate_tables(t)) return -1;
+  COLLIE_REQUIRE(m >= 0, "negative pair count");
+  if (m == 0) return 0;
+  COLLIE_REQUIRE(users && items && scores, "mf_score_dropout: NULL pointer");
+  ScoreParams p;
+  memset(&p, 0, sizeof(p));
+  p.t = *t;
+  p.users = users;
+  p.items = items;
+  p.udt = users_dtype;
+  p.idt = items_dtype;
+  p.m = m;
+  p.has_y = has_y_range;
+  p.y_lo = y_lo;
+  p.y_hi = y_hi;
+  p.out = scores;
+  p.status = status;
+  if (set_dropout(p, dropout_p, seed, call)) return -1;
+  return run_score<false>(p, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int collie_mf_score_dropout_backward(
+    const collie_mf_tables* t, const void* users, int32_t users_dtype, const void* items,
+    int32_t items_dtype, int64_t m, int32_t has_y_range, float y_lo, float y_hi, float dropout_p,
+    uint64_t seed, uint64_t call, const float* grad_out, float* grad_user_rows,
+    float* grad_item_rows, float* grad_bias, int32_t* status, collie_stream_t stream) {
+  if (validate_tables(t)) return -1;
+  COLLIE_REQUIRE(m >= 0, "negative pair count");
+  if (m == 0) return 0;
+  COLLIE_REQUIRE(users && items && grad_out && grad_user_rows && grad_item_rows && grad_bias,
+                 "mf_score_dropout_backward: NULL pointer");
+  ScoreParams p;
+  memset(&p, 0, sizeof(p));
+  p.t = *t;
+  p.users = users;
+  p.items = items;
+  p.udt = users_dtype;
+  p.idt = items_dtype;
+  p.m = m;
+  p.has_y = has_y_range;
+  p.y_lo = y_lo;
+  p.y_hi = y_hi;
+  p.grad_out = grad_out;
+  p.gu_rows = grad_user_rows;
+  p.gi_rows = grad_item_rows;
+  p.gbias = grad_bias;
+  p.status = status;
+  if (set_dropout(p, dropout_p, seed, call)) return -1;
   return run_score<true>(p, static_cast<hipStream_t>(stream));
 }
 

@@ -14,28 +14,6 @@ namespace {
 
 constexpr int kBlock = 256;
 
-struct Philox {
-  uint32_t c[4];
-};
-
-__device__ __forceinline__ Philox philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                                uint32_t k0, uint32_t k1) {
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const uint64_t p0 = static_cast<uint64_t>(0xD2511F53u) * c0;
-    const uint64_t p1 = static_cast<uint64_t>(0xCD9E8D57u) * c2;
-    const uint32_t n0 = static_cast<uint32_t>(p1 >> 32) ^ c1 ^ k0;
-    const uint32_t n2 = static_cast<uint32_t>(p0 >> 32) ^ c3 ^ k1;
-    c1 = static_cast<uint32_t>(p1);
-    c3 = static_cast<uint32_t>(p0);
-    c0 = n0;
-    c2 = n2;
-    k0 += 0x9E3779B9u;
-    k1 += 0xBB67AE85u;
-  }
-  return Philox{{c0, c1, c2, c3}};
-}
-
 // uniform item id in [0, num_items): high 64 bits of (64 random bits) x num_items
 __device__ __forceinline__ int64_t draw_item(uint64_t seed, uint64_t position, uint32_t draw,
                                              uint64_t num_items) {

@@ -52,18 +52,19 @@ class HParams(dict):
 # ---- generic route: model(users, items) ---------------------------------------------------------
 class _MFScore(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, users, items, ue, ie, ub, ib, y_range, sparse, status):
+    def forward(ctx, users, items, ue, ie, ub, ib, y_range, sparse, status, dropout=None):
         tables = _lib.make_tables(ue, ie, ub, ib)
-        out = ops.mf_score(tables, users, items, y_range, status)
+        out = ops.mf_score(tables, users, items, y_range, status, dropout)
         ctx.save_for_backward(users, items, ue, ie, ub, ib)
-        ctx.y_range, ctx.sparse, ctx.status = y_range, sparse, status
+        ctx.y_range, ctx.sparse, ctx.status, ctx.dropout = y_range, sparse, status, dropout
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         users, items, ue, ie, ub, ib = ctx.saved_tensors
         tables = _lib.make_tables(ue, ie, ub, ib)
-        gu, gi, gb = ops.mf_score_backward(tables, users, items, grad_out, ctx.y_range, ctx.status)
+        gu, gi, gb = ops.mf_score_backward(tables, users, items, grad_out, ctx.y_range, ctx.status,
+                                           ctx.dropout)
         u_idx = users.long().reshape(1, -1)
         i_idx = items.long().reshape(1, -1)
 
@@ -73,7 +74,7 @@ class _MFScore(torch.autograd.Function):
             return torch.zeros_like(like).index_add_(0, idx[0], vals)
 
         return (None, None, build(u_idx, gu, ue), build(i_idx, gi, ie), build(u_idx, gb, ub),
-                build(i_idx, gb, ib), None, None, None)
+                build(i_idx, gb, ib), None, None, None, None)
 
 
 # ---- fused route: calculate_loss ---------------------------------------------------------------
@@ -473,16 +474,23 @@ class MatrixFactorizationModel(nn.Module):
 
     def forward(self, users: torch.Tensor, items: torch.Tensor) -> torch.Tensor:
         """``matrix_factorization.py:120-159``."""
-        if self.training and self.hparams.dropout_p > 0:
-            raise NotImplementedError(
-                'dropout_p > 0 in training mode is not implemented in the HIP path '
-                '(SURVEY.md §7: torch-RNG parity is infeasible); use dropout_p=0.')
         _lib.require_hip(self.user_embeddings.weight, 'MatrixFactorizationModel')
         y = self.hparams.get('y_range')
+        dropout = None
+        if self.training and self.hparams.dropout_p > 0:
+            # nn.Dropout on both gathered rows (:143-147), masks from the library's counter-based
+            # generator: seeded once per model from torch's generator (so ``torch.manual_seed``
+            # makes runs repeatable), a fresh call number per forward (fresh masks per call)
+            if self.__dict__.get('_dropout_seed') is None:
+                self.__dict__['_dropout_seed'] = int(torch.randint(0, 2 ** 62, (1,)).item())
+                self.__dict__['_dropout_calls'] = 0
+            self.__dict__['_dropout_calls'] += 1
+            dropout = (float(self.hparams.dropout_p), self.__dict__['_dropout_seed'],
+                       self.__dict__['_dropout_calls'])
         return _MFScore.apply(users, items, self.user_embeddings.weight,
                               self.item_embeddings.weight, self.user_biases.weight,
                               self.item_biases.weight, tuple(y) if y is not None else None,
-                              bool(self.hparams.sparse), self._status_flag())
+                              bool(self.hparams.sparse), self._status_flag(), dropout)
 
     def _can_fuse(self):
         if self._loss_kind is None or self.hparams.get('y_range') is not None:

@@ -222,7 +222,8 @@ def optim_cfg(algo, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0
                     float(lr_decay))
 
 
-def mf_score(tables, users, items, y_range=None, status=None):
+def mf_score(tables, users, items, y_range=None, status=None, dropout=None):
+    """``dropout = (p, seed, call)``: training-mode forward with nn.Dropout on both rows."""
     require_hip(users, 'users')
     require_hip(items, 'items')
     users = users.contiguous()
@@ -231,6 +232,15 @@ def mf_score(tables, users, items, y_range=None, status=None):
         raise ValueError('users and items must be 1-d tensors of the same length')
     out = torch.empty(users.shape[0], dtype=torch.float32, device=users.device)
     has_y = y_range is not None
+    if dropout is not None:
+        p, seed, call = dropout
+        check(load().collie_mf_score_dropout(
+            byref(tables), ptr(users), idx_dtype(users), ptr(items), idx_dtype(items),
+            users.shape[0], int(has_y), float(y_range[0]) if has_y else 0.0,
+            float(y_range[1]) if has_y else 0.0, float(p), seed & 0xFFFFFFFFFFFFFFFF,
+            call & 0xFFFFFFFFFFFFFFFF, ptr(out), ptr(status), stream_ptr()),
+            'collie_mf_score_dropout')
+        return out
     check(load().collie_mf_score(
         byref(tables), ptr(users), idx_dtype(users), ptr(items), idx_dtype(items),
         users.shape[0], int(has_y), float(y_range[0]) if has_y else 0.0,
@@ -239,7 +249,7 @@ def mf_score(tables, users, items, y_range=None, status=None):
     return out
 
 
-def mf_score_backward(tables, users, items, grad_out, y_range=None, status=None):
+def mf_score_backward(tables, users, items, grad_out, y_range=None, status=None, dropout=None):
     users = users.contiguous()
     items = items.contiguous()
     grad_out = grad_out.contiguous().float()
@@ -249,6 +259,14 @@ def mf_score_backward(tables, users, items, grad_out, y_range=None, status=None)
     gi = torch.empty(M, D, dtype=torch.float32, device=dev)
     gb = torch.empty(M, 1, dtype=torch.float32, device=dev)
     has_y = y_range is not None
+    if dropout is not None:
+        p, seed, call = dropout
+        check(load().collie_mf_score_dropout_backward(
+            byref(tables), ptr(users), idx_dtype(users), ptr(items), idx_dtype(items), M,
+            int(has_y), float(y_range[0]) if has_y else 0.0, float(y_range[1]) if has_y else 0.0,
+            float(p), seed & 0xFFFFFFFFFFFFFFFF, call & 0xFFFFFFFFFFFFFFFF, ptr(grad_out), ptr(gu),
+            ptr(gi), ptr(gb), ptr(status), stream_ptr()), 'collie_mf_score_dropout_backward')
+        return gu, gi, gb
     check(load().collie_mf_score_backward(
         byref(tables), ptr(users), idx_dtype(users), ptr(items), idx_dtype(items), M, int(has_y),
         float(y_range[0]) if has_y else 0.0, float(y_range[1]) if has_y else 0.0, ptr(grad_out),

@@ -135,6 +135,27 @@ int collie_mf_score_backward(const collie_mf_tables* t, const void* users, int32
                              float* grad_user_rows, float* grad_item_rows, float* grad_bias,
                              int32_t* status, collie_stream_t stream);
 
+/* The same two calls in TRAINING mode with dropout_p > 0 (matrix_factorization.py:143-147:
+ * nn.Dropout on the gathered user rows and, independently, on the gathered item rows, before the
+ * product).  Element d of pair j is kept with probability 1 - p and scaled by 1 / (1 - p); the
+ * multipliers come from Philox4x32-10 with counter (j, d, call) and key `seed`, so the backward
+ * call reproduces the forward call's masks from (seed, call) alone -- nothing is stored.  Pass a
+ * fresh `call` number for every forward call (the reference draws fresh masks for the positive and
+ * the negative pass of one step).  torch's own generator stream cannot be reproduced on a device:
+ * the DISTRIBUTION and the arithmetic given a mask are what match the reference. */
+int collie_mf_score_dropout(const collie_mf_tables* t, const void* users, int32_t users_dtype,
+                            const void* items, int32_t items_dtype, int64_t m,
+                            int32_t has_y_range, float y_lo, float y_hi, float dropout_p,
+                            uint64_t seed, uint64_t call, float* scores, int32_t* status,
+                            collie_stream_t stream);
+int collie_mf_score_dropout_backward(const collie_mf_tables* t, const void* users,
+                                     int32_t users_dtype, const void* items, int32_t items_dtype,
+                                     int64_t m, int32_t has_y_range, float y_lo, float y_hi,
+                                     float dropout_p, uint64_t seed, uint64_t call,
+                                     const float* grad_out, float* grad_user_rows,
+                                     float* grad_item_rows, float* grad_bias, int32_t* status,
+                                     collie_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * A4-A7  stand-alone loss callables  f(positive_scores, negative_scores, num_items=, ...)
  * collie/loss/{bpr,hinge,warp,metadata_utils}.py.  s_neg is [K,B] row-major (K = 1 for the

@@ -64,6 +64,41 @@ def mf_forward(tables, users, items, y_range=None):
     return preds
 
 
+def dropout_multipliers(n_pairs, dim, p, seed, call):
+    """The multipliers (0 or 1 / (1 - p)) ``nn.Dropout`` applies to the gathered user rows and item
+    rows of one training-mode forward call (matrix_factorization.py:143-147), drawn from the
+    build's counter-based stream (Philox4x32-10, counter = (pair, element, call), key = seed): the
+    reference's torch generator stream cannot be reproduced on a device, so the STREAM is parity
+    unpinned; the distribution (independent Bernoulli(1 - p) per element and row) and everything
+    computed from a given mask are the reference's."""
+    from oracle.sampler_oracle import MASK32, philox4x32_10
+    thr = max(int(float(p) * 4294967296.0), 1)
+    scale = F32(1.0) / (F32(1.0) - F32(p)) if p < 1 else F32(0.0)
+    mu = np.zeros((n_pairs, dim), F32)
+    mi = np.zeros((n_pairs, dim), F32)
+    key = (seed & MASK32, ((seed >> 32) ^ (call >> 32)) & MASK32)
+    for q in range(n_pairs):
+        for d in range(dim):
+            r = philox4x32_10((q & MASK32, (q >> 32) & MASK32, d, call & MASK32), key)
+            mu[q, d] = scale if r[0] >= thr else 0.0
+            mi[q, d] = scale if r[1] >= thr else 0.0
+    return mu, mi
+
+
+def mf_forward_dropout(tables, users, items, p, seed, call, grad_out=None):
+    """Training-mode forward with dropout on both rows, and (if ``grad_out`` is given) the values
+    of the uncoalesced sparse gradients autograd produces: d/dU rows, d/dI rows, d/d bias."""
+    mu, mi = dropout_multipliers(len(users), tables['user_embeddings'].shape[1], p, seed, call)
+    ue = (tables['user_embeddings'][users] * mu).astype(F32)
+    ie = (tables['item_embeddings'][items] * mi).astype(F32)
+    preds = ((ue * ie).sum(axis=1, dtype=F32) + tables['user_biases'][users, 0]
+             + tables['item_biases'][items, 0]).astype(F32)
+    if grad_out is None:
+        return preds
+    g = np.asarray(grad_out, F32)[:, None]
+    return preds, ((g * ie) * mu).astype(F32), ((g * ue) * mi).astype(F32), g.astype(F32)
+
+
 # --------------------------------------------------------------------------------------------
 # A7  ideal_difference_from_metadata  (collie/loss/metadata_utils.py:60-71)
 # --------------------------------------------------------------------------------------------

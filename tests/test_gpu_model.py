@@ -468,3 +468,86 @@ def test_similarity_and_user_predictions_vs_oracle():
             model.item_item_similarity(123)
         with pytest.raises(ValueError):
             model.get_user_predictions(item_id=123)
+
+
+def test_dropout_forward_backward_vs_oracle_and_statistics(dev):
+    """``dropout_p > 0`` in training mode (matrix_factorization.py:143-147).  Given the mask stream
+    (counter-based, so the oracle can replay it) scores and sparse gradient values equal the
+    reference's op sequence to 1e-5; over many calls the scores are unbiased with the analytic
+    variance (statistical parity with nn.Dropout); eval mode applies no dropout."""
+    from oracle import mf_oracle as O
+    from collie_amd import _lib, ops
+    rng = np.random.default_rng(0)
+    U, N, D, M, p = 40, 30, 24, 57, 0.3
+    tables = O.init_tables(U, N, D, rng)
+    tables['user_embeddings'] *= np.float32(12.0)
+    tables['item_embeddings'] *= np.float32(12.0)
+    tables['item_biases'] = rng.normal(0, 0.1, (N, 1)).astype(np.float32)
+    td = {n: torch.tensor(v, device=dev) for n, v in tables.items()}
+    t = _lib.make_tables(td['user_embeddings'], td['item_embeddings'], td['user_biases'],
+                         td['item_biases'])
+    users = rng.integers(0, U, M)
+    items = rng.integers(0, N, M)
+    ut, it = torch.tensor(users, device=dev), torch.tensor(items, device=dev)
+    g = rng.normal(size=M).astype(np.float32)
+    for seed, call in ((5, 1), (2 ** 40 + 7, 2 ** 33 + 3)):
+        want = O.mf_forward_dropout(tables, users, items, p, seed, call, g)
+        got = ops.mf_score(t, ut, it, None, None, (p, seed, call)).cpu().numpy()
+        close(got, want[0], rtol=1e-5)
+        gu, gi, gb = ops.mf_score_backward(t, ut, it, torch.tensor(g, device=dev), None, None,
+                                           (p, seed, call))
+        close(gu.cpu().numpy(), want[1], rtol=1e-5)
+        close(gi.cpu().numpy(), want[2], rtol=1e-5)
+        close(gb.cpu().numpy(), want[3], rtol=1e-6)
+        # zeros exactly where either row's element was dropped
+        assert np.array_equal(gu.cpu().numpy() == 0, want[1] == 0)
+    # statistics over calls: E[score] = undropped score, Var = sum_d (u_d i_d)^2 (1/(1-p)^2 - 1)
+    calls = 4000
+    acc = torch.zeros(M, dtype=torch.float64, device=dev)
+    acc2 = torch.zeros(M, dtype=torch.float64, device=dev)
+    for c in range(calls):
+        s = ops.mf_score(t, ut, it, None, None, (p, 11, c + 1)).double()
+        acc += s
+        acc2 += s * s
+    mean = (acc / calls).cpu().numpy()
+    var = (acc2 / calls).cpu().numpy() - mean ** 2
+    plain = O.mf_forward(tables, users, items)
+    prod = (tables['user_embeddings'][users] * tables['item_embeddings'][items]).astype(np.float64)
+    var_want = (prod ** 2).sum(1) * (1.0 / (1 - p) ** 2 - 1.0)
+    assert np.all(np.abs(mean - plain) <= 5 * np.sqrt(var_want / calls) + 1e-6)
+    np.testing.assert_allclose(var, var_want, rtol=0.15)
+
+
+def test_dropout_model_trains_and_eval_mode_is_plain(dev):
+    from collie_amd.model import MatrixFactorizationModel
+    from collie_amd.trainer import CollieMinimalTrainer
+    runs = []
+    for rep in range(2):
+        inter = synth(400, 300, 6000, seed=2, K=5)      # its negative sampler is seeded too
+        torch.manual_seed(7)
+        m = MatrixFactorizationModel(train=inter, embedding_dim=16, dropout_p=0.25, sparse=True,
+                                     optimizer='sparse_adam', loss='bpr', lr=5e-2,
+                                     lr_scheduler_func=None)
+        with torch.no_grad():
+            m.user_embeddings.weight.mul_(5.0)
+            m.item_embeddings.weight.mul_(5.0)
+        tr = CollieMinimalTrainer(m, max_epochs=3, verbosity=0, enable_model_summary=False,
+                                  early_stopping_patience=None)
+        first = []
+        inner = tr._train_loop_single_epoch
+        tr._train_loop_single_epoch = lambda model, epoch: first.append(inner(model, epoch)) or first[-1]
+        tr.fit(m)
+        runs.append((first, m.item_embeddings.weight.detach().cpu().numpy().copy()))
+        assert first[-1] < first[0]                  # it learns
+    # eval mode: no dropout, forward equals the plain score kernel; train mode differs
+    m.eval()
+    u = torch.arange(50, device=dev)
+    i = torch.arange(50, device=dev)
+    with torch.no_grad():
+        a, b = m(u, i), m(u, i)
+        m.train()
+        c = m(u, i)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    # the loader's negatives come from its own numpy generator (seeded); masks from the model's
+    # seed drawn under torch.manual_seed: the two runs are identical
+    np.testing.assert_array_equal(runs[0][1], runs[1][1])
