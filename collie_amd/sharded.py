@@ -254,6 +254,16 @@ class _Comm:
                 dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
+    def gather_to_host(self, t, dst=0):
+        """Every rank's ``t`` (same shape) as a list of HOST tensors on rank ``dst``; None on the
+        other ranks.  Only ``dst`` ever holds more than its own piece."""
+        if self.world == 1:
+            return [t.cpu()]
+        src = t.cpu() if (self.staged and t.is_cuda) else t.contiguous()
+        out = [torch.empty_like(src) for _ in range(self.world)] if self.rank == dst else None
+        dist.gather(src, out, dst=dst, group=self.group)
+        return [o.cpu() for o in out] if out is not None else None
+
     def all_gather(self, t):
         if self.world == 1:
             return [t]
@@ -441,7 +451,8 @@ class ShardedMatrixFactorizationModel:
         return full
 
     def state_dict(self):
-        """Reference-format ``state_dict`` (full tables on every rank: moderate sizes only)."""
+        """Reference-format ``state_dict`` with the full tables on EVERY rank's device: for
+        moderate sizes and tests; ``save_model`` / ``state_dict_to_rank0`` stream instead."""
         U, N = self.hparams['num_users'], self.hparams['num_items']
         return {
             'user_biases.weight': self._gather_rows(self.user_biases, U).reshape(U, 1),
@@ -450,9 +461,50 @@ class ShardedMatrixFactorizationModel:
             'item_embeddings.weight': self._gather_rows(self.item_embeddings, N),
         }
 
-    def save_model(self, filename='model.pth'):
-        """``base_pipeline.py:880-900`` file format, written by rank 0 from the gathered tables."""
-        sd = {k: v.cpu() for k, v in self.state_dict().items()}
+    def _table_to_rank0_host(self, local, n_global, chunk_rows):
+        """One table in global row order as a HOST tensor on rank 0 (None elsewhere), streamed in
+        chunks of ``chunk_rows`` local rows: no rank ever holds another rank's shard on its GPU and
+        only rank 0's host memory holds the full table (100 M x 128 floats = 51 GB)."""
+        G, rank = self.comm.world, self.comm.rank
+        per = (n_global + G - 1) // G
+        full = None
+        if rank == 0:
+            full = torch.empty((n_global,) + tuple(local.shape[1:]), dtype=local.dtype)
+        for lo in range(0, per, chunk_rows):
+            hi = min(lo + chunk_rows, per)
+            piece = torch.zeros((hi - lo,) + tuple(local.shape[1:]), dtype=local.dtype,
+                                device=local.device)
+            have = max(0, min(hi, local.shape[0]) - lo)
+            if have:
+                piece[:have] = local[lo:lo + have]
+            parts = self.comm.gather_to_host(piece, dst=0)
+            if parts is not None:
+                for r, part in enumerate(parts):
+                    n_r = (n_global - r + G - 1) // G            # rows rank r owns
+                    take = max(0, min(hi, n_r) - lo)
+                    if take:
+                        full[lo * G + r:(lo + take - 1) * G + r + 1:G] = part[:take]
+        return full
+
+    def state_dict_to_rank0(self, chunk_rows: int = 1 << 20):
+        """Reference-format ``state_dict`` on rank 0's HOST only (None on the other ranks)."""
+        U, N = self.hparams['num_users'], self.hparams['num_items']
+        out = {}
+        for name, local, n, shape in (
+                ('user_biases.weight', self.user_biases, U, (U, 1)),
+                ('item_biases.weight', self.item_biases, N, (N, 1)),
+                ('user_embeddings.weight', self.user_embeddings, U, None),
+                ('item_embeddings.weight', self.item_embeddings, N, None)):
+            full = self._table_to_rank0_host(local, n, chunk_rows)
+            if full is not None:
+                out[name] = full.reshape(shape) if shape is not None else full
+        return out if self.comm.rank == 0 else None
+
+    def save_model(self, filename='model.pth', chunk_rows: int = 1 << 20):
+        """``base_pipeline.py:880-900`` file format, written by rank 0.  The tables are streamed to
+        rank 0's host memory chunk by chunk (``state_dict_to_rank0``): no GPU ever holds more than
+        its own shard plus one chunk.  Collective: every rank must call it."""
+        sd = self.state_dict_to_rank0(chunk_rows)
         if self.comm.rank == 0:
             hp = {k: v for k, v in self.hparams.items() if k not in ('seed', 'num_negative_samples')}
             hp.update(dropout_p=0.0, weight_decay=0.0, metadata_for_loss=None,

@@ -107,6 +107,25 @@ def check_init(rank, world):
     assert torch.equal(sd['user_embeddings.weight'].cpu(), want_u)  # independent of G and device
     assert torch.equal(sd['item_embeddings.weight'].cpu(), want_i)
     assert float(sd['user_biases.weight'].abs().max()) == 0.0
+    # streamed gather to rank 0's host (tiny chunks: several rounds, ragged last chunk) and the
+    # reference-format file written from it
+    host = m.state_dict_to_rank0(chunk_rows=5)
+    assert (host is None) == (rank != 0)
+    if rank == 0:
+        for k_, v in sd.items():
+            assert torch.equal(host[k_], v.cpu()), k_
+    import os
+    import tempfile
+    path = os.path.join(tempfile.gettempdir(), f'collie_sharded_save_{os.getppid()}.pth')
+    m.save_model(path, chunk_rows=7)
+    dist.barrier()
+    if rank == 0:
+        loaded = torch.load(path, weights_only=False)
+        assert set(loaded) == {'state_dict', 'hparams'}
+        for k_, v in sd.items():
+            assert torch.equal(loaded['state_dict'][k_], v.cpu()), k_
+        assert loaded['hparams']['num_users'] == U and loaded['hparams']['embedding_dim'] == D
+        os.remove(path)
     big = counter_normal(torch.arange(4096), 64, 0, 0, 1.0)
     assert abs(float(big.mean())) < 0.01 and abs(float(big.std()) - 1.0) < 0.01
 
