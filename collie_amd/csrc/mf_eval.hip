@@ -283,22 +283,63 @@ constexpr int kBlockDma = 512;
 constexpr int kWavesDma = kBlockDma / kWave;
 constexpr int kUsersPerBlockDma = 32 * kWavesDma;  // 256
 
-// t_lt += #{e < N: s < lo_e}, t_le += #{e < N: s <= hi_e} over register-resident thresholds
+// ---- rank counting against register-resident thresholds -----------------------------------------
+// Thresholds are held as (lo_e, hn_e = nextafter(hi_e, +inf)): s <= hi  <=>  s < hn, so both counters
+// are "how many thresholds is s below".  Two forms with identical results on finite scores:
+//  * compare form (count_thr): v_cmp + add-with-carry per test.  Every test goes through a lane
+//    mask (VCC), and back-to-back VCC producers / consumers cost ~21 cycles per test on gfx950
+//    (tools/calib/mfma_valu_overlap.hip).  Kept for the partial last tile of a chunk, whose
+//    masked rows are NaN (a NaN must fail every test).
+//  * sign form (count_thr_sign): s < t  <=>  the sign bit of (s - t) is set.  One subtract, and
+//    v_alignbit_b32 shifts the sign bit into a 32-bit collector that is popcounted once per
+//    score: 2 instructions per test, none touching VCC (~6 cycles each).  s - t is exact in sign:
+//    a negative difference cannot round to +0, equal operands give +0, and thresholds of -inf /
+//    +inf behave as the comparisons do for every finite score.
+// On gfx950 the fp32 MFMAs and the vector instructions of a SIMD do not overlap (same calibration
+// file: a wave's MFMA + VALU time is the sum, two waves per SIMD gain ~30 %), so the counting has to
+// be made short, it cannot be hidden.
+// compare form; N = threshold pairs in use
 template <int N>
-__device__ __forceinline__ void count_thr(float s, const float (&lo)[kCap], const int (&hi)[kCap],
+__device__ __forceinline__ void count_thr(float s, const float (&lo)[kCap], const float (&hn)[kCap],
                                           uint32_t& t_lt, uint32_t& t_le) {
 #pragma unroll
   for (int e = 0; e < N; ++e) {
     t_lt += s < lo[e] ? 1u : 0u;
-    t_le += s <= __int_as_float(hi[e]) ? 1u : 0u;
+    t_le += s < hn[e] ? 1u : 0u;
   }
 }
 
-// rank counters of one lane's 16 scores of a sub-tile; N = threshold registers in use (one fully
-// unrolled, statically indexed instance per wave-uniform tier)
+// nextafter(x, +inf) for the "<=" thresholds (x is never NaN); +inf stays +inf
+__device__ __forceinline__ float next_up(float x) {
+  if (x == INFINITY) return x;
+  if (x == 0.0f) return __uint_as_float(1u);                    // smallest positive denormal
+  const uint32_t u = __float_as_uint(x);
+  return __uint_as_float(x > 0.0f ? u + 1u : u - 1u);
+}
+
+// sign form: the sign bits of one score's N differences of a kind go into one 32-bit collector.
+// (A packed variant -- v_pk_add_f32 on two scores at once -- was tried: through inline asm it
+// spills ~1000 registers, through vector types the compiler splats every threshold into a
+// register pair and the pass gets slower, 261 ms against 221 ms.)
 template <int N>
+__device__ __forceinline__ void count_thr_sign(float s, const float (&lo)[kCap],
+                                               const float (&hn)[kCap], uint32_t& t_lt,
+                                               uint32_t& t_le) {
+  uint32_t bits_lt = 0, bits_le = 0;
+#pragma unroll
+  for (int e = 0; e < N; ++e) {
+    bits_lt = __builtin_amdgcn_alignbit(bits_lt, __float_as_uint(s - lo[e]), 31);
+    bits_le = __builtin_amdgcn_alignbit(bits_le, __float_as_uint(s - hn[e]), 31);
+  }
+  t_lt += __popc(bits_lt);
+  t_le += __popc(bits_le);
+}
+
+// rank counters of one lane's 16 scores of a sub-tile; N = threshold pairs in use (one fully
+// unrolled instance per wave-uniform tier), SIGN = sign form (full tiles only)
+template <int N, bool SIGN>
 __device__ __forceinline__ void rank_subtile(const f32x16& acc, const float (&lo)[kCap],
-                                             const int (&hi)[kCap], float bscore, int bid,
+                                             const float (&hn)[kCap], float bscore, int bid,
                                              int64_t gid0, int64_t id_stride, uint32_t& t_above,
                                              uint32_t& t_lt, uint32_t& t_le) {
   // global ids fit 31 bits (checked by the entry points): 32-bit id arithmetic for the tie-break
@@ -308,7 +349,10 @@ __device__ __forceinline__ void rank_subtile(const f32x16& acc, const float (&lo
     const float s = acc[rr];
     const int gid = g0 + ((rr & 3) + 8 * (rr >> 2)) * st;
     t_above += (s > bscore || (s == bscore && gid < bid)) ? 1u : 0u;
-    count_thr<N>(s, lo, hi, t_lt, t_le);
+    if (SIGN)
+      count_thr_sign<N>(s, lo, hn, t_lt, t_le);
+    else
+      count_thr<N>(s, lo, hn, t_lt, t_le);
   }
 }
 
@@ -344,8 +388,7 @@ __global__ __launch_bounds__(kBlockDma) void eval_gemm_dma_kernel(const EvalPara
 
   float top_s[kCap];   // TOPK: the sorted candidate list
   int top_i[kCap];
-  float thr_l[kCap];   // RANK: (lo, hi) raw-score intervals of the user's first kCap positives
-  int thr_h[kCap];
+  float thr_l[kCap], thr_h[kCap];  // RANK: (lo, next_up(hi)) raw-score bounds of the first kCap positives
   unsigned long long c_above = 0, c_lt = 0, c_le = 0, c_below_all = 0;
   int64_t e_begin = 0, e_end = 0;
   float bscore = 0.0f, lo_min = INFINITY, hi_max = -INFINITY;
@@ -365,7 +408,7 @@ __global__ __launch_bounds__(kBlockDma) void eval_gemm_dma_kernel(const EvalPara
 #pragma unroll
     for (int i = 0; i < kCap; ++i) {
       thr_l[i] = -INFINITY;
-      thr_h[i] = __float_as_int(-INFINITY);
+      thr_h[i] = next_up(-INFINITY);
     }
     if (user_ok) {
       e_begin = p.indptr[uslot];
@@ -376,7 +419,7 @@ __global__ __launch_bounds__(kBlockDma) void eval_gemm_dma_kernel(const EvalPara
       for (int i = 0; i < kCap; ++i) {
         if (e_begin + i < e_end) {
           thr_l[i] = p.thr_lo[e_begin + i];
-          thr_h[i] = __float_as_int(p.thr_hi[e_begin + i]);
+          thr_h[i] = next_up(p.thr_hi[e_begin + i]);
         }
       }
       for (int64_t e = e_begin + kCap; e < e_end; ++e) {
@@ -520,8 +563,15 @@ __global__ __launch_bounds__(kBlockDma) void eval_gemm_dma_kernel(const EvalPara
         // 32-bit counters per sub-tile (at most 16 * kCap increments), folded into the 64-bit ones
         uint32_t t_above = 0, t_lt = 0, t_le = 0;
         const int64_t gid0 = (base + sub * 32 + 4 * h) * p.id_stride + p.id_offset;
-#define COLLIE_RANK_TIER(N_) \
-  rank_subtile<N_>(acc, thr_l, thr_h, bscore, bid, gid0, p.id_stride, t_above, t_lt, t_le)
+#define COLLIE_RANK_TIER(N_)                                                                       \
+  do {                                                                                            \
+    if (full)                                                                                     \
+      rank_subtile<N_, true>(acc, thr_l, thr_h, bscore, bid, gid0, p.id_stride, t_above, t_lt,    \
+                             t_le);                                                               \
+    else                                                                                          \
+      rank_subtile<N_, false>(acc, thr_l, thr_h, bscore, bid, gid0, p.id_stride, t_above, t_lt,   \
+                              t_le);                                                              \
+  } while (0)
         // tiers of two threshold pairs: the counting is VALU-bound, every unused pair costs
         if (n_thr <= 8) {
           if (n_thr <= 4) { if (n_thr <= 2) COLLIE_RANK_TIER(2); else COLLIE_RANK_TIER(4); }
