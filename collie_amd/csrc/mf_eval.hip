@@ -283,31 +283,24 @@ constexpr int kBlockDma = 512;
 constexpr int kWavesDma = kBlockDma / kWave;
 constexpr int kUsersPerBlockDma = 32 * kWavesDma;  // 256
 
-// ---- rank counting against register-resident thresholds -----------------------------------------
-// Thresholds are held as (lo_e, hn_e = nextafter(hi_e, +inf)): s <= hi  <=>  s < hn, so both counters
-// are "how many thresholds is s below".  Two forms with identical results on finite scores:
-//  * compare form (count_thr): v_cmp + add-with-carry per test.  Every test goes through a lane
-//    mask (VCC), and back-to-back VCC producers / consumers cost ~21 cycles per test on gfx950
-//    (tools/calib/mfma_valu_overlap.hip).  Kept for the partial last tile of a chunk, whose
-//    masked rows are NaN (a NaN must fail every test).
-//  * sign form (count_thr_sign): s < t  <=>  the sign bit of (s - t) is set.  One subtract, and
-//    v_alignbit_b32 shifts the sign bit into a 32-bit collector that is popcounted once per
-//    score: 2 instructions per test, none touching VCC (~6 cycles each).  s - t is exact in sign:
-//    a negative difference cannot round to +0, equal operands give +0, and thresholds of -inf /
-//    +inf behave as the comparisons do for every finite score.
-// On gfx950 the fp32 MFMAs and the vector instructions of a SIMD do not overlap (same calibration
-// file: a wave's MFMA + VALU time is the sum, two waves per SIMD gain ~30 %), so the counting has to
-// be made short, it cannot be hidden.
-// compare form; N = threshold pairs in use
-template <int N>
-__device__ __forceinline__ void count_thr(float s, const float (&lo)[kCap], const float (&hn)[kCap],
-                                          uint32_t& t_lt, uint32_t& t_le) {
-#pragma unroll
-  for (int e = 0; e < N; ++e) {
-    t_lt += s < lo[e] ? 1u : 0u;
-    t_le += s < hn[e] ? 1u : 0u;
-  }
-}
+// ---- rank counting: a per-user search tree in LDS ---------------------------------------------------
+// What the AUC needs from score s is  sum_e [s < lo_e]  and  sum_e [s <= hi_e] = sum_e [s < hn_e],
+// hn_e = nextafter(hi_e, +inf), over the user's positives e.  Testing s against every threshold
+// costs 2 vector instructions per test whatever the form (v_cmp + add-with-carry, or subtract +
+// v_alignbit of the sign bit), and on gfx950 the fp32 MFMAs and the vector instructions of a SIMD do
+// not overlap (tools/calib/mfma_valu_overlap.hip: a wave's MFMA + VALU time is the sum), so that
+// counting cannot be hidden under the GEMM: with 10 positives it is 40 instructions per score.
+// Instead the 2n values {lo_e} u {hn_e} of a user's first kTreePos positives are sorted once per
+// workgroup (descending) into an implicit binary tree in LDS (node k has children 2k, 2k+1; unused
+// nodes hold -inf).  A score walks it in 5 steps,  k <- 2k + [s < node[k]]  -- one LDS read, one
+// subtract and one v_alignbit each (s < v  <=>  sign bit of s - v; exact: a negative difference
+// cannot round to +0, equal operands give +0) -- and ends at k = 32 + g, g = number of values
+// above s.  Entry 32 + g of the same array holds (#lo among the g largest) | (#hn among them) << 16,
+// which are the two sums.  17 vector instructions per score, independent of n.
+// The sigmoid-tie intervals [lo_e, hi_e] of distinct positives are disjoint or identical, which is
+// all the ordering of equal values needs.  Scores are assumed finite (as the sign test always did).
+constexpr int kTreePos = 15;     // positives per user in the tree: 2 * 15 values, 31 nodes
+constexpr int kTreeWords = 64;   // [1, 32) nodes, [32, 64) counts
 
 // nextafter(x, +inf) for the "<=" thresholds (x is never NaN); +inf stays +inf
 __device__ __forceinline__ float next_up(float x) {
@@ -317,43 +310,91 @@ __device__ __forceinline__ float next_up(float x) {
   return __uint_as_float(x > 0.0f ? u + 1u : u - 1u);
 }
 
-// sign form: the sign bits of one score's N differences of a kind go into one 32-bit collector.
-// (A packed variant -- v_pk_add_f32 on two scores at once -- was tried: through inline asm it
-// spills ~1000 registers, through vector types the compiler splats every threshold into a
-// register pair and the pass gets slower, 261 ms against 221 ms.)
-template <int N>
-__device__ __forceinline__ void count_thr_sign(float s, const float (&lo)[kCap],
-                                               const float (&hn)[kCap], uint32_t& t_lt,
-                                               uint32_t& t_le) {
-  uint32_t bits_lt = 0, bits_le = 0;
-#pragma unroll
-  for (int e = 0; e < N; ++e) {
-    bits_lt = __builtin_amdgcn_alignbit(bits_lt, __float_as_uint(s - lo[e]), 31);
-    bits_le = __builtin_amdgcn_alignbit(bits_le, __float_as_uint(s - hn[e]), 31);
+// Builds one user's tree; `tree` points at the user's column of a [kTreeWords][32] word array
+// (entry k at tree[k * 32]).  Called by one lane per user.
+__device__ void build_rank_tree(uint32_t* tree, const float* __restrict__ thr_lo,
+                                const float* __restrict__ thr_hi, int n) {
+  for (int k = 1; k < 32; ++k) tree[k * 32] = __float_as_uint(-INFINITY);
+  for (int g = 0; g < 32; ++g) tree[(32 + g) * 32] = 0u;
+  const int m = 2 * n;
+  for (int i = 0; i < m; ++i) {
+    const float vi = i < n ? thr_lo[i] : next_up(thr_hi[i - n]);
+    int rank = 0;                                   // position in descending order (stable)
+    for (int j = 0; j < m; ++j) {
+      const float vj = j < n ? thr_lo[j] : next_up(thr_hi[j - n]);
+      rank += (vj > vi || (vj == vi && j < i)) ? 1 : 0;
+    }
+    // in-order position rank of the perfect 31-node tree -> node number
+    const int t = rank + 1, z = __builtin_ctz(t);
+    tree[((1 << (4 - z)) + (t >> (z + 1))) * 32] = __float_as_uint(vi);
+    tree[(32 + rank + 1) * 32] += i < n ? 1u : 0x10000u;   // delta: this value is among the g
+  }                                                        // largest for every g > rank
+  uint32_t run = 0;
+  for (int g = 1; g < 32; ++g) {
+    run += tree[(32 + g) * 32];
+    tree[(32 + g) * 32] = run;
   }
-  t_lt += __popc(bits_lt);
-  t_le += __popc(bits_le);
 }
 
-// rank counters of one lane's 16 scores of a sub-tile; N = threshold pairs in use (one fully
-// unrolled instance per wave-uniform tier), SIGN = sign form (full tiles only)
-template <int N, bool SIGN>
-__device__ __forceinline__ void rank_subtile(const f32x16& acc, const float (&lo)[kCap],
-                                             const float (&hn)[kCap], float bscore, int bid,
-                                             int64_t gid0, int64_t id_stride, uint32_t& t_above,
-                                             uint32_t& t_lt, uint32_t& t_le) {
-  // global ids fit 31 bits (checked by the entry points): 32-bit id arithmetic for the tie-break
-  const int g0 = static_cast<int>(gid0), st = static_cast<int>(id_stride);
+// sum over a lane's 16 scores of (sum_e [s < lo_e]) | (sum_e [s < hn_e]) << 16.  The 16 walks go
+// down the tree level by level, so that 16 LDS reads are in flight at a time (one walk at a time
+// waits out the LDS latency five times per score).  MASKED: NaN scores (rows past the shard end in
+// the partial last tile) walk somewhere and are dropped.
+template <bool MASKED>
+__device__ __forceinline__ uint32_t rank_tree_count16(const uint32_t* tree, const f32x16& acc) {
+  uint32_t k[16];
+  const float root = __uint_as_float(tree[32]);
+#pragma unroll
+  for (int rr = 0; rr < 16; ++rr)
+    k[rr] = __builtin_amdgcn_alignbit(1u, __float_as_uint(acc[rr] - root), 31);
+#pragma unroll
+  for (int level = 1; level < 5; ++level) {
+    float v[16];
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) v[rr] = __uint_as_float(tree[k[rr] * 32]);
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr)
+      k[rr] = __builtin_amdgcn_alignbit(k[rr], __float_as_uint(acc[rr] - v[rr]), 31);
+  }
+  uint32_t c[16], total = 0;
+#pragma unroll
+  for (int rr = 0; rr < 16; ++rr) c[rr] = tree[k[rr] * 32];
+#pragma unroll
+  for (int rr = 0; rr < 16; ++rr) total += (!MASKED || acc[rr] == acc[rr]) ? c[rr] : 0u;
+  return total;
+}
+
+// #{scores that precede the user's best positive (bscore, bid) in (score desc, id asc) order}
+template <bool MASKED>
+__device__ __forceinline__ uint32_t count_above16(const f32x16& acc, float bscore, int bid, int g0,
+                                                  int st) {
+  uint32_t n = 0;
+  if (MASKED) {                                  // compare form: a NaN fails every test
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+      const int gid = g0 + ((rr & 3) + 8 * (rr >> 2)) * st;
+      n += ((acc[rr] > bscore) | ((acc[rr] == bscore) & (gid < bid))) ? 1u : 0u;
+    }
+    return n;
+  }
+  // s > bscore  <=>  sign bit of bscore - s; exact ties (the positive itself, or a colliding
+  // score) are rare and settled by id in a branch almost no wave takes
+  uint32_t bits = 0;
+  bool any_eq = false;
 #pragma unroll
   for (int rr = 0; rr < 16; ++rr) {
-    const float s = acc[rr];
-    const int gid = g0 + ((rr & 3) + 8 * (rr >> 2)) * st;
-    t_above += (s > bscore || (s == bscore && gid < bid)) ? 1u : 0u;
-    if (SIGN)
-      count_thr_sign<N>(s, lo, hn, t_lt, t_le);
-    else
-      count_thr<N>(s, lo, hn, t_lt, t_le);
+    bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(bscore - acc[rr]), 31);
+    any_eq |= acc[rr] == bscore;
   }
+  n = __popc(bits);
+  if (any_eq) {
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+      const int gid = g0 + ((rr & 3) + 8 * (rr >> 2)) * st;
+      n += ((acc[rr] == bscore) & (gid < bid)) ? 1u : 0u;
+    }
+  }
+  return n;
 }
 
 // MODE 2 = MODE 0 and MODE 1 in ONE pass over the catalogue (both epilogues on every sub-tile):
@@ -369,6 +410,8 @@ __global__ __launch_bounds__(kBlockDma) void eval_gemm_dma_kernel(const EvalPara
   constexpr int kBufF4 = kTileF4 + kTileItems / 4;  // tile + its 64 item biases
   static_assert(kPerWave >= 1, "embedding_dim >= 32");
   __shared__ float4 smem[2 * kBufF4];            // ONE array: both tiles and both bias vectors
+  // RANK: the search trees of the workgroup's users, [wave][entry][user column]
+  __shared__ uint32_t rank_trees[RANK ? kWavesDma * kTreeWords * 32 : 1];
 
   const int lane = lane_id();
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
@@ -388,7 +431,7 @@ __global__ __launch_bounds__(kBlockDma) void eval_gemm_dma_kernel(const EvalPara
 
   float top_s[kCap];   // TOPK: the sorted candidate list
   int top_i[kCap];
-  float thr_l[kCap], thr_h[kCap];  // RANK: (lo, next_up(hi)) raw-score bounds of the first kCap positives
+  uint32_t* tree = rank_trees + (RANK ? wave * kTreeWords * 32 + col : 0);
   unsigned long long c_above = 0, c_lt = 0, c_le = 0, c_below_all = 0;
   int64_t e_begin = 0, e_end = 0;
   float bscore = 0.0f, lo_min = INFINITY, hi_max = -INFINITY;
@@ -401,41 +444,27 @@ __global__ __launch_bounds__(kBlockDma) void eval_gemm_dma_kernel(const EvalPara
     }
   }
   if (RANK) {
-    // the first kCap (lo, hi) threshold pairs of the user's positives live in registers; unused
-    // slots hold -inf, which no score is below.  The rare user with more positives walks the rest
-    // of its CSR row per score (lo_min / hi_max bound the scores that can differ from "below all" /
-    // "above all" of that remainder).
-#pragma unroll
-    for (int i = 0; i < kCap; ++i) {
-      thr_l[i] = -INFINITY;
-      thr_h[i] = next_up(-INFINITY);
-    }
+    // the first kTreePos positives of the user go into its LDS tree.  The rare user with more
+    // walks the rest of its CSR row per score (lo_min / hi_max bound the scores that can differ
+    // from "below all" / "above all" of that remainder).
     if (user_ok) {
       e_begin = p.indptr[uslot];
       e_end = p.indptr[uslot + 1];
       bscore = p.best_score[uslot];
       bid = static_cast<int>(p.best_id[uslot]);
-#pragma unroll
-      for (int i = 0; i < kCap; ++i) {
-        if (e_begin + i < e_end) {
-          thr_l[i] = p.thr_lo[e_begin + i];
-          thr_h[i] = next_up(p.thr_hi[e_begin + i]);
-        }
-      }
-      for (int64_t e = e_begin + kCap; e < e_end; ++e) {
+      for (int64_t e = e_begin + kTreePos; e < e_end; ++e) {
         lo_min = fminf(lo_min, p.thr_lo[e]);
         hi_max = fmaxf(hi_max, p.thr_hi[e]);
       }
     }
+    if (h == 0) {
+      int n = static_cast<int>(e_end - e_begin);
+      if (n > kTreePos) n = kTreePos;
+      build_rank_tree(tree, p.thr_lo + e_begin, p.thr_hi + e_begin, n);
+    }
+    // read by both lane halves after the first barrier of the tile loop
   }
-  // wave-uniform number of register-resident threshold pairs in use (the rest are skipped)
-  int npos_here = static_cast<int>(e_end - e_begin);
-  if (npos_here > kCap) npos_here = kCap;
-  int n_thr = npos_here;
-#pragma unroll
-  for (int o = kWave / 2; o > 0; o >>= 1) n_thr = max(n_thr, __shfl_xor(n_thr, o, kWave));
-  n_thr = __builtin_amdgcn_readfirstlane(n_thr);
-  const bool any_long = __ballot(e_end - e_begin > kCap) != 0ull;
+  const bool any_long = __ballot(e_end - e_begin > kTreePos) != 0ull;
   const int k = p.k;
   float thr = -INFINITY;  // TOPK: score of the k-th best candidate so far
   const bool has_cut = MODE == 0 && p.cut_s != nullptr;  // uniform (later rounds of k > kCap)
@@ -480,7 +509,7 @@ __global__ __launch_bounds__(kBlockDma) void eval_gemm_dma_kernel(const EvalPara
     const float* tile_bias = reinterpret_cast<const float*>(tile + kTileF4);
     const bool full = base + kTileItems <= chunk_end;
 
-    // RANK keeps one sub-tile live at a time (its epilogue holds 32 threshold registers)
+    // RANK keeps one sub-tile live at a time
 #pragma unroll MODE == 0 ? 2 : 1
     for (int sub = 0; sub < kTileItems / 32; ++sub) {
       f32x16 acc;
@@ -560,34 +589,22 @@ __global__ __launch_bounds__(kBlockDma) void eval_gemm_dma_kernel(const EvalPara
         }
       }
       if (RANK) {
-        // 32-bit counters per sub-tile (at most 16 * kCap increments), folded into the 64-bit ones
-        uint32_t t_above = 0, t_lt = 0, t_le = 0;
-        const int64_t gid0 = (base + sub * 32 + 4 * h) * p.id_stride + p.id_offset;
-#define COLLIE_RANK_TIER(N_)                                                                       \
-  do {                                                                                            \
-    if (full)                                                                                     \
-      rank_subtile<N_, true>(acc, thr_l, thr_h, bscore, bid, gid0, p.id_stride, t_above, t_lt,    \
-                             t_le);                                                               \
-    else                                                                                          \
-      rank_subtile<N_, false>(acc, thr_l, thr_h, bscore, bid, gid0, p.id_stride, t_above, t_lt,   \
-                              t_le);                                                              \
-  } while (0)
-        // tiers of two threshold pairs: the counting is VALU-bound, every unused pair costs
-        if (n_thr <= 8) {
-          if (n_thr <= 4) { if (n_thr <= 2) COLLIE_RANK_TIER(2); else COLLIE_RANK_TIER(4); }
-          else { if (n_thr <= 6) COLLIE_RANK_TIER(6); else COLLIE_RANK_TIER(8); }
-        } else if (n_thr <= 12) {
-          if (n_thr <= 10) COLLIE_RANK_TIER(10); else COLLIE_RANK_TIER(12);
+        // 32-bit counters per sub-tile, folded into the 64-bit ones afterwards
+        uint32_t t_above = 0, t_pair = 0;
+        const int g0 = static_cast<int>((base + sub * 32 + 4 * h) * p.id_stride + p.id_offset);
+        const int st = static_cast<int>(p.id_stride);   // global ids fit 31 bits (entry points)
+        if (full) {
+          t_above = count_above16<false>(acc, bscore, bid, g0, st);
+          t_pair = rank_tree_count16<false>(tree, acc);
         } else {
-          if (n_thr <= 14) COLLIE_RANK_TIER(14); else COLLIE_RANK_TIER(kCap);
+          t_above = count_above16<true>(acc, bscore, bid, g0, st);
+          t_pair = rank_tree_count16<true>(tree, acc);
         }
-#undef COLLIE_RANK_TIER
-        // the sub-tile counts stay 32-bit (without this the compiler accumulates every compare
-        // straight into the 64-bit counters: a v_lshl_add_u64 per compare)
-        asm volatile("" : "+v"(t_above), "+v"(t_lt), "+v"(t_le));
+        // (without this the compiler accumulates straight into the 64-bit counters)
+        asm volatile("" : "+v"(t_above), "+v"(t_pair));
         c_above += t_above;
-        c_lt += t_lt;
-        c_le += t_le;
+        c_lt += t_pair & 0xffffu;
+        c_le += t_pair >> 16;
         if (any_long) {
 #pragma unroll 1
           for (int rr = 0; rr < 16; ++rr) {
@@ -595,7 +612,7 @@ __global__ __launch_bounds__(kBlockDma) void eval_gemm_dma_kernel(const EvalPara
             if (s < lo_min) {
               c_below_all += 1ull;                     // below every remaining positive
             } else if (s <= hi_max) {
-              for (int64_t e = e_begin + kCap; e < e_end; ++e) {
+              for (int64_t e = e_begin + kTreePos; e < e_end; ++e) {
                 c_lt += s < p.thr_lo[e] ? 1ull : 0ull;
                 c_le += s <= p.thr_hi[e] ? 1ull : 0ull;
               }
@@ -619,7 +636,8 @@ __global__ __launch_bounds__(kBlockDma) void eval_gemm_dma_kernel(const EvalPara
   }
   if (RANK) {
     const unsigned long long npos =
-        e_end - e_begin > kCap ? static_cast<unsigned long long>(e_end - e_begin - kCap) : 0ull;
+        e_end - e_begin > kTreePos ? static_cast<unsigned long long>(e_end - e_begin - kTreePos)
+                                   : 0ull;
     atomicAdd(&p.counts[uslot * 3 + 0], c_above);
     atomicAdd(&p.counts[uslot * 3 + 1], c_lt + c_below_all * npos);
     atomicAdd(&p.counts[uslot * 3 + 2], c_le + c_below_all * npos);

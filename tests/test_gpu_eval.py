@@ -175,6 +175,7 @@ def test_topk_ids_exact_on_exactly_representable_scores(dev, D, N, U, k):
     np.testing.assert_array_equal(mi.cpu().numpy(), ref)
     # metrics against the oracle
     nnz_per_user = rng.integers(1, 12, len(users))
+    nnz_per_user[:6] = (14, 15, 16, 17, 31, 40)   # around and beyond the 15 positives of the LDS tree
     rows = np.repeat(users, nnz_per_user)
     cols = np.concatenate([rng.choice(N, n, replace=False) for n in nnz_per_user])
     csr = sp.coo_matrix((np.ones(len(rows)), (rows, cols)), shape=(U, N)).tocsr()
@@ -194,7 +195,7 @@ def test_topk_ids_exact_on_exactly_representable_scores(dev, D, N, U, k):
 def test_fused_topk_and_rank_counts_equal_the_two_passes(dev, D, N, U, k, stride, y_range):
     """collie_mf_eval_topk_rank_counts against collie_mf_eval_topk + collie_mf_eval_rank_counts:
     ids, scores and the three rank counters bit for bit (ragged last tile, users with 0 ... 40
-    positives, i.e. beyond the 16 register-resident threshold pairs)."""
+    positives, i.e. beyond the 15 positives of the per-user LDS search tree)."""
     from oracle import mf_oracle as O
     from collie_amd import ops
     from collie_amd.metrics import _csr_slice
