@@ -17,6 +17,8 @@ stats stats_B65536 $ARGS --batch 65536
 stats stats_B1048576 $ARGS --batch 1048576
 stats stats_c4 $C4
 stats stats_eval --no-cpu-baseline --hybrid-steps 0 --c4-steps 0 --steps 2 --warmup 1 --eval-users 65536
+EVAL="--no-cpu-baseline --hybrid-steps 0 --c4-steps 0 --steps 1 --warmup 1 --eval-users 65536"
+pmc pmc_sq_eval "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_LDS" $EVAL
 pmc pmc_fetch_B1048576 FETCH_SIZE $ARGS --batch 1048576
 pmc pmc_write_B1048576 WRITE_SIZE $ARGS --batch 1048576
 pmc pmc_fetch_c4 FETCH_SIZE $C4
