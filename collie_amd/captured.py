@@ -1,0 +1,242 @@
+"""
+The trainers' loop body -- ``zero_grad`` / ``calculate_loss`` / ``loss.backward()`` /
+``optimizer.step()`` for every optimizer (reference: ``collie/model/base/trainer.py:458-470``) -- as
+ONE replayed HIP graph.
+
+At the reference's default batch size (1,024) a step is ~20 short kernels; issued one by one from
+Python the host is the bottleneck (small-batch section).  ``CapturedTrainStep`` records
+the launches of one step once (``torch.cuda.CUDAGraph`` over the library's own entry points) and
+replays the recording for the following batches.  What changes from step to step is kept out of the
+frozen kernel arguments:
+
+* the batch is copied into the buffers the recording reads;
+* the step id and the optimizers' step-dependent scalars come from a schedule in device memory that
+  the library fills ahead (``collie_mf_train_schedule_steps``: the same host code that computes
+  them by value, so a replayed trajectory is bit-identical to a stepped one);
+* learning-rate changes (schedulers) re-fill the schedule, anything else that a recording froze
+  (table storage, optimizer state tensors, betas / eps, batch shape) makes a new recording.
+
+The optimizers' ``state['step']`` counters, the workspace's step counter and the model's staged-step
+slot are kept exactly as a stepped batch leaves them, so stepped and replayed batches can be mixed.
+"""
+import torch
+
+from collie_amd import _lib, ops
+from collie_amd.optim import _FusedMixin, _step_count
+
+_TABLES = ('user_embeddings', 'item_embeddings', 'user_biases', 'item_biases')
+_SLOTS = ((_lib.SIDE_USER, False), (_lib.SIDE_ITEM, False), (_lib.SIDE_USER, True),
+          (_lib.SIDE_ITEM, True))
+
+
+def _count(opt, p):
+    state = opt.state[p]
+    if '_steps' in state:
+        return int(state['_steps'])
+    return _step_count(state) if 'step' in state else 0
+
+
+def _bump(opt, p):
+    state = opt.state[p]
+    if '_steps' in state:
+        state['_steps'] += 1
+    else:
+        state['step'] += 1
+
+
+class CapturedTrainStep:
+    """``step = CapturedTrainStep(model, optimizers); loss = step(batch)``.
+
+    ``step(batch)`` returns ``None`` when this batch cannot be replayed (the caller then steps it
+    the usual way); otherwise the step has been queued and the returned 0-d tensor is the loss
+    buffer of the recording: read or accumulate it before the next call.
+    """
+
+    def __init__(self, model, optimizers, max_batch=16384):
+        self.model = model
+        self.optimizers = list(optimizers)
+        self.max_batch = max_batch
+        self._graph = None
+        self._graph_key = None
+        self._sched_key = None
+        self._expect = None         # (workspace step id, per-table step counts) after our last replay
+        self._left = 0              # schedule entries not yet replayed
+        self.replays = 0
+        self.captures = 0
+
+    # ------------------------------------------------------------------------------ eligibility
+    def _owners(self):
+        """[(optimizer, group, param) or None] per table, or None if a table's optimizer is not one
+        of the fused classes (or has hooks): then nothing is replayed."""
+        model = self.model
+        weights = model._weights()
+        owners = [None] * 4
+        for opt in self.optimizers:
+            if not isinstance(opt, _FusedMixin) or getattr(opt, '_collie_model', None) is not model:
+                return None
+            if opt._optimizer_step_pre_hooks or opt._optimizer_step_post_hooks:
+                return None
+            for group in opt.param_groups:
+                for p in group['params']:
+                    for i, w in enumerate(weights):
+                        if w is p:
+                            if owners[i] is not None:
+                                return None
+                            owners[i] = (opt, group, p)
+                            break
+                    else:
+                        return None                     # a parameter that is not one of the tables
+        for i, o in enumerate(owners):
+            if o is not None and not o[2].requires_grad:
+                owners[i] = None
+        return owners if any(o is not None for o in owners) else None
+
+    def _batch_ok(self, batch):
+        model = self.model
+        if not (model.training and torch.is_grad_enabled() and model._can_fuse()
+                and model.hparams.sparse):
+            return None
+        try:
+            (users, pos), neg = batch
+        except (TypeError, ValueError):
+            return None
+        if not (torch.is_tensor(users) and torch.is_tensor(pos) and torch.is_tensor(neg)):
+            return None
+        if neg.dim() == 1:
+            neg = neg.reshape(-1, 1)
+        if (users.dim() != 1 or pos.dim() != 1 or neg.dim() != 2 or not users.is_cuda
+                or users.shape[0] == 0 or users.shape[0] > self.max_batch
+                or neg.shape[1] > _lib.MAX_NEG or pos.shape[0] != users.shape[0]
+                or neg.shape[0] != users.shape[0]):
+            return None
+        return users, pos, neg
+
+    # ----------------------------------------------------------------------------------- record
+    def _record(self, users, pos, neg, owners):
+        model = self.model
+        dev = users.device
+        self._u = users.clone()
+        self._p = pos.clone()
+        self._n = neg.contiguous().clone()
+        B, K = self._n.shape
+        ws = model._train_workspace(dev)
+        self._buf = ws.ensure(B, K, model.hparams.embedding_dim, model.hparams.num_users,
+                              model.hparams.num_items)
+        self._tables = model._tables()
+        self._hbatch = ops.make_batch(self._u, self._p, self._n)
+        self._loss = torch.empty(1, dtype=torch.float32, device=dev)
+        # the loss configuration the model itself would use (built by a first ordinary step)
+        cfg = model.__dict__.get('_loss_cfg')
+        status = model._status_flag()
+        per_kind = {False: {}, True: {}}
+        for i, o in enumerate(owners):
+            if o is None:
+                continue
+            opt, group, p = o
+            side, is_bias = _SLOTS[i]
+            per_kind[is_bias][side] = self._table_args(opt, group, p)
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            ops.train_forward(self._tables, self._hbatch, cfg, self._buf, True, ops.STEP_DEVICE,
+                              self._loss, None, None, status)
+            ops.train_build_segments(self._tables, self._hbatch, self._buf)
+            for is_bias in (False, True):
+                if per_kind[is_bias]:
+                    ops.train_update(self._tables, self._hbatch, self._buf, 1 if is_bias else 0,
+                                     False, ops.STEP_DEVICE, per_kind[is_bias], None)
+            ops.train_advance_step(self._tables, self._hbatch, self._buf)
+        self._graph = graph
+        self._keep = per_kind
+        self.captures += 1
+
+    @staticmethod
+    def _table_args(opt, group, p):
+        """(cfg, state1, state2, row_stamp) WITHOUT counting a step (``_table_args`` of the fused
+        optimizers creates missing state and counts one)."""
+        before = _count(opt, p)
+        args = opt._table_args(opt._collie_model, p, group, False)
+        state = opt.state[p]
+        if '_steps' in state:
+            state['_steps'] = before
+        elif torch.is_tensor(state['step']):
+            state['step'].fill_(before)
+        else:
+            state['step'] = before
+        return args
+
+    def _keys(self, users, pos, neg, owners):
+        model = self.model
+        ws = model._train_workspace(users.device)
+        graph_key = [users.shape[0], neg.shape[1], users.dtype, pos.dtype, neg.dtype,
+                     tuple(w.data_ptr() for w in model._weights()),
+                     id(model.__dict__.get('_loss_cfg')), None if ws.buf is None else ws.buf.data_ptr()]
+        sched_key = []
+        for o in owners:
+            if o is None:
+                graph_key.append(None)
+                sched_key.append(None)
+                continue
+            opt, group, p = o
+            state = opt.state[p]
+            graph_key.append((id(opt), tuple(group.get('betas', ())), group.get('eps'),
+                              group.get('weight_decay'),
+                              tuple(v.data_ptr() for k, v in sorted(state.items())
+                                    if torch.is_tensor(v) and v.is_cuda)))
+            sched_key.append((group['lr'], group.get('lr_decay')))
+        return tuple(graph_key), tuple(sched_key)
+
+    def _schedule(self, owners):
+        model = self.model
+        ws = model._workspace
+        cfgs = []
+        for o in owners:
+            if o is None:
+                cfgs.append(None)
+                continue
+            opt, group, p = o
+            cfg = self._table_args(opt, group, p)[0]
+            cfg.step = _count(opt, p) + 1
+            cfgs.append(cfg)
+        n = ops.STEP_SCHEDULE_MAX
+        ops.train_schedule_steps(self._tables, self._hbatch, self._buf, ws.step_id + 1, n, cfgs)
+        self._left = n
+
+    # ----------------------------------------------------------------------------------- replay
+    def __call__(self, batch):
+        parts = self._batch_ok(batch)
+        if parts is None:
+            return None
+        owners = self._owners()
+        if owners is None:
+            return None
+        users, pos, neg = parts
+        model = self.model
+        if model.__dict__.get('_loss_cfg') is None or model._workspace is None:
+            return None                 # the first step of a model is an ordinary one
+        graph_key, sched_key = self._keys(users, pos, neg, owners)
+        if graph_key != self._graph_key:
+            if self._graph_key is not None and graph_key[:5] != self._graph_key[:5] and \
+                    users.shape[0] < self._graph_key[0]:
+                return None             # the ragged last batch of an epoch: stepped, not recorded
+            self._record(users, pos, neg, owners)
+            self._graph_key = self._keys(users, pos, neg, owners)[0]
+            self._sched_key = None
+        ws = model._workspace
+        now = (ws.step_id, tuple(None if o is None else _count(o[0], o[2]) for o in owners))
+        if sched_key != self._sched_key or self._left == 0 or now != self._expect:
+            self._schedule(owners)
+            self._sched_key = sched_key
+        self._u.copy_(users)
+        self._p.copy_(pos)
+        self._n.copy_(neg)
+        model.__dict__['_staged_step'] = None       # the workspace is overwritten
+        self._graph.replay()
+        self._left -= 1
+        ws.next_step()
+        for o in owners:
+            if o is not None:
+                _bump(o[0], o[2])
+        self._expect = (ws.step_id, tuple(None if o is None else _count(o[0], o[2]) for o in owners))
+        self.replays += 1
+        return self._loss.reshape(())

@@ -71,6 +71,7 @@ struct FwdParams {
   int32_t* status;
   int need_grad;
   int step_id;
+  const StepDyn* dyn;  // captured-step replay: the tag comes from device memory (train_ws.h)
   int nchunks;  // ceil(dim / VEC)
   float inv_b;
 };
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(kBlock) void mf_train_fwd_kernel(const FwdParams p)
     const bool live = g != 0.0f;
     const int sel_item = __shfl(item, sel, kWave);
     const int pos_item_b = __shfl(item, 0, kWave);
-    if (lane <= K) p.ws.touch_item[item] = touch_tag(p.step_id);
+    if (lane <= K) p.ws.touch_item[item] = p.dyn ? p.dyn->tag : touch_tag(p.step_id);
     if (lane < 3) {  // lane 0: user entry, lane 1: positive item, lane 2: selected negative
       const int64_t slot = lane == 0 ? b : B + 2 * b + (lane - 1);
       const uint32_t key =
@@ -532,7 +533,8 @@ __global__ __launch_bounds__(kBlock) void mf_train_fwd_fast(const FwdParams p) {
     }
 #pragma unroll
     for (int pass = 0; pass < NPASS; ++pass)
-      if (lig == 0 && pass * RPW + grp <= K) p.ws.touch_item[item[pass]] = touch_tag(p.step_id);
+      if (lig == 0 && pass * RPW + grp <= K)
+        p.ws.touch_item[item[pass]] = p.dyn ? p.dyn->tag : touch_tag(p.step_id);
     if (lane < 3) {  // lane 0: user entry, lane 1: positive item, lane 2: selected negative
       const int64_t slot = lane == 0 ? b : B + 2 * b + (lane - 1);
       const uint32_t key =
@@ -617,6 +619,7 @@ struct LdsParams {
   float* loss_partials;
   int32_t* status;
   int32_t step_id, need_grad;
+  const StepDyn* dyn;       // captured-step replay (train_ws.h), else NULL
   float inv_b, warp_items;  // warp_items = float(loss.num_items)
   const int32_t* meta[COLLIE_MAX_META];
   float meta_weight[COLLIE_MAX_META];
@@ -691,7 +694,7 @@ __global__ __launch_bounds__(kBlock, (CH * NP <= 4 ? 8 : 4)) void mf_train_fwd_l
   const int D = p.dim;
   const int64_t B = p.batch;
   const uint32_t key_off = static_cast<uint32_t>(p.num_users);
-  const int tag = touch_tag(p.step_id);
+  const int tag = p.dyn ? p.dyn->tag : touch_tag(p.step_id);
   float4* const items_l = &park[wave_in_block][0];
   float4* const user_l = &park[wave_in_block][kItemF4];
   bool row_lane[NP], neg_lane[NP];
@@ -1059,6 +1062,7 @@ int launch_fwd_lds(int lpr, int ch, int np, dim3 grid, hipStream_t stream, const
   q.loss_partials = p.ws.loss_partials;
   q.status = p.status;
   q.step_id = p.step_id;
+  q.dyn = p.dyn;
   q.need_grad = p.need_grad;
   q.inv_b = p.inv_b;
   q.warp_items = static_cast<float>(p.loss.num_items);
@@ -1152,12 +1156,15 @@ extern "C" int collie_mf_train_forward(const collie_mf_tables* t, const collie_m
     COLLIE_REQUIRE(b->num_neg == 1, "non-adaptive losses need exactly one negative per sample");
   if (loss->kind == COLLIE_LOSS_WARP)
     COLLIE_REQUIRE(b->num_neg > 1, "Cannot use WARP loss with a single negative sample!");
-  COLLIE_REQUIRE(step_id >= 1, "step_id must be >= 1 (got %d)", step_id);
+  const bool from_device = step_id == COLLIE_STEP_DEVICE;
+  COLLIE_REQUIRE(step_id >= 1 || from_device, "step_id must be >= 1 (got %d)", step_id);
+  COLLIE_REQUIRE(!from_device || need_grad, "COLLIE_STEP_DEVICE is for steps with need_grad");
   TrainWs ws = carve_train_ws(workspace, b->batch, b->num_neg, t->dim, t->num_users, t->num_items);
   COLLIE_REQUIRE(workspace != nullptr && workspace_bytes >= ws.bytes,
                  "workspace too small: need %zu bytes, got %zu", ws.bytes, workspace_bytes);
   // the 8-bit stamp tags start a new cycle: forget the previous cycle's stamps (train_ws.h)
-  if (need_grad && step_id % kTouchCycle == 0)
+  // (a replayed step: collie_mf_train_advance_step does it on the device)
+  if (need_grad && !from_device && step_id % kTouchCycle == 0)
     COLLIE_CHECK_HIP(hipMemsetAsync(ws.touch_item, 0, static_cast<size_t>(t->num_items), stream));
 
   FwdParams p;
@@ -1170,6 +1177,7 @@ extern "C" int collie_mf_train_forward(const collie_mf_tables* t, const collie_m
   p.status = status;
   p.need_grad = need_grad;
   p.step_id = step_id;
+  p.dyn = from_device ? ws.dyn_cur : nullptr;
   p.inv_b = 1.0f / static_cast<float>(b->batch);
   const int vec = pick_vec(t);
   p.nchunks = (t->dim + vec - 1) / vec;

@@ -11,6 +11,8 @@
 // and moves the parameter exactly as torch does after coalesce().
 //
 // Compiled with -ffp-contract=off so that every rounding step of the torch formulas is kept.
+#include <vector>
+
 #include "rowsort.h"
 
 namespace collie {
@@ -65,6 +67,15 @@ __device__ __forceinline__ float apply_update(const Hyper& h, float p, float g, 
   }
 }
 
+// captured-step replay: the step-dependent scalars come from device memory (train_ws.h)
+__device__ __forceinline__ Hyper dyn_hyper(Hyper h, const StepDyn* dyn, int idx) {
+  if (dyn) {
+    h.neg_lr = dyn->neg_lr[idx];
+    h.bc2_sqrt = dyn->bc2_sqrt[idx];
+  }
+  return h;
+}
+
 struct TableDesc {
   float* table;        // [rows, D] (D = 1 for a bias table); NULL = not owned by this call
   float* s1;
@@ -93,6 +104,8 @@ struct UpdParams {
   int export_side;
   int D;
   int step;
+  const StepDyn* dyn;  // non-NULL: step and the step-dependent Hyper fields are read from here
+  int dyn_base;        // 2 * is_bias: index of d[0]'s table in StepDyn
 };
 
 template <int VEC>
@@ -213,6 +226,8 @@ __global__ __launch_bounds__(kBlock) void emb_rows_kernel(const UpdParams p) {
   const uint32_t nseg = p.nseg[0];
   const uint32_t first1 = p.nseg[1];
   const float scale = p.grad_scale ? *p.grad_scale : 1.0f;
+  const Hyper h0 = dyn_hyper(p.d[0].h, p.dyn, p.dyn_base), h1 = dyn_hyper(p.d[1].h, p.dyn, p.dyn_base + 1);
+  const int step = p.dyn ? p.dyn->step : p.step;
   const int D = p.D;
   const int nchunks = (D + VEC - 1) / VEC;
   const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
@@ -307,7 +322,8 @@ __global__ __launch_bounds__(kBlock) void emb_rows_kernel(const UpdParams p) {
         } else {
           RVec<VEC> np;
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) np.v[i] = apply_update(t.h, pv.v[i], g.v[i], s1.v[i], s2.v[i]);
+          for (int i = 0; i < VEC; ++i)
+            np.v[i] = apply_update(side ? h1 : h0, pv.v[i], g.v[i], s1.v[i], s2.v[i]);
           rstore<VEC>(t.table + off, np);
           if (t.s1) rstore<VEC>(t.s1 + off, s1);
           if (t.s2) rstore<VEC>(t.s2 + off, s2);
@@ -315,8 +331,8 @@ __global__ __launch_bounds__(kBlock) void emb_rows_kernel(const UpdParams p) {
       }
     }
     if (!EXPORT && active && lig == 0) {
-      if (t.row_stamp) t.row_stamp[row] = p.step;
-      if (t.seg_stamp) t.seg_stamp[row] = p.step;
+      if (t.row_stamp) t.row_stamp[row] = step;
+      if (t.seg_stamp) t.seg_stamp[row] = step;
     }
   }
 }
@@ -335,6 +351,8 @@ __global__ __launch_bounds__(kBlock) void bias_rows_kernel(const UpdParams p) {
   const uint32_t nseg = p.nseg[0];
   const uint32_t first1 = p.nseg[1];
   const float scale = p.grad_scale ? *p.grad_scale : 1.0f;
+  const Hyper h0 = dyn_hyper(p.d[0].h, p.dyn, p.dyn_base), h1 = dyn_hyper(p.d[1].h, p.dyn, p.dyn_base + 1);
+  const int step = p.dyn ? p.dyn->step : p.step;
   const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
   if (EXPORT && blockIdx.x == 0 && threadIdx.x == 0)
     *p.count_out = static_cast<int32_t>(p.export_side ? nseg - first1 : first1);
@@ -378,11 +396,11 @@ __global__ __launch_bounds__(kBlock) void bias_rows_kernel(const UpdParams p) {
       } else {
         float s1 = t.s1 ? t.s1[row] : 0.0f;
         float s2 = t.s2 ? t.s2[row] : 0.0f;
-        t.table[row] = apply_update(t.h, t.table[row], g, s1, s2);
+        t.table[row] = apply_update(side ? h1 : h0, t.table[row], g, s1, s2);
         if (t.s1) t.s1[row] = s1;
         if (t.s2) t.s2[row] = s2;
-        if (t.row_stamp) t.row_stamp[row] = p.step;
-        if (t.seg_stamp) t.seg_stamp[row] = p.step;
+        if (t.row_stamp) t.row_stamp[row] = step;
+        if (t.seg_stamp) t.seg_stamp[row] = step;
       }
     }
   }
@@ -394,8 +412,11 @@ __global__ __launch_bounds__(kBlock) void dense_sweep_kernel(float* __restrict__
                                                              float* __restrict__ s1p,
                                                              float* __restrict__ s2p,
                                                              const int32_t* __restrict__ stamp,
-                                                             int64_t rows, int D, int step,
-                                                             const Hyper h) {
+                                                             int64_t rows, int D, int step_,
+                                                             const Hyper h_, const StepDyn* dyn,
+                                                             int dyn_idx) {
+  const Hyper h = dyn_hyper(h_, dyn, dyn_idx);
+  const int step = dyn ? dyn->step : step_;
   const int64_t total = rows * D;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < total;
@@ -417,8 +438,11 @@ __global__ __launch_bounds__(kBlock) void touched_sweep_kernel(float* __restrict
                                                                float* __restrict__ s2p,
                                                                const uint8_t* __restrict__ touch,
                                                                const int32_t* __restrict__ seg,
-                                                               int64_t rows, int D, int step,
-                                                               const Hyper h) {
+                                                               int64_t rows, int D, int step_,
+                                                               const Hyper h_, const StepDyn* dyn,
+                                                               int dyn_idx) {
+  const Hyper h = dyn_hyper(h_, dyn, dyn_idx);
+  const int step = dyn ? dyn->step : step_;
   const int64_t total = rows * D;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < total;
@@ -443,8 +467,11 @@ __global__ __launch_bounds__(kBlock) void touched_rows_kernel(float* __restrict_
                                                               float* __restrict__ s2p,
                                                               const uint8_t* __restrict__ touch,
                                                               const int32_t* __restrict__ seg,
-                                                              int64_t rows, int D, int step,
-                                                              const Hyper h) {
+                                                              int64_t rows, int D, int step_,
+                                                              const Hyper h_, const StepDyn* dyn,
+                                                              int dyn_idx) {
+  const Hyper h = dyn_hyper(h_, dyn, dyn_idx);
+  const int step = dyn ? dyn->step : step_;
   constexpr int GPW = kWave / LPR;
   __shared__ int list[kWavesPerBlock][kWave];
   const int lane = lane_id();
@@ -533,6 +560,33 @@ int validate_batch(const collie_mf_batch* b);
 
 namespace {
 
+// the two Hyper fields that depend on the step count (also what a step schedule holds)
+void step_scalars(const collie_optim_cfg* cfg, float& neg_lr, float& bc2_sqrt) {
+  const double lr = cfg->lr;
+  bc2_sqrt = 1.0f;
+  switch (cfg->algo) {
+    case COLLIE_OPT_ADAGRAD:
+      neg_lr = static_cast<float>(
+          -(lr / (1.0 + (cfg->step - 1) * static_cast<double>(cfg->lr_decay))));
+      break;
+    case COLLIE_OPT_SPARSE_ADAM: {
+      const double bc1 = 1.0 - pow(static_cast<double>(cfg->beta1), cfg->step);
+      const double bc2 = 1.0 - pow(static_cast<double>(cfg->beta2), cfg->step);
+      neg_lr = static_cast<float>(-(lr * sqrt(bc2) / bc1));
+      break;
+    }
+    case COLLIE_OPT_ADAM: {
+      const double bc1 = 1.0 - pow(static_cast<double>(cfg->beta1), cfg->step);
+      const double bc2 = 1.0 - pow(static_cast<double>(cfg->beta2), cfg->step);
+      neg_lr = static_cast<float>(-(lr / bc1));
+      bc2_sqrt = static_cast<float>(sqrt(bc2));
+      break;
+    }
+    default:  // COLLIE_OPT_SGD
+      neg_lr = static_cast<float>(-lr);
+  }
+}
+
 int make_hyper(Hyper& h, const collie_optim_cfg* cfg, int dense, bool need_s1, float* s1,
                float* s2) {
   COLLIE_REQUIRE(cfg->step >= 1, "optimizer step must be >= 1 (got %d)", cfg->step);
@@ -543,40 +597,27 @@ int make_hyper(Hyper& h, const collie_optim_cfg* cfg, int dense, bool need_s1, f
   h.beta2 = cfg->beta2;
   h.c1 = static_cast<float>(1.0 - static_cast<double>(cfg->beta1));
   h.c2 = static_cast<float>(1.0 - static_cast<double>(cfg->beta2));
-  h.bc2_sqrt = 1.0f;
-  const double lr = cfg->lr;
   (void)need_s1;
   switch (cfg->algo) {
     case COLLIE_OPT_SGD:
-      h.neg_lr = static_cast<float>(-lr);
       break;
     case COLLIE_OPT_ADAGRAD:
       COLLIE_REQUIRE(s1 != nullptr, "Adagrad needs state1 = state_sum");
-      h.neg_lr = static_cast<float>(
-          -(lr / (1.0 + (cfg->step - 1) * static_cast<double>(cfg->lr_decay))));
       break;
-    case COLLIE_OPT_SPARSE_ADAM: {
+    case COLLIE_OPT_SPARSE_ADAM:
       COLLIE_REQUIRE(!dense,
                      "SparseAdam does not support dense gradients, please consider Adam instead");
       COLLIE_REQUIRE(s1 && s2, "SparseAdam needs state1 = exp_avg, state2 = exp_avg_sq");
-      const double bc1 = 1.0 - pow(static_cast<double>(cfg->beta1), cfg->step);
-      const double bc2 = 1.0 - pow(static_cast<double>(cfg->beta2), cfg->step);
-      h.neg_lr = static_cast<float>(-(lr * sqrt(bc2) / bc1));
       break;
-    }
-    case COLLIE_OPT_ADAM: {
+    case COLLIE_OPT_ADAM:
       COLLIE_REQUIRE(dense,
                      "Adam does not support sparse gradients, please consider SparseAdam instead");
       COLLIE_REQUIRE(s1 && s2, "Adam needs state1 = exp_avg, state2 = exp_avg_sq");
-      const double bc1 = 1.0 - pow(static_cast<double>(cfg->beta1), cfg->step);
-      const double bc2 = 1.0 - pow(static_cast<double>(cfg->beta2), cfg->step);
-      h.neg_lr = static_cast<float>(-(lr / bc1));
-      h.bc2_sqrt = static_cast<float>(sqrt(bc2));
       break;
-    }
     default:
       COLLIE_REQUIRE(false, "%d is not a valid optimizer!", cfg->algo);
   }
+  step_scalars(cfg, h.neg_lr, h.bc2_sqrt);
   if (!dense)
     COLLIE_REQUIRE(cfg->weight_decay == 0.0f,
                    "weight_decay option is not compatible with sparse gradients");
@@ -709,7 +750,13 @@ extern "C" int collie_mf_train_update(const collie_mf_tables* t, const collie_mf
   memset(&p, 0, sizeof(p));
   fill_sorted(p, ws.sort, t->num_users + t->num_items, static_cast<uint32_t>(t->num_users));
   p.grad_scale = grad_scale;
+  // a replayed step: the step id and the step-dependent scalars of cfg come from the schedule in
+  // the workspace (cfg[].step is ignored; every other field of cfg is read now, as usual)
+  const bool from_device = step_id == COLLIE_STEP_DEVICE;
+  COLLIE_REQUIRE(step_id >= 1 || from_device, "step_id must be >= 1 (got %d)", step_id);
   p.step = step_id;
+  p.dyn = from_device ? ws.dyn_cur : nullptr;
+  p.dyn_base = is_bias ? 2 : 0;
   p.D = is_bias ? 1 : t->dim;
   bool sweep[2] = {false, false}, touched[2] = {false, false};
   for (int side = 0; side < 2; ++side) {
@@ -727,7 +774,9 @@ extern "C" int collie_mf_train_update(const collie_mf_tables* t, const collie_mf
     d.s2 = (cfg[side].algo == COLLIE_OPT_SPARSE_ADAM || cfg[side].algo == COLLIE_OPT_ADAM)
                ? state2[side]
                : nullptr;
-    if (make_hyper(d.h, &cfg[side], dense, true, d.s1, d.s2)) return -1;
+    collie_optim_cfg c = cfg[side];
+    if (from_device) c.step = 1;
+    if (make_hyper(d.h, &c, dense, true, d.s1, d.s2)) return -1;
     // dense algorithms whose zero-gradient update is not the identity sweep the other rows
     sweep[side] = dense && (cfg[side].algo == COLLIE_OPT_ADAM || cfg[side].weight_decay != 0.0f);
     if (sweep[side]) {
@@ -753,7 +802,8 @@ extern "C" int collie_mf_train_update(const collie_mf_tables* t, const collie_mf
     const int64_t rows = side == COLLIE_SIDE_USER ? t->num_users : t->num_items;
     if (sweep[side]) {
       hipLaunchKernelGGL(dense_sweep_kernel, dim3(sweep_grid(rows * p.D)), dim3(kBlock), 0, stream,
-                         d.table, d.s1, d.s2, d.row_stamp, rows, p.D, p.step, d.h);
+                         d.table, d.s1, d.s2, d.row_stamp, rows, p.D, p.step, d.h, p.dyn,
+                         p.dyn_base + side);
       if (check_launch("dense_sweep_kernel")) return -2;
     }
     if (touched[side]) {
@@ -764,22 +814,121 @@ extern "C" int collie_mf_train_update(const collie_mf_tables* t, const collie_mf
         const unsigned grid = sweep_grid(rows * 4);
         if (nchunks <= 16)
           hipLaunchKernelGGL(touched_rows_kernel<4>, dim3(grid), dim3(kBlock), 0, stream, d.table,
-                             d.s1, d.s2, ws.touch_item, ws.seg_item, rows, p.D, p.step, d.h);
+                             d.s1, d.s2, ws.touch_item, ws.seg_item, rows, p.D, p.step, d.h, p.dyn,
+                             p.dyn_base + side);
         else if (nchunks <= 32)
           hipLaunchKernelGGL(touched_rows_kernel<8>, dim3(grid), dim3(kBlock), 0, stream, d.table,
-                             d.s1, d.s2, ws.touch_item, ws.seg_item, rows, p.D, p.step, d.h);
+                             d.s1, d.s2, ws.touch_item, ws.seg_item, rows, p.D, p.step, d.h, p.dyn,
+                             p.dyn_base + side);
         else
           hipLaunchKernelGGL(touched_rows_kernel<16>, dim3(grid), dim3(kBlock), 0, stream, d.table,
-                             d.s1, d.s2, ws.touch_item, ws.seg_item, rows, p.D, p.step, d.h);
+                             d.s1, d.s2, ws.touch_item, ws.seg_item, rows, p.D, p.step, d.h, p.dyn,
+                             p.dyn_base + side);
       } else {
         hipLaunchKernelGGL(touched_sweep_kernel, dim3(sweep_grid(rows * p.D)), dim3(kBlock), 0,
                            stream, d.table, d.s1, d.s2, ws.touch_item, ws.seg_item, rows, p.D,
-                           p.step, d.h);
+                           p.step, d.h, p.dyn, p.dyn_base + side);
       }
       if (check_launch("touched_sweep_kernel")) return -2;
     }
   }
   return 0;
+}
+
+// ---- captured-step replay --------------------------------------------------------------------------
+namespace collie {
+namespace {
+
+__global__ void dyn_reset_kernel(DynCtl* ctl, StepDyn* cur, const StepDyn* sched, int n) {
+  ctl->cursor = 0;
+  ctl->n = n;
+  ctl->overrun = 0;
+  *cur = sched[0];
+}
+
+// last node of a captured step: move `cur` to the next schedule entry and, when that step starts a
+// new cycle of stamp tags, clear the stamps (what the forward entry point does from the host for a
+// step id it is given by value).  One workgroup: the clear runs once in 255 steps.
+__global__ __launch_bounds__(1024) void dyn_advance_kernel(DynCtl* ctl, StepDyn* cur,
+                                                           const StepDyn* sched,
+                                                           uint8_t* touch_item, int64_t num_items) {
+  __shared__ StepDyn next;
+  __shared__ int next_at;
+  if (threadIdx.x == 0) {
+    int c = ctl->cursor + 1;
+    if (c >= ctl->n) {
+      c = ctl->n - 1;
+      ctl->overrun = 1;
+    }
+    next_at = c;
+    next = sched[c];
+  }
+  __syncthreads();
+  if (next.tag == touch_tag(0)) {
+    const int64_t words = num_items / 16;
+    uint4* w = reinterpret_cast<uint4*>(touch_item);       // Carver blocks are 256-byte aligned
+    for (int64_t i = threadIdx.x; i < words; i += blockDim.x) w[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (int64_t i = words * 16 + threadIdx.x; i < num_items; i += blockDim.x) touch_item[i] = 0;
+  }
+  if (threadIdx.x == 0) {
+    ctl->cursor = next_at;
+    *cur = next;
+  }
+}
+
+}  // namespace
+}  // namespace collie
+
+extern "C" int collie_mf_train_schedule_steps(const collie_mf_tables* t, const collie_mf_batch* b,
+                                              void* workspace, size_t workspace_bytes,
+                                              int32_t first_step_id, int32_t n_steps,
+                                              const collie_optim_cfg* cfg, collie_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (validate_tables(t) || validate_batch(b)) return -1;
+  COLLIE_REQUIRE(cfg != nullptr, "schedule_steps: cfg is NULL");
+  COLLIE_REQUIRE(first_step_id >= 1, "first_step_id must be >= 1 (got %d)", first_step_id);
+  COLLIE_REQUIRE(n_steps >= 1 && n_steps <= kSchedLen, "n_steps must be in [1, %d] (got %d)",
+                 kSchedLen, n_steps);
+  TrainWs ws = carve_train_ws(workspace, b->batch, b->num_neg, t->dim, t->num_users, t->num_items);
+  COLLIE_REQUIRE(workspace != nullptr && workspace_bytes >= ws.bytes,
+                 "workspace too small: need %zu bytes, got %zu", ws.bytes, workspace_bytes);
+  std::vector<StepDyn> host(static_cast<size_t>(n_steps));
+  for (int s = 0; s < n_steps; ++s) {
+    StepDyn& e = host[static_cast<size_t>(s)];
+    memset(&e, 0, sizeof(e));
+    e.step = first_step_id + s;
+    e.tag = touch_tag(e.step);
+    for (int i = 0; i < 4; ++i) {
+      e.bc2_sqrt[i] = 1.0f;
+      if (cfg[i].algo < 0) continue;                // table not updated by the captured step
+      COLLIE_REQUIRE(cfg[i].algo <= COLLIE_OPT_ADAM, "%d is not a valid optimizer!", cfg[i].algo);
+      COLLIE_REQUIRE(cfg[i].step >= 1, "optimizer step must be >= 1 (got %d)", cfg[i].step);
+      collie_optim_cfg c = cfg[i];
+      c.step = cfg[i].step + s;
+      step_scalars(&c, e.neg_lr[i], e.bc2_sqrt[i]);
+    }
+  }
+  // blocks the host until the copy is done (`host` is pageable and dies with this call)
+  COLLIE_CHECK_HIP(hipMemcpyWithStream(ws.dyn_sched, host.data(), host.size() * sizeof(StepDyn),
+                                       hipMemcpyHostToDevice, stream));
+  if (first_step_id % kTouchCycle == 0)
+    COLLIE_CHECK_HIP(hipMemsetAsync(ws.touch_item, 0, static_cast<size_t>(t->num_items), stream));
+  hipLaunchKernelGGL(dyn_reset_kernel, dim3(1), dim3(1), 0, stream, ws.dyn_ctl, ws.dyn_cur,
+                     ws.dyn_sched, n_steps);
+  return check_launch("dyn_reset_kernel");
+}
+
+extern "C" int collie_mf_train_advance_step(const collie_mf_tables* t, const collie_mf_batch* b,
+                                            void* workspace, size_t workspace_bytes,
+                                            collie_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (validate_tables(t) || validate_batch(b)) return -1;
+  TrainWs ws = carve_train_ws(workspace, b->batch, b->num_neg, t->dim, t->num_users, t->num_items);
+  COLLIE_REQUIRE(workspace != nullptr && workspace_bytes >= ws.bytes,
+                 "workspace too small: need %zu bytes, got %zu", ws.bytes, workspace_bytes);
+  hipLaunchKernelGGL(dyn_advance_kernel, dim3(1), dim3(1024), 0, stream, ws.dyn_ctl, ws.dyn_cur,
+                     ws.dyn_sched, ws.touch_item, t->num_items);
+  return check_launch("dyn_advance_kernel");
 }
 
 extern "C" int collie_mf_train_export_grad(const collie_mf_tables* t, const collie_mf_batch* b,
@@ -1026,7 +1175,7 @@ extern "C" int collie_dense_rows_update(float* table, int64_t num_rows, int32_t 
   }
   if (sweep) {
     hipLaunchKernelGGL(dense_sweep_kernel, dim3(sweep_grid(num_rows * dim)), dim3(kBlock), 0, stream,
-                       d.table, d.s1, d.s2, d.row_stamp, num_rows, dim, p.step, d.h);
+                       d.table, d.s1, d.s2, d.row_stamp, num_rows, dim, p.step, d.h, nullptr, 0);
     if (check_launch("dense_sweep_kernel")) return -2;
   }
   return 0;

@@ -50,6 +50,27 @@ __host__ __device__ inline uint8_t touch_tag(int step) {
   return static_cast<uint8_t>(step % kTouchCycle + 1);
 }
 
+// Captured-step replay (collie_mf_train_schedule_steps / collie_mf_train_advance_step): the kernel
+// arguments that change from one step to the next -- the step id, its stamp tag and the optimizers'
+// step-dependent scalars -- also exist in device memory, so that a HIP graph of the step, whose
+// kernel arguments are frozen at capture, can be replayed for the following steps.  The host fills a
+// schedule of the next kSchedLen steps (with the very code that computes the by-value arguments:
+// the replayed trajectory is bit-identical); the graph's last node moves `cur` one entry on.
+constexpr int kSchedLen = 1024;
+constexpr int kDynUserEmb = 0, kDynItemEmb = 1, kDynUserBias = 2, kDynItemBias = 3;
+struct StepDyn {
+  int32_t step;         // step_id of collie_mf_train_forward / _update
+  int32_t tag;          // touch_tag(step)
+  float neg_lr[4];      // Hyper::neg_lr per table, index = 2 * is_bias + side
+  float bc2_sqrt[4];    // Hyper::bc2_sqrt
+  int32_t pad[2];
+};
+struct DynCtl {
+  int32_t cursor;       // schedule entry `cur` holds
+  int32_t n;            // entries in the schedule
+  int32_t overrun;      // set if a step was replayed past the end of the schedule
+};
+
 constexpr int kPieceLen = 256;
 constexpr uint32_t kNoPiece = 0xffffffffu;
 // every piece but the last of a segment is full, and only segments longer than one piece have any
@@ -101,6 +122,9 @@ struct TrainWs {
   SortWs sort;
   uint8_t* touch_item;   // [num_items] touch_tag(step) of the last forward that looked the item up
   int32_t* seg_item;     // [num_items] step id of the last update in which the item had a segment
+  DynCtl* dyn_ctl;       // captured-step replay: see StepDyn
+  StepDyn* dyn_cur;      // [1] the scalars of the step being replayed
+  StepDyn* dyn_sched;    // [kSchedLen]
   size_t bytes;
 };
 
@@ -113,6 +137,9 @@ inline TrainWs carve_train_ws(void* base, int64_t B, int K, int D, int64_t num_u
   // persistent part first: its offsets must not move when the batch size changes
   w.touch_item = c.take<uint8_t>(num_items);
   w.seg_item = c.take<int32_t>(num_items);
+  w.dyn_ctl = c.take<DynCtl>(1);
+  w.dyn_cur = c.take<StepDyn>(1);
+  w.dyn_sched = c.take<StepDyn>(kSchedLen);
   w.stage_u = c.take<float>(static_cast<size_t>(B) * D);
   w.stage_i = c.take<float>(static_cast<size_t>(B) * D);
   w.gcoef = c.take<float>(B);

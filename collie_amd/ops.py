@@ -143,6 +143,30 @@ def train_update(tables, batch, ws_buf, is_bias, dense, step_id, per_side, grad_
         ptr(grad_scale), stream_ptr()), 'collie_mf_train_update')
 
 
+STEP_DEVICE = -1           # COLLIE_STEP_DEVICE
+STEP_SCHEDULE_MAX = 1024   # COLLIE_STEP_SCHEDULE_MAX
+
+
+def train_schedule_steps(tables, batch, ws_buf, first_step_id, n_steps, cfgs):
+    """cfgs: four OptimCfg (user_emb, item_emb, user_bias, item_bias; ``None`` = not updated) as
+    they stand at the first scheduled step (``collie_mf_train_schedule_steps``)."""
+    arr = (OptimCfg * 4)()
+    for i, c in enumerate(cfgs):
+        if c is None:
+            arr[i].algo = -1
+        else:
+            arr[i] = c
+    check(load().collie_mf_train_schedule_steps(
+        byref(tables), byref(batch), ptr(ws_buf), ws_buf.numel(), int(first_step_id), int(n_steps),
+        arr, stream_ptr()), 'collie_mf_train_schedule_steps')
+
+
+def train_advance_step(tables, batch, ws_buf):
+    check(load().collie_mf_train_advance_step(
+        byref(tables), byref(batch), ptr(ws_buf), ws_buf.numel(), stream_ptr()),
+        'collie_mf_train_advance_step')
+
+
 def train_export_grad(tables, batch, ws_buf, side, is_bias, step_id):
     """
     Coalesced gradient of one table as torch's ``grad.coalesce()`` would hold it: (rows int64 [n],

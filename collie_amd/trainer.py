@@ -129,6 +129,10 @@ class CollieMinimalTrainer():
         self.progress_bar_refresh_rate = progress_bar_refresh_rate
         self.verbosity = (2 if verbosity else 0) if isinstance(verbosity, bool) else verbosity
 
+        # small batches are launch-bound: replay their step as one HIP graph (collie_amd/captured.py)
+        self.capture_small_batches = True
+        self._captured = None
+
         self.best_epoch_loss = (0, sys.maxsize)       # (epoch, loss) of the best epoch so far
         self.train_steps = 0
         self.val_steps = 0
@@ -233,6 +237,7 @@ class CollieMinimalTrainer():
         if not isinstance(configured, list):
             raise ValueError('Unexpected output from ``model.configure_optimizers()``!')
         self.optimizer = MultiOptimizer(configured)
+        self._captured = None                 # recordings belong to one set of optimizers
         self.lr_scheduler = MultiLRScheduler(schedulers) if schedulers is not None else None
 
     # ------------------------------------------------------------------------------ epoch loops
@@ -244,15 +249,19 @@ class CollieMinimalTrainer():
         check_anomaly = getattr(model, 'check_anomaly', None) if self.detect_anomaly else None
         steps = progress.wrap(self.train_dataloader, total=len(self.train_dataloader), unit='step',
                               desc=f'({epoch :^5})', leave=False)
+        replay = self._step_replayer(model) if check_anomaly is None else None
         for batch_idx, batch in enumerate(steps):
-            self.optimizer.zero_grad()
-            loss = model.calculate_loss(self._move_batch_to_device(batch))
-            loss.backward()
-            if check_anomaly is not None:
-                check_anomaly()             # before any optimizer applies a poisoned gradient
-            for optimizer_idx, optimizer in enumerate(self.optimizer.optimizers):
-                model.optimizer_step(epoch=epoch, batch_idx=batch_idx, optimizer=optimizer,
-                                     optimizer_idx=optimizer_idx, optimizer_closure=None)
+            batch = self._move_batch_to_device(batch)
+            loss = replay(batch) if replay is not None else None
+            if loss is None:
+                self.optimizer.zero_grad()
+                loss = model.calculate_loss(batch)
+                loss.backward()
+                if check_anomaly is not None:
+                    check_anomaly()         # before any optimizer applies a poisoned gradient
+                for optimizer_idx, optimizer in enumerate(self.optimizer.optimizers):
+                    model.optimizer_step(epoch=epoch, batch_idx=batch_idx, optimizer=optimizer,
+                                         optimizer_idx=optimizer_idx, optimizer_closure=None)
             self.train_steps += 1
             meter.add(loss)
             progress.show_loss(steps, batch_idx, meter)
@@ -261,6 +270,22 @@ class CollieMinimalTrainer():
         if hasattr(model, 'check_status'):
             model.check_status()            # out-of-range ids seen by any kernel of the epoch
         return meter.value(over=len(self.train_dataloader))
+
+    def _step_replayer(self, model):
+        """The whole loop body as one replayed HIP graph, for models and batch sizes where that
+        applies (``collie_amd/captured.py``); ``None`` otherwise.  A model whose class overrides
+        ``optimizer_step`` or ``calculate_loss`` is stepped the ordinary way."""
+        if not self.capture_small_batches or self.device != 'cuda':
+            return None
+        from collie_amd.model import MatrixFactorizationModel
+        if not isinstance(model, MatrixFactorizationModel) or \
+                type(model).optimizer_step is not MatrixFactorizationModel.optimizer_step or \
+                type(model).calculate_loss is not MatrixFactorizationModel.calculate_loss:
+            return None
+        if self._captured is None or self._captured.model is not model:
+            from collie_amd.captured import CapturedTrainStep
+            self._captured = CapturedTrainStep(model, self.optimizer.optimizers)
+        return self._captured
 
     def _val_loop_single_epoch(self, model) -> float:
         """One pass over the validation loader without gradients."""

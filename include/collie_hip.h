@@ -219,6 +219,39 @@ int collie_mf_train_update(const collie_mf_tables* t, const collie_mf_batch* b, 
                            int32_t* const* row_stamp /*[2]*/, const float* grad_scale,
                            collie_stream_t stream);
 
+/* ---- replaying a captured training step -----------------------------------------------------------
+ * The loop body of the trainers (collie/model/base/trainer.py:458-470: zero_grad, training_step,
+ * backward, optimizer.step for every optimizer) is, on this path, a fixed sequence of kernel
+ * launches: at the reference's default batch size (1,024) the host cannot issue them as fast as the
+ * GPU runs them.  A caller may therefore capture the sequence into a HIP graph once and replay it.
+ * Kernel arguments are frozen in a captured graph, so the arguments that change from step to step
+ * -- step_id and the step-dependent scalars the optimizers derive from cfg[].step (bias
+ * corrections, Adagrad's decayed rate) -- are read from device memory instead when step_id is
+ * COLLIE_STEP_DEVICE:
+ *   collie_mf_train_schedule_steps  (NOT capturable: blocks the host, copies from host memory)
+ *       writes the schedule of the next n_steps <= COLLIE_STEP_SCHEDULE_MAX steps into the
+ *       workspace, computed from cfg exactly as collie_mf_train_update computes them by value (the
+ *       replayed trajectory is bit-identical to the one stepped by value).  cfg[4]: the optimizer of
+ *       user_emb, item_emb, user_bias, item_bias at the FIRST scheduled step (cfg[i].step = that
+ *       table's 1-based step count then; algo = -1: table not updated).  Call it again before the
+ *       schedule runs out, after any change of lr / betas / lr_decay, and after any step that was
+ *       made by value in between.
+ *   collie_mf_train_forward / collie_mf_train_update with step_id = COLLIE_STEP_DEVICE
+ *       use the current schedule entry (cfg[].step is ignored, every other cfg field is read at
+ *       the call, i.e. frozen at capture).
+ *   collie_mf_train_advance_step    the last launch of the step: moves on to the next entry (and
+ *       restarts the stamp-tag cycle when that step is due to).
+ * No counterpart in the reference.
+ * ------------------------------------------------------------------------------------------- */
+#define COLLIE_STEP_DEVICE (-1)
+#define COLLIE_STEP_SCHEDULE_MAX 1024
+int collie_mf_train_schedule_steps(const collie_mf_tables* t, const collie_mf_batch* b,
+                                   void* workspace, size_t workspace_bytes, int32_t first_step_id,
+                                   int32_t n_steps, const collie_optim_cfg* cfg /*[4]*/,
+                                   collie_stream_t stream);
+int collie_mf_train_advance_step(const collie_mf_tables* t, const collie_mf_batch* b,
+                                 void* workspace, size_t workspace_bytes, collie_stream_t stream);
+
 /* Materialise the coalesced gradient of one table (tests, and `.grad` for callers that ask):
  * rows_out [cap] int64 (sorted unique rows that carry gradient entries), vals_out [cap, dim or 1],
  * count_out [1] int32 (device); cap >= 2 * batch.  touched_out (optional, uint8 [num_items], item
