@@ -58,8 +58,8 @@ class CapturedTrainStep:
         self.max_batch = max_batch
         self._graph = None
         self._graph_key = None
-        self._sched_key = None
-        self._expect = None         # (workspace step id, per-table step counts) after our last replay
+        self._owners_cache = None   # owners of the last fully checked call
+        self._next_sig = None       # signature the next call must show to be replayed unchecked
         self._left = 0              # schedule entries not yet replayed
         self.replays = 0
         self.captures = 0
@@ -203,7 +203,62 @@ class CapturedTrainStep:
         self._left = n
 
     # ----------------------------------------------------------------------------------- replay
+    _STEP_AT = 11       # position of the workspace step id in a signature
+
+    def _signature(self, users, pos, neg, owners):
+        """Everything a replay depends on that can change between two calls, as a flat list that is
+        cheap to build (this runs every step: a launch-bound step has ~30 us of host time in all).
+        Batch shape and dtypes, table / workspace storage, the step counters a stepped batch in
+        between would have moved, and the learning rates."""
+        model = self.model
+        ws = model._workspace
+        w = model._weights()
+        sig = [users.shape[0], neg.shape[1], users.dtype, pos.dtype, neg.dtype, model.training,
+               torch.is_grad_enabled(), w[0].data_ptr(), w[1].data_ptr(), w[2].data_ptr(),
+               w[3].data_ptr(), ws.step_id, 0 if ws.buf is None else ws.buf.data_ptr(),
+               id(model.__dict__.get('_loss_cfg'))]
+        for o in owners:
+            if o is not None:
+                sig.append(_count(o[0], o[2]))
+                sig.append(o[1]['lr'])
+        return sig
+
     def __call__(self, batch):
+        try:
+            (users, pos), neg = batch
+            if neg.dim() == 1:
+                neg = neg.reshape(-1, 1)
+            owners = self._owners_cache
+            if owners is not None and self._signature(users, pos, neg, owners) == self._next_sig \
+                    and self._left > 0:
+                return self._replay(users, pos, neg, owners)
+        except (TypeError, ValueError, AttributeError):
+            return None
+        return self._slow(batch)
+
+    def _replay(self, users, pos, neg, owners):
+        model = self.model
+        self._u.copy_(users)
+        self._p.copy_(pos)
+        self._n.copy_(neg)
+        model.__dict__['_staged_step'] = None       # the workspace is overwritten
+        self._graph.replay()
+        self._left -= 1
+        model._workspace.next_step()
+        sig = self._next_sig                        # what the next call must find: one step on
+        sig[self._STEP_AT] += 1
+        at = len(sig) - 2 * sum(o is not None for o in owners)
+        for o in owners:
+            if o is not None:
+                _bump(o[0], o[2])
+                sig[at] += 1
+                at += 2
+        self.replays += 1
+        return self._loss.reshape(())
+
+    def _slow(self, batch):
+        """Full checks; records / schedules as needed; None if the batch has to be stepped."""
+        self._owners_cache = None
         parts = self._batch_ok(batch)
         if parts is None:
             return None
@@ -221,22 +276,8 @@ class CapturedTrainStep:
                 return None             # the ragged last batch of an epoch: stepped, not recorded
             self._record(users, pos, neg, owners)
             self._graph_key = self._keys(users, pos, neg, owners)[0]
-            self._sched_key = None
-        ws = model._workspace
-        now = (ws.step_id, tuple(None if o is None else _count(o[0], o[2]) for o in owners))
-        if sched_key != self._sched_key or self._left == 0 or now != self._expect:
-            self._schedule(owners)
-            self._sched_key = sched_key
-        self._u.copy_(users)
-        self._p.copy_(pos)
-        self._n.copy_(neg)
-        model.__dict__['_staged_step'] = None       # the workspace is overwritten
-        self._graph.replay()
-        self._left -= 1
-        ws.next_step()
-        for o in owners:
-            if o is not None:
-                _bump(o[0], o[2])
-        self._expect = (ws.step_id, tuple(None if o is None else _count(o[0], o[2]) for o in owners))
-        self.replays += 1
-        return self._loss.reshape(())
+        # a stepped batch, a new learning rate or an exhausted schedule brought us here
+        self._schedule(owners)
+        self._owners_cache = owners
+        self._next_sig = self._signature(users, pos, neg, owners)
+        return self._replay(users, pos, neg, owners)

@@ -694,9 +694,15 @@ int launch_emb(const UpdParams& p, int64_t segs, hipStream_t stream) {
   int64_t pblocks = (max_pieces_for(segs) + gpw * kWavesPerBlock - 1) / (gpw * kWavesPerBlock);
   if (pblocks > 2048) pblocks = 2048;
   const unsigned pgrid = static_cast<unsigned>(pblocks);
-  if (vec == 4) launch_piece_lpr<EXPORT, 4>(lpr, pgrid, stream, p);
-  else if (vec == 2) launch_piece_lpr<EXPORT, 2>(lpr, pgrid, stream, p);
-  else launch_piece_lpr<EXPORT, 1>(lpr, pgrid, stream, p);
+  if (small_coalesce(segs)) {
+    // no pieces exist (rowsort.hip): the row kernel sums every segment itself
+  } else if (vec == 4) {
+    launch_piece_lpr<EXPORT, 4>(lpr, pgrid, stream, p);
+  } else if (vec == 2) {
+    launch_piece_lpr<EXPORT, 2>(lpr, pgrid, stream, p);
+  } else {
+    launch_piece_lpr<EXPORT, 1>(lpr, pgrid, stream, p);
+  }
   if (vec == 4) launch_emb_lpr<EXPORT, 4>(lpr, grid, stream, p);
   else if (vec == 2) launch_emb_lpr<EXPORT, 2>(lpr, grid, stream, p);
   else launch_emb_lpr<EXPORT, 1>(lpr, grid, stream, p);
@@ -789,7 +795,8 @@ extern "C" int collie_mf_train_update(const collie_mf_tables* t, const collie_mf
     if (touched[side]) d.seg_stamp = ws.seg_item;
   }
   if (is_bias) {
-    hipLaunchKernelGGL(piece_bias_kernel<false>, dim3(piece_bias_grid(3 * b->batch)), dim3(kBlock),
+    if (!small_coalesce(3 * b->batch))
+      hipLaunchKernelGGL(piece_bias_kernel<false>, dim3(piece_bias_grid(3 * b->batch)), dim3(kBlock),
                        0, stream, p);
     hipLaunchKernelGGL(bias_rows_kernel<false>, dim3(bias_grid(3 * b->batch)), dim3(kBlock), 0,
                        stream, p);
@@ -959,7 +966,8 @@ extern "C" int collie_mf_train_export_grad(const collie_mf_tables* t, const coll
     p.d[1].stage = ws.stage_i;
   }
   if (is_bias) {
-    hipLaunchKernelGGL(piece_bias_kernel<true>, dim3(piece_bias_grid(3 * b->batch)), dim3(kBlock),
+    if (!small_coalesce(3 * b->batch))
+      hipLaunchKernelGGL(piece_bias_kernel<true>, dim3(piece_bias_grid(3 * b->batch)), dim3(kBlock),
                        0, stream, p);
     hipLaunchKernelGGL(bias_rows_kernel<true>, dim3(bias_grid(3 * b->batch)), dim3(kBlock), 0,
                        stream, p);
@@ -1019,7 +1027,8 @@ extern "C" int collie_sparse_rows_update(float* table, int64_t num_rows, int32_t
                  "Adam does not support sparse gradients, please consider SparseAdam instead");
   if (make_hyper(d.h, cfg, 0, true, d.s1, d.s2)) return -1;
   if (dim == 1) {
-    hipLaunchKernelGGL(piece_bias_kernel<false>, dim3(piece_bias_grid(m)), dim3(kBlock), 0, stream,
+    if (!small_coalesce(m))
+      hipLaunchKernelGGL(piece_bias_kernel<false>, dim3(piece_bias_grid(m)), dim3(kBlock), 0, stream,
                        p);
     hipLaunchKernelGGL(bias_rows_kernel<false>, dim3(bias_grid(m)), dim3(kBlock), 0, stream, p);
     return check_launch("sparse_rows_update");
@@ -1076,7 +1085,8 @@ extern "C" int collie_sparse_rows_update_pair(float* table, float* bias_table, i
   q.d[0].s2 = bias_cfg->algo == COLLIE_OPT_SPARSE_ADAM ? bias_state2 : nullptr;
   if (make_hyper(q.d[0].h, bias_cfg, 0, true, q.d[0].s1, q.d[0].s2)) return -1;
   if (launch_emb<false>(p, m, stream)) return -2;
-  hipLaunchKernelGGL(piece_bias_kernel<false>, dim3(piece_bias_grid(m)), dim3(kBlock), 0, stream, q);
+  if (!small_coalesce(m))
+    hipLaunchKernelGGL(piece_bias_kernel<false>, dim3(piece_bias_grid(m)), dim3(kBlock), 0, stream, q);
   hipLaunchKernelGGL(bias_rows_kernel<false>, dim3(bias_grid(m)), dim3(kBlock), 0, stream, q);
   return check_launch("sparse_rows_update_pair");
 }
@@ -1166,7 +1176,8 @@ extern "C" int collie_dense_rows_update(float* table, int64_t num_rows, int32_t 
     d.row_stamp = row_stamp;
   }
   if (dim == 1) {
-    hipLaunchKernelGGL(piece_bias_kernel<false>, dim3(piece_bias_grid(m)), dim3(kBlock), 0, stream,
+    if (!small_coalesce(m))
+      hipLaunchKernelGGL(piece_bias_kernel<false>, dim3(piece_bias_grid(m)), dim3(kBlock), 0, stream,
                        p);
     hipLaunchKernelGGL(bias_rows_kernel<false>, dim3(bias_grid(m)), dim3(kBlock), 0, stream, p);
     if (check_launch("dense_rows_update")) return -2;

@@ -302,12 +302,21 @@ __global__ __launch_bounds__(kBlock) void piece_plan_kernel(const uint32_t* __re
 // ---- small batches: the whole coalesce in ONE workgroup ---------------------------------------------
 // Up to kSmallMax entries (B <= 1365 at 3 entries per sample, i.e. the reference's default batch
 // size of 1,024): the ~11 launches of the general path cost more than their work.  Entries live in
-// LDS; the sort is a stable LSD radix sort one bit at a time (a block-wide prefix count of the
-// zero-bit entries gives every entry its place: zeros keep their order in front, ones behind), then
-// segment heads, the split index and the long-segment pieces, all written in the general layout.
+// LDS; the sort is a stable LSD radix sort, 6 bits per pass: wave w owns entries [256 w, 256 w + 256)
+// of the current order and ranks them among its own entries of the same digit (ballot matching, as
+// radix_scatter_kernel does); the 64 x 16 (digit, wave) counts are one per thread in digit-major
+// order, so ONE workgroup-wide exclusive scan turns them into output positions.  Then segment heads
+// and the split index, all written in the general layout.  No segment is cut into pieces here
+// (long_base = kNoPiece, nseg[2] = 0): with at most 4,096 entries the row-update kernels sum even a
+// degenerate segment in entry order themselves, and the two piece kernels are not launched
+// (small_coalesce() tells the callers).
 constexpr int kSmallBlock = 1024;
 constexpr int kSmallPer = 4;
-constexpr int kSmallMax = kSmallBlock * kSmallPer;  // 4096 entries
+static_assert(kSmallBlock * kSmallPer == kSmallMax, "small-sort shape");
+constexpr int kSmallBits = 6;
+constexpr int kSmallRadix = 1 << kSmallBits;
+constexpr int kSmallWaves = kSmallBlock / kWave;
+static_assert(kSmallRadix * kSmallWaves == kSmallBlock, "one (digit, wave) counter per thread");
 
 // exclusive prefix sum of one value per thread over the workgroup; total to every thread
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* wave_tot, uint32_t& total) {
@@ -324,7 +333,7 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* wave_t
   __syncthreads();
   uint32_t before = 0, all = 0;
 #pragma unroll
-  for (int i = 0; i < kSmallBlock / kWave; ++i) {
+  for (int i = 0; i < kSmallWaves; ++i) {
     const uint32_t t = wave_tot[i];
     before += i < w ? t : 0u;
     all += t;
@@ -336,44 +345,60 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* wave_t
 __global__ __launch_bounds__(kSmallBlock) void small_sort_segment_kernel(
     const uint32_t* __restrict__ ekeys, const uint32_t* __restrict__ ecodes, int m, int nbits,
     uint32_t split, uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
-    uint32_t* __restrict__ seg_start, uint32_t* __restrict__ nseg, uint32_t* __restrict__ long_base,
-    uint32_t* __restrict__ piece_start, uint32_t* __restrict__ piece_end) {
+    uint32_t* __restrict__ seg_start, uint32_t* __restrict__ nseg, uint32_t* __restrict__ long_base) {
   __shared__ uint32_t kbuf[2][kSmallMax];
   __shared__ uint32_t vbuf[2][kSmallMax];
-  __shared__ uint32_t heads[kSmallMax + 1];
-  __shared__ uint32_t wave_tot[kSmallBlock / kWave];
-  __shared__ uint32_t npieces;
+  __shared__ uint32_t wcount[kSmallBlock];   // [digit][wave]
+  __shared__ uint32_t wave_tot[kSmallWaves];
   const int tid = threadIdx.x;
+  const int lane = lane_id();
+  const int w = tid / kWave;
   for (int i = tid; i < kSmallMax; i += kSmallBlock) {
     kbuf[0][i] = i < m ? ekeys[i] : 0xffffffffu;  // padding sorts last and keeps its place
     vbuf[0][i] = i < m ? ecodes[i] : 0u;
   }
-  if (tid == 0) npieces = 0;
-  __syncthreads();
   int cur = 0;
-  for (int bit = 0; bit < nbits; ++bit) {
-    // thread t owns entries 4t .. 4t+3 of the current order
-    uint32_t k[kSmallPer], v[kSmallPer];
-    uint32_t zeros = 0;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  for (int shift = 0; shift < nbits; shift += kSmallBits) {
+    wcount[tid] = 0;
+    __syncthreads();               // also: kbuf[cur] / vbuf[cur] are complete
+    uint32_t key[kSmallPer], val[kSmallPer], rnk[kSmallPer];
+    volatile uint32_t* mycount = wcount;
 #pragma unroll
-    for (int j = 0; j < kSmallPer; ++j) {
-      k[j] = kbuf[cur][tid * kSmallPer + j];
-      v[j] = vbuf[cur][tid * kSmallPer + j];
-      zeros += ((k[j] >> bit) & 1u) ^ 1u;
-    }
-    uint32_t total_zeros;
-    uint32_t zbefore = block_excl_scan(zeros, wave_tot, total_zeros);
+    for (int i = 0; i < kSmallPer; ++i) {
+      const int idx = w * (kWave * kSmallPer) + i * kWave + lane;
+      key[i] = kbuf[cur][idx];
+      val[i] = vbuf[cur][idx];
+      const uint32_t digit = (key[i] >> shift) & (kSmallRadix - 1);
+      unsigned long long peers = ~0ull;
 #pragma unroll
-    for (int j = 0; j < kSmallPer; ++j) {
-      const uint32_t idx = tid * kSmallPer + j;
-      const bool one = (k[j] >> bit) & 1u;
-      const uint32_t pos = one ? total_zeros + (idx - zbefore) : zbefore;
-      kbuf[cur ^ 1][pos] = k[j];
-      vbuf[cur ^ 1][pos] = v[j];
-      zbefore += one ? 0u : 1u;
+      for (int bit = 0; bit < kSmallBits; ++bit) {
+        const bool one = (digit >> bit) & 1u;
+        const unsigned long long bm = __ballot(one);
+        peers &= one ? bm : ~bm;
+      }
+      const uint32_t before = __popcll(peers & lt_mask);
+      const uint32_t old = mycount[digit * kSmallWaves + w];
+      __builtin_amdgcn_wave_barrier();
+      if (before == 0) mycount[digit * kSmallWaves + w] = old + __popcll(peers);
+      __builtin_amdgcn_wave_barrier();
+      rnk[i] = old + before;
     }
     __syncthreads();
+    const uint32_t mine = wcount[tid];
+    uint32_t total;
+    const uint32_t base = block_excl_scan(mine, wave_tot, total);
+    wcount[tid] = base;            // every thread read its own counter before the scan's barriers
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kSmallPer; ++i) {
+      const uint32_t digit = (key[i] >> shift) & (kSmallRadix - 1);
+      const uint32_t pos = wcount[digit * kSmallWaves + w] + rnk[i];
+      kbuf[cur ^ 1][pos] = key[i];
+      vbuf[cur ^ 1][pos] = val[i];
+    }
     cur ^= 1;
+    __syncthreads();               // the positions in wcount have been used by everyone
   }
   // ---- sorted entries out + segment heads ----------------------------------------------------------
   uint32_t nh = 0;
@@ -396,40 +421,22 @@ __global__ __launch_bounds__(kSmallBlock) void small_sort_segment_kernel(
   for (int j = 0; j < kSmallPer; ++j) {
     const int idx = tid * kSmallPer + j;
     if (head[j]) {
-      heads[hbefore] = idx;
       seg_start[hbefore] = idx;
+      long_base[hbefore] = kNoPiece;
       const uint32_t key = kbuf[cur][idx];
       if (key >= split && (idx == 0 || kbuf[cur][idx - 1] < split)) first_split = hbefore;
       ++hbefore;
     }
   }
   if (tid == 0) {
-    heads[total_heads] = m;
     seg_start[total_heads] = m;
     nseg[0] = total_heads;
-    nseg[1] = total_heads;  // overwritten below if a key >= split exists
+    nseg[2] = 0;
   }
-  __syncthreads();
-  if (first_split != 0xffffffffu) nseg[1] = first_split;  // exactly one thread
-  // ---- long segments -> pieces ---------------------------------------------------------------------
-  for (uint32_t seg = tid; seg < total_heads; seg += kSmallBlock) {
-    const uint32_t start = heads[seg], end = heads[seg + 1];
-    const uint32_t len = end - start;
-    if (len <= kPieceLen) {
-      long_base[seg] = kNoPiece;
-      continue;
-    }
-    const uint32_t np = (len + kPieceLen - 1) / kPieceLen;
-    const uint32_t base = atomicAdd(&npieces, np);
-    long_base[seg] = base;
-    for (uint32_t i = 0; i < np; ++i) {
-      piece_start[base + i] = start + i * kPieceLen;
-      const uint32_t pe = start + (i + 1) * kPieceLen;
-      piece_end[base + i] = pe < end ? pe : end;
-    }
-  }
-  __syncthreads();
-  if (tid == 0) nseg[2] = npieces;
+  // the first segment of the second table: exactly one head qualifies, if any
+  const bool any_split = __syncthreads_or(first_split != 0xffffffffu);
+  if (first_split != 0xffffffffu) nseg[1] = first_split;
+  if (!any_split && tid == 0) nseg[1] = total_heads;
 }
 
 template <int BITS>
@@ -452,13 +459,13 @@ int run_pass(const SortWs& s, const uint32_t* kin, const uint32_t* vin, uint32_t
 int sort_and_segment(const SortWs& s, int64_t nkeys, uint32_t split, hipStream_t stream) {
   const RadixPlan plan = radix_plan(nkeys);
   COLLIE_REQUIRE(plan.passes <= 4, "key range too large for the radix plan");
-  if (s.m <= kSmallMax) {
+  if (small_coalesce(s.m)) {
     int nbits = 1;
     while ((int64_t{1} << nbits) < nkeys) ++nbits;
     const int out = (plan.passes - 1) & 1;  // where sorted_keys() / sorted_vals() look
     hipLaunchKernelGGL(small_sort_segment_kernel, dim3(1), dim3(kSmallBlock), 0, stream, s.ekeys,
                        s.ecodes, static_cast<int>(s.m), nbits, split, s.keys[out], s.vals[out],
-                       s.seg_start, s.nseg, s.long_base, s.piece_start, s.piece_end);
+                       s.seg_start, s.nseg, s.long_base);
     return check_launch("small_sort_segment_kernel");
   }
   for (int pass = 0; pass < plan.passes; ++pass) {

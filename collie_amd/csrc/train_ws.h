@@ -71,6 +71,11 @@ struct DynCtl {
   int32_t overrun;      // set if a step was replayed past the end of the schedule
 };
 
+// Coalesces of at most kSmallMax entries run in one workgroup and cut no segment into pieces
+// (rowsort.hip): callers skip the piece kernels for them.
+constexpr int kSmallMax = 4096;
+inline bool small_coalesce(int64_t m) { return m <= kSmallMax; }
+
 constexpr int kPieceLen = 256;
 constexpr uint32_t kNoPiece = 0xffffffffu;
 // every piece but the last of a segment is full, and only segments longer than one piece have any

@@ -280,8 +280,10 @@ class CollieMinimalTrainer():
         from collie_amd.model import MatrixFactorizationModel
         if not isinstance(model, MatrixFactorizationModel) or \
                 type(model).optimizer_step is not MatrixFactorizationModel.optimizer_step or \
-                type(model).calculate_loss is not MatrixFactorizationModel.calculate_loss:
-            return None
+                type(model).calculate_loss is not MatrixFactorizationModel.calculate_loss or \
+                any(name in vars(model) for name in ('calculate_loss', 'optimizer_step',
+                                                     'training_step', 'forward')):
+            return None                       # (also methods replaced on the instance)
         if self._captured is None or self._captured.model is not model:
             from collie_amd.captured import CapturedTrainStep
             self._captured = CapturedTrainStep(model, self.optimizer.optimizers)
