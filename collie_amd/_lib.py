@@ -107,7 +107,8 @@ SIGNATURES = {
                                                       c_size_t, c_int32, c_int32, POINTER(OptimCfg),
                                                       c_void_p]),
     'collie_mf_train_advance_step': (ctypes.c_int, [POINTER(Tables), POINTER(Batch), c_void_p,
-                                                    c_size_t, c_void_p]),
+                                                    c_size_t, c_void_p, c_void_p, c_void_p]),
+    'collie_mf_batch_copy': (ctypes.c_int, [POINTER(Batch), POINTER(Batch), c_void_p]),
     'collie_sparse_rows_workspace_bytes': (c_size_t, [c_int64, c_int32]),
     'collie_sparse_rows_update': (ctypes.c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int32,
                                                  c_void_p, c_int64, POINTER(OptimCfg), c_void_p,

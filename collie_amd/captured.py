@@ -109,7 +109,7 @@ class CapturedTrainStep:
                 or neg.shape[1] > _lib.MAX_NEG or pos.shape[0] != users.shape[0]
                 or neg.shape[0] != users.shape[0]):
             return None
-        return users, pos, neg
+        return users.contiguous(), pos.contiguous(), neg
 
     # ----------------------------------------------------------------------------------- record
     def _record(self, users, pos, neg, owners):
@@ -138,15 +138,18 @@ class CapturedTrainStep:
         torch.cuda.synchronize(dev)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            ops.train_forward(self._tables, self._hbatch, cfg, self._buf, True, ops.STEP_DEVICE,
-                              self._loss, None, None, status)
+            # (a second captured stream for the loss and the bias update was tried: the fork / join
+            # nodes cost more than the overlap gains -- a replayed step is bound by its node count)
+            ops.train_forward(self._tables, self._hbatch, cfg, self._buf, 1 | ops.DEFER_LOSS,
+                              ops.STEP_DEVICE, self._loss, None, None, status)
             ops.train_build_segments(self._tables, self._hbatch, self._buf)
             for is_bias in (False, True):
                 if per_kind[is_bias]:
                     ops.train_update(self._tables, self._hbatch, self._buf, 1 if is_bias else 0,
                                      False, ops.STEP_DEVICE, per_kind[is_bias], None)
-            ops.train_advance_step(self._tables, self._hbatch, self._buf)
+            ops.train_advance_step(self._tables, self._hbatch, self._buf, self._loss, status)
         self._graph = graph
+        self._src = ops.make_batch(self._u, self._p, self._n)    # refilled per call (pointers, strides)
         self._keep = per_kind
         self.captures += 1
 
@@ -213,6 +216,8 @@ class CapturedTrainStep:
         model = self.model
         ws = model._workspace
         w = model._weights()
+        if users.stride(0) != 1 or pos.stride(0) != 1:
+            raise ValueError('strided ids')             # -> the slow path makes them contiguous
         sig = [users.shape[0], neg.shape[1], users.dtype, pos.dtype, neg.dtype, model.training,
                torch.is_grad_enabled(), w[0].data_ptr(), w[1].data_ptr(), w[2].data_ptr(),
                w[3].data_ptr(), ws.step_id, 0 if ws.buf is None else ws.buf.data_ptr(),
@@ -233,14 +238,19 @@ class CapturedTrainStep:
                     and self._left > 0:
                 return self._replay(users, pos, neg, owners)
         except (TypeError, ValueError, AttributeError):
-            return None
+            pass
         return self._slow(batch)
 
     def _replay(self, users, pos, neg, owners):
         model = self.model
-        self._u.copy_(users)
-        self._p.copy_(pos)
-        self._n.copy_(neg)
+        src = self._src
+        src.users = users.data_ptr()
+        src.pos_items = pos.data_ptr()
+        src.neg_items = neg.data_ptr()
+        src.neg_stride_b = neg.stride(0)
+        src.neg_stride_k = neg.stride(1)
+        src._keepalive = (users, pos, neg)
+        ops.batch_copy(src, self._hbatch)
         model.__dict__['_staged_step'] = None       # the workspace is overwritten
         self._graph.replay()
         self._left -= 1

@@ -932,38 +932,10 @@ __global__ __launch_bounds__(kBlock, (CH * NP <= 4 ? 8 : 4)) void mf_train_fwd_l
   }
 }
 
-// loss = (sum l + sum l^2) / B   (bpr.py:89, hinge.py:85, warp.py:133); fixed-order reduction
 __global__ __launch_bounds__(kBlock) void loss_finalize_kernel(const float* partials, int nblocks,
                                                                float inv_b, float* loss_out,
                                                                int32_t* status) {
-  __shared__ double sh[2][kWavesPerBlock];
-  double a = 0.0, c = 0.0;
-  for (int i = threadIdx.x; i < nblocks; i += kBlock) {
-    a += partials[2 * i];
-    c += partials[2 * i + 1];
-  }
-  for (int o = kWave / 2; o > 0; o >>= 1) {
-    a += __shfl_xor(a, o, kWave);
-    c += __shfl_xor(c, o, kWave);
-  }
-  if (lane_id() == 0) {
-    sh[0][threadIdx.x / kWave] = a;
-    sh[1][threadIdx.x / kWave] = c;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double ta = 0.0, tc = 0.0;
-    for (int w = 0; w < kWavesPerBlock; ++w) {
-      ta += sh[0][w];
-      tc += sh[1][w];
-    }
-    const float loss = static_cast<float>((ta + tc) * static_cast<double>(inv_b));
-    *loss_out = loss;
-    // a non-finite loss term makes the sum non-finite: the flag detect_anomaly polls
-    // (trainer.py:333 wraps the fit in torch.autograd.set_detect_anomaly; the fused step has no
-    // autograd graph, so the kernel reports it)
-    if (status && !isfinite(loss)) atomicOr(status, 2);
-  }
+  finalize_loss_block(partials, nblocks, inv_b, loss_out, status);
 }
 
 template <int LPR, int NP>
@@ -1156,6 +1128,9 @@ extern "C" int collie_mf_train_forward(const collie_mf_tables* t, const collie_m
     COLLIE_REQUIRE(b->num_neg == 1, "non-adaptive losses need exactly one negative per sample");
   if (loss->kind == COLLIE_LOSS_WARP)
     COLLIE_REQUIRE(b->num_neg > 1, "Cannot use WARP loss with a single negative sample!");
+  // need_grad bit 1 (COLLIE_DEFER_LOSS): loss_out is written by collie_mf_train_advance_step
+  const bool defer_loss = (need_grad & COLLIE_DEFER_LOSS) != 0;
+  need_grad &= 1;
   const bool from_device = step_id == COLLIE_STEP_DEVICE;
   COLLIE_REQUIRE(step_id >= 1 || from_device, "step_id must be >= 1 (got %d)", step_id);
   COLLIE_REQUIRE(!from_device || need_grad, "COLLIE_STEP_DEVICE is for steps with need_grad");
@@ -1214,8 +1189,53 @@ extern "C" int collie_mf_train_forward(const collie_mf_tables* t, const collie_m
   else if (vec == 4) rc = launch_fwd<4>(lpr, grid, stream, p);
   else if (vec == 2) rc = launch_fwd<2>(lpr, grid, stream, p);
   else rc = launch_fwd<1>(lpr, grid, stream, p);
-  if (rc) return rc;
+  if (rc || defer_loss) return rc;
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(kBlock), 0, stream, ws.loss_partials,
                      static_cast<int>(nblocks), p.inv_b, loss_out, status);
   return check_launch("loss_finalize_kernel");
+}
+
+// ---- one batch into the buffers a captured step reads (collie_mf_batch_copy) ----------------------
+namespace collie {
+namespace {
+__device__ __forceinline__ void store_idx(void* p, int dtype, int64_t i, int64_t v) {
+  if (dtype == COLLIE_I64) static_cast<int64_t*>(p)[i] = v;
+  else static_cast<int32_t*>(p)[i] = static_cast<int32_t>(v);
+}
+__global__ __launch_bounds__(kBlock) void batch_copy_kernel(const collie_mf_batch s,
+                                                            const collie_mf_batch d) {
+  const int64_t B = s.batch;
+  const int K = s.num_neg;
+  const int64_t total = B * (K + 2);
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < total;
+       i += stride) {
+    if (i < B) {
+      store_idx(const_cast<void*>(d.users), d.users_dtype, i, load_idx(s.users, s.users_dtype, i));
+    } else if (i < 2 * B) {
+      const int64_t j = i - B;
+      store_idx(const_cast<void*>(d.pos_items), d.pos_dtype, j,
+                load_idx(s.pos_items, s.pos_dtype, j));
+    } else {
+      const int64_t j = i - 2 * B, row = j / K, k = j - row * K;
+      store_idx(const_cast<void*>(d.neg_items), d.neg_dtype,
+                row * d.neg_stride_b + k * d.neg_stride_k,
+                load_idx(s.neg_items, s.neg_dtype, row * s.neg_stride_b + k * s.neg_stride_k));
+    }
+  }
+}
+}  // namespace
+}  // namespace collie
+
+extern "C" int collie_mf_batch_copy(const collie_mf_batch* src, const collie_mf_batch* dst,
+                                    collie_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (validate_batch(src) || validate_batch(dst)) return -1;
+  COLLIE_REQUIRE(src->batch == dst->batch && src->num_neg == dst->num_neg,
+                 "batch_copy: shapes differ");
+  int64_t blocks = (src->batch * (src->num_neg + 2) + kBlock - 1) / kBlock;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(batch_copy_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0,
+                     stream, *src, *dst);
+  return check_launch("batch_copy_kernel");
 }

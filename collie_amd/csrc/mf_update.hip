@@ -469,7 +469,10 @@ __global__ __launch_bounds__(kBlock) void touched_rows_kernel(float* __restrict_
                                                               const int32_t* __restrict__ seg,
                                                               int64_t rows, int D, int step_,
                                                               const Hyper h_, const StepDyn* dyn,
-                                                              int dyn_idx) {
+                                                              int dyn_idx, int span) {
+  // span = stamps a wave scans at a time: 64 (one coalesced line per wave) for big tables; 16 for
+  // small ones, where the grid has a wave per 16 rows anyway and a wave that took 64 would leave
+  // three idle and walk its rows in four dependent rounds instead of one
   const Hyper h = dyn_hyper(h_, dyn, dyn_idx);
   const int step = dyn ? dyn->step : step_;
   constexpr int GPW = kWave / LPR;
@@ -480,10 +483,10 @@ __global__ __launch_bounds__(kBlock) void touched_rows_kernel(float* __restrict_
   const int lig = lane % LPR;
   const int nchunks = D / 4;
   const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
-  for (int64_t base = (static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave) * kWave;
-       base < rows; base += nwaves * kWave) {
+  for (int64_t base = (static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave) * span;
+       base < rows; base += nwaves * span) {
     const int64_t r = base + lane;
-    const bool need = r < rows && touch[r] == touch_tag(step) && seg[r] != step;
+    const bool need = lane < span && r < rows && touch[r] == touch_tag(step) && seg[r] != step;
     const unsigned long long mask = __ballot(need);
     if (mask == 0ull) continue;
     const int n = __popcll(mask);
@@ -819,18 +822,19 @@ extern "C" int collie_mf_train_update(const collie_mf_tables* t, const collie_mf
         // rows of 16-byte chunks: 4, 8 or 16 lanes per row (at most 4 chunks per lane and pass)
         const int nchunks = p.D / 4;
         const unsigned grid = sweep_grid(rows * 4);
+        const int span = rows * 4 <= 4096 * static_cast<int64_t>(kBlock) ? 16 : kWave;
         if (nchunks <= 16)
           hipLaunchKernelGGL(touched_rows_kernel<4>, dim3(grid), dim3(kBlock), 0, stream, d.table,
                              d.s1, d.s2, ws.touch_item, ws.seg_item, rows, p.D, p.step, d.h, p.dyn,
-                             p.dyn_base + side);
+                             p.dyn_base + side, span);
         else if (nchunks <= 32)
           hipLaunchKernelGGL(touched_rows_kernel<8>, dim3(grid), dim3(kBlock), 0, stream, d.table,
                              d.s1, d.s2, ws.touch_item, ws.seg_item, rows, p.D, p.step, d.h, p.dyn,
-                             p.dyn_base + side);
+                             p.dyn_base + side, span);
         else
           hipLaunchKernelGGL(touched_rows_kernel<16>, dim3(grid), dim3(kBlock), 0, stream, d.table,
                              d.s1, d.s2, ws.touch_item, ws.seg_item, rows, p.D, p.step, d.h, p.dyn,
-                             p.dyn_base + side);
+                             p.dyn_base + side, span);
       } else {
         hipLaunchKernelGGL(touched_sweep_kernel, dim3(sweep_grid(rows * p.D)), dim3(kBlock), 0,
                            stream, d.table, d.s1, d.s2, ws.touch_item, ws.seg_item, rows, p.D,
@@ -858,7 +862,12 @@ __global__ void dyn_reset_kernel(DynCtl* ctl, StepDyn* cur, const StepDyn* sched
 // step id it is given by value).  One workgroup: the clear runs once in 255 steps.
 __global__ __launch_bounds__(1024) void dyn_advance_kernel(DynCtl* ctl, StepDyn* cur,
                                                            const StepDyn* sched,
-                                                           uint8_t* touch_item, int64_t num_items) {
+                                                           uint8_t* touch_item, int64_t num_items,
+                                                           const float* partials, int nblocks,
+                                                           float inv_b, float* loss_out,
+                                                           int32_t* status) {
+  // the loss the forward deferred (COLLIE_DEFER_LOSS): one launch less in the replayed step
+  if (loss_out) finalize_loss_block(partials, nblocks, inv_b, loss_out, status);
   __shared__ StepDyn next;
   __shared__ int next_at;
   if (threadIdx.x == 0) {
@@ -927,14 +936,19 @@ extern "C" int collie_mf_train_schedule_steps(const collie_mf_tables* t, const c
 
 extern "C" int collie_mf_train_advance_step(const collie_mf_tables* t, const collie_mf_batch* b,
                                             void* workspace, size_t workspace_bytes,
+                                            float* loss_out, int32_t* status,
                                             collie_stream_t stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   if (validate_tables(t) || validate_batch(b)) return -1;
   TrainWs ws = carve_train_ws(workspace, b->batch, b->num_neg, t->dim, t->num_users, t->num_items);
   COLLIE_REQUIRE(workspace != nullptr && workspace_bytes >= ws.bytes,
                  "workspace too small: need %zu bytes, got %zu", ws.bytes, workspace_bytes);
+  int64_t nblocks = (b->batch + 3) / 4;   // the forward's grid: one wave per sample, 4 per block
+  if (nblocks > kMaxLossBlocks) nblocks = kMaxLossBlocks;
   hipLaunchKernelGGL(dyn_advance_kernel, dim3(1), dim3(1024), 0, stream, ws.dyn_ctl, ws.dyn_cur,
-                     ws.dyn_sched, ws.touch_item, t->num_items);
+                     ws.dyn_sched, ws.touch_item, t->num_items, ws.loss_partials,
+                     static_cast<int>(nblocks), 1.0f / static_cast<float>(b->batch), loss_out,
+                     status);
   return check_launch("dyn_advance_kernel");
 }
 

@@ -348,7 +348,7 @@ __global__ __launch_bounds__(kSmallBlock) void small_sort_segment_kernel(
     uint32_t* __restrict__ seg_start, uint32_t* __restrict__ nseg, uint32_t* __restrict__ long_base) {
   __shared__ uint32_t kbuf[2][kSmallMax];
   __shared__ uint32_t vbuf[2][kSmallMax];
-  __shared__ uint32_t wcount[kSmallBlock];   // [digit][wave]
+  __shared__ uint32_t wcount[kSmallBlock];   // [wave][digit]: a wave's lanes hit distinct banks
   __shared__ uint32_t wave_tot[kSmallWaves];
   const int tid = threadIdx.x;
   const int lane = lane_id();
@@ -378,22 +378,24 @@ __global__ __launch_bounds__(kSmallBlock) void small_sort_segment_kernel(
         peers &= one ? bm : ~bm;
       }
       const uint32_t before = __popcll(peers & lt_mask);
-      const uint32_t old = mycount[digit * kSmallWaves + w];
+      const uint32_t old = mycount[w * kSmallRadix + digit];
       __builtin_amdgcn_wave_barrier();
-      if (before == 0) mycount[digit * kSmallWaves + w] = old + __popcll(peers);
+      if (before == 0) mycount[w * kSmallRadix + digit] = old + __popcll(peers);
       __builtin_amdgcn_wave_barrier();
       rnk[i] = old + before;
     }
     __syncthreads();
-    const uint32_t mine = wcount[tid];
+    // thread t scans the counter of (digit t / 16, wave t % 16): digit-major order = output order
+    const int mine_at = (tid % kSmallWaves) * kSmallRadix + tid / kSmallWaves;
+    const uint32_t mine = wcount[mine_at];
     uint32_t total;
     const uint32_t base = block_excl_scan(mine, wave_tot, total);
-    wcount[tid] = base;            // every thread read its own counter before the scan's barriers
+    wcount[mine_at] = base;        // every thread read its own counter before the scan's barriers
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < kSmallPer; ++i) {
       const uint32_t digit = (key[i] >> shift) & (kSmallRadix - 1);
-      const uint32_t pos = wcount[digit * kSmallWaves + w] + rnk[i];
+      const uint32_t pos = wcount[w * kSmallRadix + digit] + rnk[i];
       kbuf[cur ^ 1][pos] = key[i];
       vbuf[cur ^ 1][pos] = val[i];
     }

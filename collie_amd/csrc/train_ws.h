@@ -133,6 +133,47 @@ struct TrainWs {
   size_t bytes;
 };
 
+#ifdef __HIPCC__
+// loss = (sum l + sum l^2) / B   (bpr.py:89, hinge.py:85, warp.py:133) from the forward kernel's
+// per-block partials, reduced in a fixed order by the first 256 threads of ONE workgroup (every
+// thread of the workgroup must call this).  Shared by loss_finalize_kernel and the captured step's
+// last kernel, so both give the same bits.
+__device__ __forceinline__ void finalize_loss_block(const float* partials, int nblocks, float inv_b,
+                                                    float* loss_out, int32_t* status) {
+  constexpr int kThreads = 256;
+  __shared__ double sh[2][kThreads / kWave];
+  double a = 0.0, c = 0.0;
+  if (threadIdx.x < kThreads) {
+    for (int i = threadIdx.x; i < nblocks; i += kThreads) {
+      a += partials[2 * i];
+      c += partials[2 * i + 1];
+    }
+    for (int o = kWave / 2; o > 0; o >>= 1) {
+      a += __shfl_xor(a, o, kWave);
+      c += __shfl_xor(c, o, kWave);
+    }
+    if (lane_id() == 0) {
+      sh[0][threadIdx.x / kWave] = a;
+      sh[1][threadIdx.x / kWave] = c;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double ta = 0.0, tc = 0.0;
+    for (int w = 0; w < kThreads / kWave; ++w) {
+      ta += sh[0][w];
+      tc += sh[1][w];
+    }
+    const float loss = static_cast<float>((ta + tc) * static_cast<double>(inv_b));
+    *loss_out = loss;
+    // a non-finite loss term makes the sum non-finite: the flag detect_anomaly polls
+    // (trainer.py:333 wraps the fit in torch.autograd.set_detect_anomaly; the fused step has no
+    // autograd graph, so the kernel reports it)
+    if (status && !isfinite(loss)) atomicOr(status, 2);
+  }
+}
+#endif
+
 inline TrainWs carve_train_ws(void* base, int64_t B, int K, int D, int64_t num_users,
                               int64_t num_items) {
   (void)K;

@@ -93,7 +93,7 @@ def train_forward(tables, batch, loss_cfg, ws_buf, need_grad, step_id, loss_out,
                   s_neg_out=None, status=None):
     check(load().collie_mf_train_forward(
         byref(tables), byref(batch), byref(loss_cfg), ptr(ws_buf), ws_buf.numel(),
-        1 if need_grad else 0, step_id, ptr(loss_out), ptr(s_pos_out), ptr(s_neg_out),
+        int(need_grad), step_id, ptr(loss_out), ptr(s_pos_out), ptr(s_neg_out),
         ptr(status), stream_ptr()), 'collie_mf_train_forward')
 
 
@@ -161,10 +161,18 @@ def train_schedule_steps(tables, batch, ws_buf, first_step_id, n_steps, cfgs):
         arr, stream_ptr()), 'collie_mf_train_schedule_steps')
 
 
-def train_advance_step(tables, batch, ws_buf):
+DEFER_LOSS = 2             # COLLIE_DEFER_LOSS
+SMALL_COALESCE_MAX = 4096  # csrc/train_ws.h kSmallMax: coalesces this small cut no pieces
+
+
+def batch_copy(src, dst):
+    check(load().collie_mf_batch_copy(byref(src), byref(dst), stream_ptr()), 'collie_mf_batch_copy')
+
+
+def train_advance_step(tables, batch, ws_buf, loss_out=None, status=None):
     check(load().collie_mf_train_advance_step(
-        byref(tables), byref(batch), ptr(ws_buf), ws_buf.numel(), stream_ptr()),
-        'collie_mf_train_advance_step')
+        byref(tables), byref(batch), ptr(ws_buf), ws_buf.numel(), ptr(loss_out), ptr(status),
+        stream_ptr()), 'collie_mf_train_advance_step')
 
 
 def train_export_grad(tables, batch, ws_buf, side, is_bias, step_id):

@@ -240,17 +240,29 @@ int collie_mf_train_update(const collie_mf_tables* t, const collie_mf_batch* b, 
  *       use the current schedule entry (cfg[].step is ignored, every other cfg field is read at
  *       the call, i.e. frozen at capture).
  *   collie_mf_train_advance_step    the last launch of the step: moves on to the next entry (and
- *       restarts the stamp-tag cycle when that step is due to).
+ *       restarts the stamp-tag cycle when that step is due to); also writes the loss if the forward
+ *       deferred it (COLLIE_DEFER_LOSS).
  * No counterpart in the reference.
  * ------------------------------------------------------------------------------------------- */
 #define COLLIE_STEP_DEVICE (-1)
 #define COLLIE_STEP_SCHEDULE_MAX 1024
+/* need_grad | COLLIE_DEFER_LOSS for collie_mf_train_forward: the loss partials stay in the workspace
+ * and loss_out (+ the non-finite bit of *status) is written by the collie_mf_train_advance_step that
+ * ends the step: one launch less in a replayed step, where every launch costs more than the work. */
+#define COLLIE_DEFER_LOSS 2
+/* Copies one batch (collie_mf_batch: any strides, int32 / int64 ids) into another of the same shape:
+ * the batch of the step into the buffers a captured step was recorded on, in ONE launch.  The
+ * loaders of the reference hand out fresh tensors per batch (collie/interactions/dataloaders.py). */
+int collie_mf_batch_copy(const collie_mf_batch* src, const collie_mf_batch* dst,
+                         collie_stream_t stream);
 int collie_mf_train_schedule_steps(const collie_mf_tables* t, const collie_mf_batch* b,
                                    void* workspace, size_t workspace_bytes, int32_t first_step_id,
                                    int32_t n_steps, const collie_optim_cfg* cfg /*[4]*/,
                                    collie_stream_t stream);
 int collie_mf_train_advance_step(const collie_mf_tables* t, const collie_mf_batch* b,
-                                 void* workspace, size_t workspace_bytes, collie_stream_t stream);
+                                 void* workspace, size_t workspace_bytes,
+                                 float* loss_out /* NULL unless the forward deferred the loss */,
+                                 int32_t* status, collie_stream_t stream);
 
 /* Materialise the coalesced gradient of one table (tests, and `.grad` for callers that ask):
  * rows_out [cap] int64 (sorted unique rows that carry gradient entries), vals_out [cap, dim or 1],
