@@ -125,16 +125,11 @@ class CapturedTrainStep:
         self._tables = model._tables()
         self._hbatch = ops.make_batch(self._u, self._p, self._n)
         self._loss = torch.empty(1, dtype=torch.float32, device=dev)
+        self._loss0 = self._loss.reshape(())
         # the loss configuration the model itself would use (built by a first ordinary step)
         cfg = model.__dict__.get('_loss_cfg')
         status = model._status_flag()
-        per_kind = {False: {}, True: {}}
-        for i, o in enumerate(owners):
-            if o is None:
-                continue
-            opt, group, p = o
-            side, is_bias = _SLOTS[i]
-            per_kind[is_bias][side] = self._table_args(opt, group, p)
+        per_table = [None if o is None else self._table_args(*o) for o in owners]
         torch.cuda.synchronize(dev)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
@@ -142,15 +137,14 @@ class CapturedTrainStep:
             # nodes cost more than the overlap gains -- a replayed step is bound by its node count)
             ops.train_forward(self._tables, self._hbatch, cfg, self._buf, 1 | ops.DEFER_LOSS,
                               ops.STEP_DEVICE, self._loss, None, None, status)
-            ops.train_build_segments(self._tables, self._hbatch, self._buf)
-            for is_bias in (False, True):
-                if per_kind[is_bias]:
-                    ops.train_update(self._tables, self._hbatch, self._buf, 1 if is_bias else 0,
-                                     False, ops.STEP_DEVICE, per_kind[is_bias], None)
+            if ops.train_update_needs_segments(self._tables, self._hbatch, False):
+                ops.train_build_segments(self._tables, self._hbatch, self._buf)
+            ops.train_update_all(self._tables, self._hbatch, self._buf, 1, False, ops.STEP_DEVICE,
+                                 per_table, None)
             ops.train_advance_step(self._tables, self._hbatch, self._buf, self._loss, status)
         self._graph = graph
         self._src = ops.make_batch(self._u, self._p, self._n)    # refilled per call (pointers, strides)
-        self._keep = per_kind
+        self._keep = per_table
         self.captures += 1
 
     @staticmethod
@@ -264,7 +258,7 @@ class CapturedTrainStep:
                 sig[at] += 1
                 at += 2
         self.replays += 1
-        return self._loss.reshape(())
+        return self._loss0
 
     def _slow(self, batch):
         """Full checks; records / schedules as needed; None if the batch has to be stepped."""

@@ -406,6 +406,160 @@ __global__ __launch_bounds__(kBlock) void bias_rows_kernel(const UpdParams p) {
   }
 }
 
+// ---- small batches: coalesce and update in ONE launch, without a sort --------------------------------
+// At most kSmallMax entries (the reference's default batch of 1,024 samples): every launch costs more
+// than its work, so the sort, the embedding-row update and the bias-row update become one kernel.
+// LPR lanes own one ENTRY i of the unsorted (key, code) list the forward kernel wrote.  The group
+// scans all keys (staged in LDS, four per lane and iteration) for equal ones: an equal key at j < i
+// means i is not the row's first entry and the group has nothing to do; equal keys at j > i are the
+// rest of the row's segment, met in increasing j -- the batch order a stable sort would give them --
+// and added as they are met.  Nearly every row of a small batch is looked up once, so a scan
+// iteration is a 16-byte LDS read, four compares and one wave-wide ballot that says "nothing here".
+// The sums are formed entry by entry in batch order, exactly as emb_rows_kernel forms them.
+struct SmallParams {
+  TableDesc e[2];      // embedding tables (user, item); table == NULL: not updated by this launch
+  TableDesc z[2];      // bias tables
+  const uint32_t* ekeys;
+  const uint32_t* ecodes;
+  const float* grad_scale;
+  const StepDyn* dyn;
+  uint32_t split;
+  int m;
+  int D;
+  int step;
+};
+
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void small_rows_kernel(const SmallParams p) {
+  constexpr int GPW = kWave / LPR;
+  constexpr int U = 4;               // scan iterations whose LDS reads are issued together
+  // (padded so that the unrolled scan may read past m: padding never equals a key)
+  __shared__ __attribute__((aligned(16))) uint32_t keys[kSmallMax + 4 * U * kWave];
+  const int tid = threadIdx.x;
+  const int lane = lane_id();
+  const int grp = lane / LPR;
+  const int lig = lane % LPR;
+  const int m = p.m;
+  for (int i = tid; i < kSmallMax + 4 * U * kWave; i += kBlock)
+    keys[i] = i < m ? p.ekeys[i] : 0xffffffffu;
+  const int i = (blockIdx.x * kWavesPerBlock + tid / kWave) * GPW + grp;
+  const bool active = i < m;
+  const uint32_t key = active ? p.ekeys[i] : 0xfffffffeu;   // matches nothing (keys < 2^32 - 2)
+  const int side = key >= p.split ? 1 : 0;
+  const int64_t row = side ? key - p.split : key;
+  const TableDesc& et = p.e[side];
+  const TableDesc& zt = p.z[side];
+  const int D = p.D;
+  const int chunk = lig;                               // D / 4 <= LPR (host)
+  const bool on = active && chunk * 4 < D;
+  const float* estage = et.table ? et.stage : nullptr;
+  const float* zstage = zt.table ? zt.stage : nullptr;
+
+  float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  float zacc = 0.0f;
+  auto add_entry = [&](int j) {
+    const uint32_t c = p.ecodes[j];
+    if (c == kCodeNone) return;
+    const float sg = (c & kCodeNeg) ? -1.0f : 1.0f;
+    const int64_t src = c & kCodeMask;
+    if (estage && on) {
+      const float4 x = *reinterpret_cast<const float4*>(estage + src * D + chunk * 4);
+      acc.x += sg * x.x;
+      acc.y += sg * x.y;
+      acc.z += sg * x.z;
+      acc.w += sg * x.w;
+    }
+    if (zstage && lig == 0) {
+      const float gv = zstage[src];
+      zacc += (c & kCodeNeg) ? -gv : gv;
+    }
+  };
+  // speculative (wasted only for the few entries that are not the first of their row): the entry's
+  // own gradient row and the row of the tables it will update are in flight during the scan
+  if (active) add_entry(i);
+  const int64_t off = row * D + chunk * 4;
+  float4 pv = make_float4(0, 0, 0, 0), s1 = pv, s2 = pv;
+  if (et.table && on) {
+    pv = *reinterpret_cast<const float4*>(et.table + off);
+    if (et.s1) s1 = *reinterpret_cast<const float4*>(et.s1 + off);
+    if (et.s2) s2 = *reinterpret_cast<const float4*>(et.s2 + off);
+  }
+  float zp = 0.0f, zs1 = 0.0f, zs2 = 0.0f;
+  if (zt.table && active && lig == 0) {
+    zp = zt.table[row];
+    if (zt.s1) zs1 = zt.s1[row];
+    if (zt.s2) zs2 = zt.s2[row];
+  }
+  __syncthreads();
+
+  bool first = active;
+  const uint4* keys4 = reinterpret_cast<const uint4*>(keys);
+  const int iters = (m + 4 * LPR - 1) / (4 * LPR);
+  const unsigned long long gmask = (LPR == kWave ? ~0ull : ((1ull << LPR) - 1ull)) << (grp * LPR);
+  for (int t0 = 0; t0 < iters; t0 += U) {
+    uint4 k4[U];
+    uint32_t eq[U], any_eq = 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) k4[u] = keys4[(t0 + u) * LPR + lig];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j0 = 4 * ((t0 + u) * LPR + lig);
+      eq[u] = (k4[u].x == key && j0 != i ? 1u : 0u) | (k4[u].y == key && j0 + 1 != i ? 2u : 0u) |
+              (k4[u].z == key && j0 + 2 != i ? 4u : 0u) | (k4[u].w == key && j0 + 3 != i ? 8u : 0u);
+      any_eq |= eq[u];
+    }
+    if (__ballot(any_eq != 0u) == 0ull) continue;      // wave-uniform: the common case
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = t0 + u;
+      const int j0 = 4 * (t * LPR + lig);
+      // an equal key before i anywhere in the group's window: i is not the first entry of its row
+      uint32_t before = 0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) before |= ((eq[u] >> c) & 1u) && j0 + c < i ? 1u : 0u;
+      if (__ballot(before != 0u) & gmask) first = false;
+      // equal keys after i, in increasing j = (lane, component) order
+      unsigned long long later[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        later[c] = (__ballot(((eq[u] >> c) & 1u) && j0 + c > i) & gmask) >> (grp * LPR);
+      unsigned long long any_later = later[0] | later[1] | later[2] | later[3];
+      if (!first) any_later = 0ull;
+      while (any_later) {
+        const int l = __builtin_ctzll(any_later);
+        any_later &= any_later - 1ull;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if ((later[c] >> l) & 1ull) add_entry(4 * (t * LPR + l) + c);
+      }
+    }
+  }
+  if (!first) return;
+
+  const float scale = p.grad_scale ? *p.grad_scale : 1.0f;
+  const int step = p.dyn ? p.dyn->step : p.step;
+  if (et.table && on) {
+    const Hyper h = dyn_hyper(et.h, p.dyn, side);
+    pv.x = apply_update(h, pv.x, acc.x * scale, s1.x, s2.x);
+    pv.y = apply_update(h, pv.y, acc.y * scale, s1.y, s2.y);
+    pv.z = apply_update(h, pv.z, acc.z * scale, s1.z, s2.z);
+    pv.w = apply_update(h, pv.w, acc.w * scale, s1.w, s2.w);
+    *reinterpret_cast<float4*>(et.table + off) = pv;
+    if (et.s1) *reinterpret_cast<float4*>(et.s1 + off) = s1;
+    if (et.s2) *reinterpret_cast<float4*>(et.s2 + off) = s2;
+  }
+  if (lig == 0) {
+    if (zt.table) {
+      const Hyper h = dyn_hyper(zt.h, p.dyn, 2 + side);
+      zt.table[row] = apply_update(h, zp, zacc * scale, zs1, zs2);
+      if (zt.s1) zt.s1[row] = zs1;
+      if (zt.s2) zt.s2[row] = zs2;
+      if (zt.seg_stamp) zt.seg_stamp[row] = step;
+    }
+    if (et.table && et.seg_stamp) et.seg_stamp[row] = step;
+  }
+}
+
 // K5: dense optimizers also move every row that had NO segment this step (gradient 0, plus
 // weight decay): Adam decays m, v and keeps stepping along m.
 __global__ __launch_bounds__(kBlock) void dense_sweep_kernel(float* __restrict__ table,
@@ -742,35 +896,25 @@ void fill_sorted(UpdParams& p, const SortWs& s, int64_t nkeys, uint32_t split) {
 
 using namespace collie;
 
-extern "C" int collie_mf_train_update(const collie_mf_tables* t, const collie_mf_batch* b,
-                                      void* workspace, size_t workspace_bytes, int32_t table_mask,
-                                      int32_t is_bias, int32_t dense, int32_t step_id,
-                                      const collie_optim_cfg* cfg, float* const* state1,
-                                      float* const* state2, int32_t* const* row_stamp,
-                                      const float* grad_scale, collie_stream_t stream_) {
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
-  if (validate_tables(t) || validate_batch(b)) return -1;
-  COLLIE_REQUIRE(cfg && state1 && state2 && row_stamp, "update: NULL argument array");
-  COLLIE_REQUIRE((table_mask & 3) != 0 && (table_mask & ~3) == 0, "bad table_mask %d", table_mask);
-  TrainWs ws = carve_train_ws(workspace, b->batch, b->num_neg, t->dim, t->num_users, t->num_items);
-  COLLIE_REQUIRE(workspace != nullptr && workspace_bytes >= ws.bytes,
-                 "workspace too small: need %zu bytes, got %zu", ws.bytes, workspace_bytes);
-  UpdParams p;
-  memset(&p, 0, sizeof(p));
-  fill_sorted(p, ws.sort, t->num_users + t->num_items, static_cast<uint32_t>(t->num_users));
-  p.grad_scale = grad_scale;
-  // a replayed step: the step id and the step-dependent scalars of cfg come from the schedule in
-  // the workspace (cfg[].step is ignored; every other field of cfg is read now, as usual)
-  const bool from_device = step_id == COLLIE_STEP_DEVICE;
-  COLLIE_REQUIRE(step_id >= 1 || from_device, "step_id must be >= 1 (got %d)", step_id);
-  p.step = step_id;
-  p.dyn = from_device ? ws.dyn_cur : nullptr;
-  p.dyn_base = is_bias ? 2 : 0;
-  p.D = is_bias ? 1 : t->dim;
-  bool sweep[2] = {false, false}, touched[2] = {false, false};
+namespace collie {
+namespace {
+
+// the TableDesc pair of one kind of table (embeddings: is_bias = 0; biases: 1, or 2 after an
+// explicit loss) for the sides in table_mask, and which of them need a sweep afterwards
+struct KindPlan {
+  TableDesc d[2];
+  bool sweep[2], touched[2];
+  int D;
+};
+
+int plan_kind(KindPlan& k, const collie_mf_tables* t, const TrainWs& ws, int table_mask, int is_bias,
+              int dense, bool from_device, const collie_optim_cfg* cfg, float* const* state1,
+              float* const* state2, int32_t* const* row_stamp) {
+  memset(&k, 0, sizeof(k));
+  k.D = is_bias ? 1 : t->dim;
   for (int side = 0; side < 2; ++side) {
     if (!(table_mask & (1 << side))) continue;
-    TableDesc& d = p.d[side];
+    TableDesc& d = k.d[side];
     if (is_bias) {
       d.table = side == COLLIE_SIDE_USER ? t->user_bias : t->item_bias;
       // pairwise losses: d loss / d user_bias == 0 exactly; explicit losses (is_bias == 2): g
@@ -787,62 +931,212 @@ extern "C" int collie_mf_train_update(const collie_mf_tables* t, const collie_mf
     if (from_device) c.step = 1;
     if (make_hyper(d.h, &c, dense, true, d.s1, d.s2)) return -1;
     // dense algorithms whose zero-gradient update is not the identity sweep the other rows
-    sweep[side] = dense && (cfg[side].algo == COLLIE_OPT_ADAM || cfg[side].weight_decay != 0.0f);
-    if (sweep[side]) {
+    k.sweep[side] = dense && (cfg[side].algo == COLLIE_OPT_ADAM || cfg[side].weight_decay != 0.0f);
+    if (k.sweep[side]) {
       COLLIE_REQUIRE(row_stamp[side] != nullptr,
                      "dense Adam / weight decay need row_stamp = int32[rows] scratch");
       d.row_stamp = row_stamp[side];
     }
     // SparseAdam moves looked-up rows even with a zero gradient: the K-1 other negatives
-    touched[side] = !dense && side == COLLIE_SIDE_ITEM && cfg[side].algo == COLLIE_OPT_SPARSE_ADAM;
-    if (touched[side]) d.seg_stamp = ws.seg_item;
+    k.touched[side] =
+        !dense && side == COLLIE_SIDE_ITEM && cfg[side].algo == COLLIE_OPT_SPARSE_ADAM;
+    if (k.touched[side]) d.seg_stamp = ws.seg_item;
   }
+  return 0;
+}
+
+// rows without a gradient entry (K5 / K5b) of one kind, after its row kernel
+int sweep_kind(const KindPlan& k, const collie_mf_tables* t, const TrainWs& ws, int step,
+               const StepDyn* dyn, int dyn_base, hipStream_t stream) {
+  for (int side = 0; side < 2; ++side) {
+    const TableDesc& d = k.d[side];
+    const int64_t rows = side == COLLIE_SIDE_USER ? t->num_users : t->num_items;
+    if (k.sweep[side]) {
+      hipLaunchKernelGGL(dense_sweep_kernel, dim3(sweep_grid(rows * k.D)), dim3(kBlock), 0, stream,
+                         d.table, d.s1, d.s2, d.row_stamp, rows, k.D, step, d.h, dyn,
+                         dyn_base + side);
+      if (check_launch("dense_sweep_kernel")) return -2;
+    }
+    if (k.touched[side]) {
+      auto al16 = [](const void* q) { return reinterpret_cast<uintptr_t>(q) % 16 == 0; };
+      if (k.D % 4 == 0 && al16(d.table) && al16(d.s1) && al16(d.s2)) {
+        // rows of 16-byte chunks: 4, 8 or 16 lanes per row (at most 4 chunks per lane and pass)
+        const int nchunks = k.D / 4;
+        const unsigned grid = sweep_grid(rows * 4);
+        const int span = rows * 4 <= 4096 * static_cast<int64_t>(kBlock) ? 16 : kWave;
+        if (nchunks <= 16)
+          hipLaunchKernelGGL(touched_rows_kernel<4>, dim3(grid), dim3(kBlock), 0, stream, d.table,
+                             d.s1, d.s2, ws.touch_item, ws.seg_item, rows, k.D, step, d.h, dyn,
+                             dyn_base + side, span);
+        else if (nchunks <= 32)
+          hipLaunchKernelGGL(touched_rows_kernel<8>, dim3(grid), dim3(kBlock), 0, stream, d.table,
+                             d.s1, d.s2, ws.touch_item, ws.seg_item, rows, k.D, step, d.h, dyn,
+                             dyn_base + side, span);
+        else
+          hipLaunchKernelGGL(touched_rows_kernel<16>, dim3(grid), dim3(kBlock), 0, stream, d.table,
+                             d.s1, d.s2, ws.touch_item, ws.seg_item, rows, k.D, step, d.h, dyn,
+                             dyn_base + side, span);
+      } else {
+        hipLaunchKernelGGL(touched_sweep_kernel, dim3(sweep_grid(rows * k.D)), dim3(kBlock), 0,
+                           stream, d.table, d.s1, d.s2, ws.touch_item, ws.seg_item, rows, k.D,
+                           step, d.h, dyn, dyn_base + side);
+      }
+      if (check_launch("touched_sweep_kernel")) return -2;
+    }
+  }
+  return 0;
+}
+
+// The sort-free kernel serves sparse algorithms on coalesces of at most kSmallMax entries whose
+// embedding rows are float4 chunks, at most 64 of them (dim <= 256).
+bool small_rows_ok(const collie_mf_tables* t, const collie_mf_batch* b, int dense) {
+  return !dense && small_coalesce(3 * b->batch) && t->dim % 4 == 0 && t->dim <= 4 * kWave;
+}
+
+bool small_descs_ok(const KindPlan* emb) {
+  auto al16 = [](const void* q) { return reinterpret_cast<uintptr_t>(q) % 16 == 0; };
+  if (!emb) return true;
+  for (int side = 0; side < 2; ++side) {
+    const TableDesc& d = emb->d[side];
+    if (!(al16(d.table) && al16(d.s1) && al16(d.s2) && al16(d.stage))) return false;
+  }
+  return true;
+}
+
+int launch_small_rows(const collie_mf_tables* t, const collie_mf_batch* b, const TrainWs& ws,
+                      const KindPlan* emb, const KindPlan* bias, int step, const StepDyn* dyn,
+                      const float* grad_scale, hipStream_t stream) {
+  SmallParams q;
+  memset(&q, 0, sizeof(q));
+  for (int side = 0; side < 2; ++side) {
+    if (emb) q.e[side] = emb->d[side];
+    if (bias) q.z[side] = bias->d[side];
+  }
+  q.ekeys = ws.sort.ekeys;
+  q.ecodes = ws.sort.ecodes;
+  q.grad_scale = grad_scale;
+  q.dyn = dyn;
+  q.split = static_cast<uint32_t>(t->num_users);
+  q.m = static_cast<int>(3 * b->batch);
+  q.D = t->dim;
+  q.step = step;
+  const int nchunks = emb ? t->dim / 4 : 1;
+  int lpr = 16;                      // at least 16 lanes per entry: the scan is split among them
+  while (lpr < nchunks) lpr *= 2;
+  const int per_block = kWavesPerBlock * (kWave / lpr);
+  const dim3 grid(static_cast<unsigned>((q.m + per_block - 1) / per_block));
+  switch (lpr) {
+    case 16: hipLaunchKernelGGL(small_rows_kernel<16>, grid, dim3(kBlock), 0, stream, q); break;
+    case 32: hipLaunchKernelGGL(small_rows_kernel<32>, grid, dim3(kBlock), 0, stream, q); break;
+    default: hipLaunchKernelGGL(small_rows_kernel<64>, grid, dim3(kBlock), 0, stream, q); break;
+  }
+  return check_launch("small_rows_kernel");
+}
+
+}  // namespace
+}  // namespace collie
+
+extern "C" int collie_mf_train_update_needs_segments(const collie_mf_tables* t,
+                                                     const collie_mf_batch* b, int32_t dense) {
+  if (validate_tables(t) || validate_batch(b)) return -1;
+  return small_rows_ok(t, b, dense) ? 0 : 1;
+}
+
+extern "C" int collie_mf_train_update(const collie_mf_tables* t, const collie_mf_batch* b,
+                                      void* workspace, size_t workspace_bytes, int32_t table_mask,
+                                      int32_t is_bias, int32_t dense, int32_t step_id,
+                                      const collie_optim_cfg* cfg, float* const* state1,
+                                      float* const* state2, int32_t* const* row_stamp,
+                                      const float* grad_scale, collie_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (validate_tables(t) || validate_batch(b)) return -1;
+  COLLIE_REQUIRE(cfg && state1 && state2 && row_stamp, "update: NULL argument array");
+  COLLIE_REQUIRE((table_mask & 3) != 0 && (table_mask & ~3) == 0, "bad table_mask %d", table_mask);
+  TrainWs ws = carve_train_ws(workspace, b->batch, b->num_neg, t->dim, t->num_users, t->num_items);
+  COLLIE_REQUIRE(workspace != nullptr && workspace_bytes >= ws.bytes,
+                 "workspace too small: need %zu bytes, got %zu", ws.bytes, workspace_bytes);
+  // a replayed step: the step id and the step-dependent scalars of cfg come from the schedule in
+  // the workspace (cfg[].step is ignored; every other field of cfg is read now, as usual)
+  const bool from_device = step_id == COLLIE_STEP_DEVICE;
+  COLLIE_REQUIRE(step_id >= 1 || from_device, "step_id must be >= 1 (got %d)", step_id);
+  const StepDyn* dyn = from_device ? ws.dyn_cur : nullptr;
+  const int dyn_base = is_bias ? 2 : 0;
+  KindPlan k;
+  if (plan_kind(k, t, ws, table_mask, is_bias, dense, from_device, cfg, state1, state2, row_stamp))
+    return -1;
+  if (small_rows_ok(t, b, dense) && small_descs_ok(is_bias ? nullptr : &k)) {
+    if (launch_small_rows(t, b, ws, is_bias ? nullptr : &k, is_bias ? &k : nullptr, step_id, dyn,
+                          grad_scale, stream))
+      return -2;
+    return sweep_kind(k, t, ws, step_id, dyn, dyn_base, stream);
+  }
+  UpdParams p;
+  memset(&p, 0, sizeof(p));
+  fill_sorted(p, ws.sort, t->num_users + t->num_items, static_cast<uint32_t>(t->num_users));
+  p.grad_scale = grad_scale;
+  p.step = step_id;
+  p.dyn = dyn;
+  p.dyn_base = dyn_base;
+  p.D = k.D;
+  p.d[0] = k.d[0];
+  p.d[1] = k.d[1];
   if (is_bias) {
     if (!small_coalesce(3 * b->batch))
       hipLaunchKernelGGL(piece_bias_kernel<false>, dim3(piece_bias_grid(3 * b->batch)), dim3(kBlock),
-                       0, stream, p);
+                         0, stream, p);
     hipLaunchKernelGGL(bias_rows_kernel<false>, dim3(bias_grid(3 * b->batch)), dim3(kBlock), 0,
                        stream, p);
     if (check_launch("bias_rows_kernel")) return -2;
   } else if (launch_emb<false>(p, 3 * b->batch, stream)) {
     return -2;
   }
-  for (int side = 0; side < 2; ++side) {
-    const TableDesc& d = p.d[side];
-    const int64_t rows = side == COLLIE_SIDE_USER ? t->num_users : t->num_items;
-    if (sweep[side]) {
-      hipLaunchKernelGGL(dense_sweep_kernel, dim3(sweep_grid(rows * p.D)), dim3(kBlock), 0, stream,
-                         d.table, d.s1, d.s2, d.row_stamp, rows, p.D, p.step, d.h, p.dyn,
-                         p.dyn_base + side);
-      if (check_launch("dense_sweep_kernel")) return -2;
-    }
-    if (touched[side]) {
-      auto al16 = [](const void* q) { return reinterpret_cast<uintptr_t>(q) % 16 == 0; };
-      if (p.D % 4 == 0 && al16(d.table) && al16(d.s1) && al16(d.s2)) {
-        // rows of 16-byte chunks: 4, 8 or 16 lanes per row (at most 4 chunks per lane and pass)
-        const int nchunks = p.D / 4;
-        const unsigned grid = sweep_grid(rows * 4);
-        const int span = rows * 4 <= 4096 * static_cast<int64_t>(kBlock) ? 16 : kWave;
-        if (nchunks <= 16)
-          hipLaunchKernelGGL(touched_rows_kernel<4>, dim3(grid), dim3(kBlock), 0, stream, d.table,
-                             d.s1, d.s2, ws.touch_item, ws.seg_item, rows, p.D, p.step, d.h, p.dyn,
-                             p.dyn_base + side, span);
-        else if (nchunks <= 32)
-          hipLaunchKernelGGL(touched_rows_kernel<8>, dim3(grid), dim3(kBlock), 0, stream, d.table,
-                             d.s1, d.s2, ws.touch_item, ws.seg_item, rows, p.D, p.step, d.h, p.dyn,
-                             p.dyn_base + side, span);
-        else
-          hipLaunchKernelGGL(touched_rows_kernel<16>, dim3(grid), dim3(kBlock), 0, stream, d.table,
-                             d.s1, d.s2, ws.touch_item, ws.seg_item, rows, p.D, p.step, d.h, p.dyn,
-                             p.dyn_base + side, span);
-      } else {
-        hipLaunchKernelGGL(touched_sweep_kernel, dim3(sweep_grid(rows * p.D)), dim3(kBlock), 0,
-                           stream, d.table, d.s1, d.s2, ws.touch_item, ws.seg_item, rows, p.D,
-                           p.step, d.h, p.dyn, p.dyn_base + side);
-      }
-      if (check_launch("touched_sweep_kernel")) return -2;
-    }
+  return sweep_kind(k, t, ws, step_id, dyn, dyn_base, stream);
+}
+
+// Both kinds of table in one call: cfg / state1 / state2 / row_stamp are indexed [user_emb,
+// item_emb, user_bias, item_bias]; cfg[i].algo < 0: table i is not updated.
+extern "C" int collie_mf_train_update_all(const collie_mf_tables* t, const collie_mf_batch* b,
+                                          void* workspace, size_t workspace_bytes,
+                                          int32_t bias_mode, int32_t dense, int32_t step_id,
+                                          const collie_optim_cfg* cfg, float* const* state1,
+                                          float* const* state2, int32_t* const* row_stamp,
+                                          const float* grad_scale, collie_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (validate_tables(t) || validate_batch(b)) return -1;
+  COLLIE_REQUIRE(cfg && state1 && state2 && row_stamp, "update: NULL argument array");
+  COLLIE_REQUIRE(bias_mode == 1 || bias_mode == 2, "bias_mode must be 1 or 2 (got %d)", bias_mode);
+  int mask[2] = {0, 0};
+  for (int i = 0; i < 4; ++i)
+    if (cfg[i].algo >= 0) mask[i / 2] |= 1 << (i % 2);
+  COLLIE_REQUIRE(mask[0] || mask[1], "update_all: no table to update");
+  TrainWs ws = carve_train_ws(workspace, b->batch, b->num_neg, t->dim, t->num_users, t->num_items);
+  COLLIE_REQUIRE(workspace != nullptr && workspace_bytes >= ws.bytes,
+                 "workspace too small: need %zu bytes, got %zu", ws.bytes, workspace_bytes);
+  const bool from_device = step_id == COLLIE_STEP_DEVICE;
+  COLLIE_REQUIRE(step_id >= 1 || from_device, "step_id must be >= 1 (got %d)", step_id);
+  const StepDyn* dyn = from_device ? ws.dyn_cur : nullptr;
+  KindPlan ke, kz;
+  if (mask[0] && plan_kind(ke, t, ws, mask[0], 0, dense, from_device, cfg, state1, state2, row_stamp))
+    return -1;
+  if (mask[1] && plan_kind(kz, t, ws, mask[1], bias_mode, dense, from_device, cfg + 2, state1 + 2,
+                           state2 + 2, row_stamp + 2))
+    return -1;
+  if (small_rows_ok(t, b, dense) && small_descs_ok(mask[0] ? &ke : nullptr)) {
+    if (launch_small_rows(t, b, ws, mask[0] ? &ke : nullptr, mask[1] ? &kz : nullptr, step_id, dyn,
+                          grad_scale, stream))
+      return -2;
+    if (mask[0] && sweep_kind(ke, t, ws, step_id, dyn, 0, stream)) return -2;
+    if (mask[1] && sweep_kind(kz, t, ws, step_id, dyn, 2, stream)) return -2;
+    return 0;
   }
+  // general path: the two ordinary calls (they need collie_mf_train_build_segments first)
+  if (mask[0] && collie_mf_train_update(t, b, workspace, workspace_bytes, mask[0], 0, dense, step_id,
+                                        cfg, state1, state2, row_stamp, grad_scale, stream_))
+    return -2;
+  if (mask[1] && collie_mf_train_update(t, b, workspace, workspace_bytes, mask[1], bias_mode, dense,
+                                        step_id, cfg + 2, state1 + 2, state2 + 2, row_stamp + 2,
+                                        grad_scale, stream_))
+    return -2;
   return 0;
 }
 

@@ -96,7 +96,13 @@ class _FusedStep:
         if not per_side:
             return                      # a table is updated at most once per staged backward
         if not self.segments:
-            ops.train_build_segments(self.tables, self.batch, self.buf)
+            # (small sparse batches are coalesced inside the update launch itself)
+            cache = self.model.__dict__.setdefault('_needs_segments', {})
+            key = (self.batch.batch, bool(dense), id(self.tables))
+            if key not in cache:
+                cache[key] = ops.train_update_needs_segments(self.tables, self.batch, dense)
+            if cache[key]:
+                ops.train_build_segments(self.tables, self.batch, self.buf)
             self.segments = True
         ops.train_update(self.tables, self.batch, self.buf,
                          (2 if self.explicit else 1) if is_bias else 0, dense, self.step_id,

@@ -143,6 +143,34 @@ def train_update(tables, batch, ws_buf, is_bias, dense, step_id, per_side, grad_
         ptr(grad_scale), stream_ptr()), 'collie_mf_train_update')
 
 
+def train_update_needs_segments(tables, batch, dense):
+    """False where ``train_update`` coalesces inside its own launch (small sparse batches)."""
+    rc = load().collie_mf_train_update_needs_segments(byref(tables), byref(batch),
+                                                      1 if dense else 0)
+    check(min(rc, 0), 'collie_mf_train_update_needs_segments')
+    return rc != 0
+
+
+def train_update_all(tables, batch, ws_buf, bias_mode, dense, step_id, per_table, grad_scale=None):
+    """per_table: four entries (user_emb, item_emb, user_bias, item_bias), each ``None`` or
+    ``(OptimCfg, state1, state2, row_stamp)`` (``collie_mf_train_update_all``)."""
+    cfgs = (OptimCfg * 4)()
+    s1, s2, st = (c_void_p * 4)(), (c_void_p * 4)(), (c_void_p * 4)()
+    for i, entry in enumerate(per_table):
+        if entry is None:
+            cfgs[i].algo = -1
+            continue
+        cfg, a, b, c = entry
+        cfgs[i] = cfg
+        s1[i] = a.data_ptr() if a is not None else None
+        s2[i] = b.data_ptr() if b is not None else None
+        st[i] = c.data_ptr() if c is not None else None
+    check(load().collie_mf_train_update_all(
+        byref(tables), byref(batch), ptr(ws_buf), ws_buf.numel(), int(bias_mode),
+        1 if dense else 0, step_id, cfgs, s1, s2, st, ptr(grad_scale), stream_ptr()),
+        'collie_mf_train_update_all')
+
+
 STEP_DEVICE = -1           # COLLIE_STEP_DEVICE
 STEP_SCHEDULE_MAX = 1024   # COLLIE_STEP_SCHEDULE_MAX
 

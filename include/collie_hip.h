@@ -264,6 +264,26 @@ int collie_mf_train_advance_step(const collie_mf_tables* t, const collie_mf_batc
                                  float* loss_out /* NULL unless the forward deferred the loss */,
                                  int32_t* status, collie_stream_t stream);
 
+/* Whether collie_mf_train_update of this batch reads the segments (1) or not (0): sparse
+ * algorithms on batches of at most 1,365 samples (the reference's default is 1,024) with
+ * embedding_dim % 4 == 0 and <= 256 are coalesced inside the update launch itself, and
+ * collie_mf_train_build_segments may be skipped for them (it is harmless to call it).
+ * collie_mf_train_export_grad always needs the segments. */
+int collie_mf_train_update_needs_segments(const collie_mf_tables* t, const collie_mf_batch* b,
+                                          int32_t dense);
+
+/* collie_mf_train_update for the embedding tables AND the bias tables in one call -- one launch
+ * where the sort-free path above applies (a captured step is bound by its number of launches),
+ * otherwise the two ordinary calls.  cfg / state1 / state2 / row_stamp are indexed [user_emb,
+ * item_emb, user_bias, item_bias]; cfg[i].algo = -1: table i is not updated.  bias_mode: the
+ * is_bias value of the bias update (1, or 2 after collie_mf_explicit_forward). */
+int collie_mf_train_update_all(const collie_mf_tables* t, const collie_mf_batch* b, void* workspace,
+                               size_t workspace_bytes, int32_t bias_mode, int32_t dense,
+                               int32_t step_id, const collie_optim_cfg* cfg /*[4]*/,
+                               float* const* state1 /*[4]*/, float* const* state2 /*[4]*/,
+                               int32_t* const* row_stamp /*[4]*/, const float* grad_scale,
+                               collie_stream_t stream);
+
 /* Materialise the coalesced gradient of one table (tests, and `.grad` for callers that ask):
  * rows_out [cap] int64 (sorted unique rows that carry gradient entries), vals_out [cap, dim or 1],
  * count_out [1] int32 (device); cap >= 2 * batch.  touched_out (optional, uint8 [num_items], item
