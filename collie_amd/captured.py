@@ -132,7 +132,9 @@ class CapturedTrainStep:
         per_table = [None if o is None else self._table_args(*o) for o in owners]
         torch.cuda.synchronize(dev)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # thread_local: calls other threads make meanwhile (a DataLoader's pin-memory thread) must
+        # not invalidate the recording
+        with torch.cuda.graph(graph, capture_error_mode='thread_local'):
             # (a second captured stream for the loss and the bias update was tried: the fork / join
             # nodes cost more than the overlap gains -- a replayed step is bound by its node count)
             ops.train_forward(self._tables, self._hbatch, cfg, self._buf, 1 | ops.DEFER_LOSS,
@@ -278,7 +280,14 @@ class CapturedTrainStep:
             if self._graph_key is not None and graph_key[:5] != self._graph_key[:5] and \
                     users.shape[0] < self._graph_key[0]:
                 return None             # the ragged last batch of an epoch: stepped, not recorded
-            self._record(users, pos, neg, owners)
+            try:
+                self._record(users, pos, neg, owners)
+            except RuntimeError:
+                # the recording could not be made here (e.g. another capture is under way): this
+                # object steps every batch the ordinary way from now on
+                self._graph = self._graph_key = None
+                self.max_batch = 0
+                return None
             self._graph_key = self._keys(users, pos, neg, owners)[0]
         # a stepped batch, a new learning rate or an exhausted schedule brought us here
         self._schedule(owners)
