@@ -255,7 +255,7 @@ __device__ __forceinline__ void load_w_slot(const FwdParams& p, int n0, int k0, 
 }
 
 template <int NTILES, bool WVEC, bool ACT>
-__global__ __launch_bounds__(kFBlock) void dense_fwd_fast_kernel(const FwdParams p) {
+__global__ __launch_bounds__(kFBlock, (NTILES == 4 && WVEC && !ACT ? 3 : 1)) void dense_fwd_fast_kernel(const FwdParams p) {
   constexpr int NT = 32 * NTILES;
   constexpr int WSLOTS = NT * kFKC / 4 / kFBlock;  // 16-byte weight slots per thread: 4, 2 or 1
   constexpr int WS = WSLOTS > 0 ? WSLOTS : 1;
