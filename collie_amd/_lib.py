@@ -110,6 +110,10 @@ SIGNATURES = {
                                                   POINTER(OptimCfg), POINTER(c_void_p),
                                                   POINTER(c_void_p), POINTER(c_void_p), c_void_p,
                                                   c_void_p]),
+    'collie_mf_train_step': (ctypes.c_int, [POINTER(Tables), POINTER(Batch), POINTER(LossCfg),
+                                            c_void_p, c_size_t, c_int32, c_int32, c_void_p, c_void_p,
+                                            POINTER(OptimCfg), POINTER(c_void_p), POINTER(c_void_p),
+                                            POINTER(c_void_p), c_void_p]),
     'collie_mf_train_schedule_steps': (ctypes.c_int, [POINTER(Tables), POINTER(Batch), c_void_p,
                                                       c_size_t, c_int32, c_int32, POINTER(OptimCfg),
                                                       c_void_p]),

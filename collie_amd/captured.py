@@ -19,6 +19,8 @@ frozen kernel arguments:
 The optimizers' ``state['step']`` counters, the workspace's step counter and the model's staged-step
 slot are kept exactly as a stepped batch leaves them, so stepped and replayed batches can be mixed.
 """
+from ctypes import byref, c_void_p
+
 import torch
 
 from collie_amd import _lib, ops
@@ -52,7 +54,11 @@ class CapturedTrainStep:
     buffer of the recording: read or accumulate it before the next call.
     """
 
-    def __init__(self, model, optimizers, max_batch=16384):
+    def __init__(self, model, optimizers, max_batch=16384, mode='graph'):
+        # mode 'graph': replay a recorded HIP graph; 'call': the same launches issued by ONE library
+        # call per step (collie_mf_train_step), no recording -- see the measurements in DESIGN.md
+        assert mode in ('graph', 'call')
+        self.mode = mode
         self.model = model
         self.optimizers = list(optimizers)
         self.max_batch = max_batch
@@ -130,6 +136,28 @@ class CapturedTrainStep:
         cfg = model.__dict__.get('_loss_cfg')
         status = model._status_flag()
         per_table = [None if o is None else self._table_args(*o) for o in owners]
+        self._status = status
+        self._loss_cfg = cfg
+        if self.mode == 'call':
+            # nothing is recorded: the argument arrays of collie_mf_train_step, filled once
+            self._cfgs = (_lib.OptimCfg * 4)()
+            self._s1, self._s2, self._st = (c_void_p * 4)(), (c_void_p * 4)(), (c_void_p * 4)()
+            for i, entry in enumerate(per_table):
+                if entry is None:
+                    self._cfgs[i].algo = -1
+                    continue
+                c, a, b, st = entry
+                self._cfgs[i] = c
+                self._s1[i] = a.data_ptr() if a is not None else None
+                self._s2[i] = b.data_ptr() if b is not None else None
+                self._st[i] = st.data_ptr() if st is not None else None
+            self._owned = [i for i, e in enumerate(per_table) if e is not None]
+            self._src = ops.make_batch(self._u, self._p, self._n)
+            self._keep = per_table
+            self._step_fn = _lib.load().collie_mf_train_step
+            self._graph = None
+            self.captures += 1
+            return
         torch.cuda.synchronize(dev)
         graph = torch.cuda.CUDAGraph()
         # thread_local: calls other threads make meanwhile (a DataLoader's pin-memory thread) must
@@ -188,6 +216,13 @@ class CapturedTrainStep:
     def _schedule(self, owners):
         model = self.model
         ws = model._workspace
+        if self.mode == 'call':
+            # by-value steps need no schedule: only the hyper-parameters are read again
+            for i, o in enumerate(owners):
+                if o is not None:
+                    self._cfgs[i] = self._table_args(*o)[0]
+            self._left = 1 << 60
+            return
         cfgs = []
         for o in owners:
             if o is None:
@@ -246,12 +281,26 @@ class CapturedTrainStep:
         src.neg_stride_b = neg.stride(0)
         src.neg_stride_k = neg.stride(1)
         src._keepalive = (users, pos, neg)
-        ops.batch_copy(src, self._hbatch)
         model.__dict__['_staged_step'] = None       # the workspace is overwritten
-        self._graph.replay()
-        self._left -= 1
-        model._workspace.next_step()
-        sig = self._next_sig                        # what the next call must find: one step on
+        sig = self._next_sig
+        if self.mode == 'call':
+            step_id = model._workspace.next_step()
+            at = len(sig) - 2 * len(self._owned)
+            cfgs = self._cfgs
+            for i in self._owned:                   # this step's 1-based count of each table
+                cfgs[i].step = sig[at] + 1
+                at += 2
+            buf = self._buf
+            _lib.check(self._step_fn(byref(self._tables), byref(src), byref(self._loss_cfg),
+                                     buf.data_ptr(), buf.numel(), step_id, 0,
+                                     self._loss.data_ptr(), self._status.data_ptr(), cfgs, self._s1,
+                                     self._s2, self._st, _lib.stream_ptr()), 'collie_mf_train_step')
+        else:
+            ops.batch_copy(src, self._hbatch)
+            self._graph.replay()
+            self._left -= 1
+            model._workspace.next_step()
+        # what the next call must find: one step on
         sig[self._STEP_AT] += 1
         at = len(sig) - 2 * sum(o is not None for o in owners)
         for o in owners:

@@ -1140,6 +1140,26 @@ extern "C" int collie_mf_train_update_all(const collie_mf_tables* t, const colli
   return 0;
 }
 
+// The whole loop body of the trainers (trainer.py:458-470) for one batch in ONE call: forward,
+// coalesce (where the update needs it), every table update.  For launch-bound batch sizes the host
+// side of a step is then one FFI call.
+extern "C" int collie_mf_train_step(const collie_mf_tables* t, const collie_mf_batch* b,
+                                    const collie_loss_cfg* loss, void* workspace,
+                                    size_t workspace_bytes, int32_t step_id, int32_t dense,
+                                    float* loss_out, int32_t* status, const collie_optim_cfg* cfg,
+                                    float* const* state1, float* const* state2,
+                                    int32_t* const* row_stamp, collie_stream_t stream) {
+  int rc = collie_mf_train_forward(t, b, loss, workspace, workspace_bytes, 1, step_id, loss_out,
+                                   nullptr, nullptr, status, stream);
+  if (rc) return rc;
+  if (!small_rows_ok(t, b, dense)) {
+    rc = collie_mf_train_build_segments(t, b, workspace, workspace_bytes, stream);
+    if (rc) return rc;
+  }
+  return collie_mf_train_update_all(t, b, workspace, workspace_bytes, 1, dense, step_id, cfg, state1,
+                                    state2, row_stamp, nullptr, stream);
+}
+
 // ---- captured-step replay --------------------------------------------------------------------------
 namespace collie {
 namespace {

@@ -219,6 +219,18 @@ int collie_mf_train_update(const collie_mf_tables* t, const collie_mf_batch* b, 
                            int32_t* const* row_stamp /*[2]*/, const float* grad_scale,
                            collie_stream_t stream);
 
+/* The trainers' loop body for one batch (trainer.py:458-470: calculate_loss, backward, every
+ * optimizer.step) in ONE call: collie_mf_train_forward + collie_mf_train_build_segments (where
+ * needed) + collie_mf_train_update_all, with grad_output = 1.  Arrays indexed [user_emb, item_emb,
+ * user_bias, item_bias]; cfg[i].algo = -1: table i is not updated; cfg[i].step: that table's
+ * 1-based step count.  For launch-bound batch sizes the host side of a step is one FFI call. */
+int collie_mf_train_step(const collie_mf_tables* t, const collie_mf_batch* b,
+                         const collie_loss_cfg* loss, void* workspace, size_t workspace_bytes,
+                         int32_t step_id, int32_t dense, float* loss_out, int32_t* status,
+                         const collie_optim_cfg* cfg /*[4]*/, float* const* state1 /*[4]*/,
+                         float* const* state2 /*[4]*/, int32_t* const* row_stamp /*[4]*/,
+                         collie_stream_t stream);
+
 /* ---- replaying a captured training step -----------------------------------------------------------
  * The loop body of the trainers (collie/model/base/trainer.py:458-470: zero_grad, training_step,
  * backward, optimizer.step for every optimizer) is, on this path, a fixed sequence of kernel

@@ -50,20 +50,21 @@ def _state_equal(ma, oa, mb, ob):
                     assert sa[k] == sb[k], k
 
 
+@pytest.mark.parametrize('mode', ['graph', 'call'])
 @pytest.mark.parametrize('optimizer,bias_optimizer,K,steps', [
     ('sparse_adam', 'sgd', 10, 300),        # crosses the 255-step stamp-tag cycle
     ('adagrad', 'adagrad', 1, 40),
     ('sgd', 'sgd', 5, 40),
     ('sparse_adam', 'sparse_adam', 4, 60),
 ])
-def test_replayed_steps_are_bit_identical_to_stepped_ones(optimizer, bias_optimizer, K, steps):
+def test_replayed_steps_are_bit_identical_to_stepped_ones(optimizer, bias_optimizer, K, steps, mode):
     from collie_amd.captured import CapturedTrainStep
     dev = torch.device('cuda:0')
     U, N, D, B = 700, 300, 64, 256
     ma, oa = _model(U, N, K, D, optimizer, bias_optimizer, dev)
     mb, ob = _model(U, N, K, D, optimizer, bias_optimizer, dev)
     _state_equal(ma, oa, mb, ob)
-    replay = CapturedTrainStep(mb, ob)
+    replay = CapturedTrainStep(mb, ob, mode=mode)
     g = torch.Generator(device='cpu').manual_seed(11)
     replayed = 0
     for i in range(steps):

@@ -28,7 +28,7 @@ def main():
         num_users, num_items, num_negative_samples = U, N, K
 
     out = {'batch': B, 'steps': args.steps}
-    for mode in ('stepped', 'replayed'):
+    for mode in ('stepped', 'replayed', 'one_call'):
         torch.manual_seed(0)
         with torch.device(dev):
             model = MatrixFactorizationModel(train=Shape(), embedding_dim=D, sparse=True,
@@ -40,10 +40,10 @@ def main():
         batches = [((torch.randint(0, U, (B,), device=dev, dtype=torch.int32),
                      torch.randint(0, N, (B,), device=dev, dtype=torch.int32)),
                     torch.randint(0, N, (B, K), device=dev)) for _ in range(8)]
-        replay = CapturedTrainStep(model, opts)
+        replay = CapturedTrainStep(model, opts, mode='call' if mode == 'one_call' else 'graph')
 
         def step(i):
-            if mode == 'replayed':
+            if mode != 'stepped':
                 loss = replay(batches[i % 8])
                 if loss is not None:
                     return
@@ -66,8 +66,9 @@ def main():
         out[mode] = {'us_per_step': wall / args.steps * 1e6,
                      'host_us_per_step': host / args.steps * 1e6,
                      'interactions_per_s': B * (K + 1) * args.steps / wall}
-        if mode == 'replayed':
+        if mode != 'stepped':
             out[mode]['replays'] = replay.replays
+        if mode == 'replayed':
             # the recording alone, batch already in its buffers: the GPU time of the step
             torch.cuda.synchronize()
             t0 = time.perf_counter()
