@@ -181,6 +181,37 @@ EVAL_USERS, EVAL_ITEMS, EVAL_DIM, EVAL_POS = 1_000_000, 1_000_000, 128, 10
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA (exact fp32 products)
 
 
+def small_batch_leg(device, batch=1024, steps=3000):
+    """The reference's default batch size (trainer / loaders: 1,024) on configs[1]'s shape: the step
+    through the product API launch by launch, and as CollieMinimalTrainer runs it (the whole loop
+    body as one library call, collie_amd/captured.py)."""
+    from collie_amd.captured import CapturedTrainStep
+    set_shape('c2')
+    out = {'workload': f'BASELINE configs[1] shape, B = {batch} (the reference\'s default batch size)',
+           'steps': steps}
+    for mode in ('stepped', 'one_call'):
+        model = build_model(device)
+        optimizers = model.configure_optimizers()
+        batches = synthetic_batches(8, batch, device, 'uniform', seed=99)
+        fused = CapturedTrainStep(model, optimizers, mode='call') if mode == 'one_call' else None
+
+        def step(i):
+            if fused is None or fused(batches[i % 8]) is None:
+                train_step(model, optimizers, batches[i % 8])
+
+        for i in range(300):
+            step(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        out[mode] = {'us_per_step': dt * 1e6, 'interactions_per_s': batch * (1 + NUM_NEG) / dt}
+        del model, optimizers
+    return out
+
+
 def eval_leg(device, n_users, sharded_world=1, group_rank=0):
     """evaluate_in_batches([mapk], k=10) on configs[2]'s shape for a sample of ``n_users`` users."""
     from collie_amd import metrics as M
@@ -419,6 +450,8 @@ def main():
     ap.add_argument('--hybrid-steps', type=int, default=10,
                     help="steps of the configs[4] leg (hybrid MLP head, reported under 'hybrid'; "
                          '0 = skip it; single-GPU runs only)')
+    ap.add_argument('--small-batch-steps', type=int, default=3000,
+                    help="steps of the B = 1,024 leg reported under 'b1024' (0 = skip it)")
     ap.add_argument('--c4-steps', type=int, default=10,
                     help="steps of the configs[3]-tables-on-one-GPU leg reported under 'c4' (the "
                          'HBM-resident shape; 0 = skip it; default shape only)')
@@ -462,6 +495,8 @@ def main():
                                                'config', 'roofline')}
         else:
             result['c4'] = {'skipped': f'{free / 2 ** 30:.0f} GiB of HBM free, the leg needs 190'}
+    if args.small_batch_steps > 0 and args.shape == 'c2':
+        result['b1024'] = small_batch_leg(device, 1024, args.small_batch_steps)
     if args.eval_users > 0:
         result['eval'] = eval_leg(device, args.eval_users)
     if args.hybrid_steps > 0 and args.shape == 'c2':

@@ -35,18 +35,22 @@ struct Hyper {
 };
 
 // One element of torch's update. g already includes grad_scale.  Returns the new parameter.
-__device__ __forceinline__ float apply_update(const Hyper& h, float p, float g, float& s1,
-                                              float& s2) {
+// neg_lr / bc2_sqrt are passed apart from the rest of Hyper: they are the two step-dependent
+// scalars, which a replayed step reads from device memory (the row kernels keep reading everything
+// else through the table descriptor: selecting whole Hyper structs per lane made `algo` a per-lane
+// value and the switch below divergent -- emb_rows_kernel 2.2 -> 2.9 ms on the 100 M x 10 M shape).
+__device__ __forceinline__ float apply_update2(const Hyper& h, float neg_lr, float bc2_sqrt, float p,
+                                               float g, float& s1, float& s2) {
   switch (h.algo) {
     case COLLIE_OPT_SGD: {
       if (h.dense && h.weight_decay != 0.0f) g = g + h.weight_decay * p;
-      return p + h.neg_lr * g;
+      return p + neg_lr * g;
     }
     case COLLIE_OPT_ADAGRAD: {
       if (h.dense && h.weight_decay != 0.0f) g = g + h.weight_decay * p;
       s1 = s1 + g * g;
       const float std_ = sqrtf(s1) + h.eps;
-      return p + h.neg_lr * (g / std_);
+      return p + neg_lr * (g / std_);
     }
     case COLLIE_OPT_SPARSE_ADAM: {
       const float um = (g - s1) * h.c1;
@@ -54,15 +58,15 @@ __device__ __forceinline__ float apply_update(const Hyper& h, float p, float g, 
       s1 = s1 + um;
       s2 = s2 + uv;
       const float denom = sqrtf(s2) + h.eps;
-      return p + h.neg_lr * (s1 / denom);
+      return p + neg_lr * (s1 / denom);
     }
     default: {  // COLLIE_OPT_ADAM (dense)
       if (h.weight_decay != 0.0f) g = g + h.weight_decay * p;
       s1 = s1 + h.c1 * (g - s1);                 // exp_avg.lerp_(grad, 1 - beta1)
       s2 = s2 * h.beta2;                         // exp_avg_sq.mul_(beta2)
       s2 = s2 + h.c2 * (g * g);                  //            .addcmul_(grad, grad, 1 - beta2)
-      const float denom = sqrtf(s2) / h.bc2_sqrt + h.eps;
-      return p + h.neg_lr * (s1 / denom);
+      const float denom = sqrtf(s2) / bc2_sqrt + h.eps;
+      return p + neg_lr * (s1 / denom);
     }
   }
 }
@@ -74,6 +78,11 @@ __device__ __forceinline__ Hyper dyn_hyper(Hyper h, const StepDyn* dyn, int idx)
     h.bc2_sqrt = dyn->bc2_sqrt[idx];
   }
   return h;
+}
+
+__device__ __forceinline__ float apply_update(const Hyper& h, float p, float g, float& s1,
+                                              float& s2) {
+  return apply_update2(h, h.neg_lr, h.bc2_sqrt, p, g, s1, s2);
 }
 
 struct TableDesc {
@@ -226,7 +235,11 @@ __global__ __launch_bounds__(kBlock) void emb_rows_kernel(const UpdParams p) {
   const uint32_t nseg = p.nseg[0];
   const uint32_t first1 = p.nseg[1];
   const float scale = p.grad_scale ? *p.grad_scale : 1.0f;
-  const Hyper h0 = dyn_hyper(p.d[0].h, p.dyn, p.dyn_base), h1 = dyn_hyper(p.d[1].h, p.dyn, p.dyn_base + 1);
+  // the two step-dependent scalars of each side (uniform); everything else of Hyper through t.h
+  const float nl0 = p.dyn ? p.dyn->neg_lr[p.dyn_base] : p.d[0].h.neg_lr;
+  const float nl1 = p.dyn ? p.dyn->neg_lr[p.dyn_base + 1] : p.d[1].h.neg_lr;
+  const float bc0 = p.dyn ? p.dyn->bc2_sqrt[p.dyn_base] : p.d[0].h.bc2_sqrt;
+  const float bc1 = p.dyn ? p.dyn->bc2_sqrt[p.dyn_base + 1] : p.d[1].h.bc2_sqrt;
   const int step = p.dyn ? p.dyn->step : p.step;
   const int D = p.D;
   const int nchunks = (D + VEC - 1) / VEC;
@@ -323,7 +336,8 @@ __global__ __launch_bounds__(kBlock) void emb_rows_kernel(const UpdParams p) {
           RVec<VEC> np;
 #pragma unroll
           for (int i = 0; i < VEC; ++i)
-            np.v[i] = apply_update(side ? h1 : h0, pv.v[i], g.v[i], s1.v[i], s2.v[i]);
+            np.v[i] = apply_update2(t.h, side ? nl1 : nl0, side ? bc1 : bc0, pv.v[i], g.v[i], s1.v[i],
+                                    s2.v[i]);
           rstore<VEC>(t.table + off, np);
           if (t.s1) rstore<VEC>(t.s1 + off, s1);
           if (t.s2) rstore<VEC>(t.s2 + off, s2);
@@ -351,7 +365,10 @@ __global__ __launch_bounds__(kBlock) void bias_rows_kernel(const UpdParams p) {
   const uint32_t nseg = p.nseg[0];
   const uint32_t first1 = p.nseg[1];
   const float scale = p.grad_scale ? *p.grad_scale : 1.0f;
-  const Hyper h0 = dyn_hyper(p.d[0].h, p.dyn, p.dyn_base), h1 = dyn_hyper(p.d[1].h, p.dyn, p.dyn_base + 1);
+  const float nl0 = p.dyn ? p.dyn->neg_lr[p.dyn_base] : p.d[0].h.neg_lr;
+  const float nl1 = p.dyn ? p.dyn->neg_lr[p.dyn_base + 1] : p.d[1].h.neg_lr;
+  const float bc0 = p.dyn ? p.dyn->bc2_sqrt[p.dyn_base] : p.d[0].h.bc2_sqrt;
+  const float bc1 = p.dyn ? p.dyn->bc2_sqrt[p.dyn_base + 1] : p.d[1].h.bc2_sqrt;
   const int step = p.dyn ? p.dyn->step : p.step;
   const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
   if (EXPORT && blockIdx.x == 0 && threadIdx.x == 0)
@@ -396,7 +413,7 @@ __global__ __launch_bounds__(kBlock) void bias_rows_kernel(const UpdParams p) {
       } else {
         float s1 = t.s1 ? t.s1[row] : 0.0f;
         float s2 = t.s2 ? t.s2[row] : 0.0f;
-        t.table[row] = apply_update(side ? h1 : h0, t.table[row], g, s1, s2);
+        t.table[row] = apply_update2(t.h, side ? nl1 : nl0, side ? bc1 : bc0, t.table[row], g, s1, s2);
         if (t.s1) t.s1[row] = s1;
         if (t.s2) t.s2[row] = s2;
         if (t.row_stamp) t.row_stamp[row] = step;
@@ -539,19 +556,21 @@ __global__ __launch_bounds__(kBlock) void small_rows_kernel(const SmallParams p)
   const float scale = p.grad_scale ? *p.grad_scale : 1.0f;
   const int step = p.dyn ? p.dyn->step : p.step;
   if (et.table && on) {
-    const Hyper h = dyn_hyper(et.h, p.dyn, side);
-    pv.x = apply_update(h, pv.x, acc.x * scale, s1.x, s2.x);
-    pv.y = apply_update(h, pv.y, acc.y * scale, s1.y, s2.y);
-    pv.z = apply_update(h, pv.z, acc.z * scale, s1.z, s2.z);
-    pv.w = apply_update(h, pv.w, acc.w * scale, s1.w, s2.w);
+    const float nl = p.dyn ? p.dyn->neg_lr[side] : et.h.neg_lr;
+    const float bc = p.dyn ? p.dyn->bc2_sqrt[side] : et.h.bc2_sqrt;
+    pv.x = apply_update2(et.h, nl, bc, pv.x, acc.x * scale, s1.x, s2.x);
+    pv.y = apply_update2(et.h, nl, bc, pv.y, acc.y * scale, s1.y, s2.y);
+    pv.z = apply_update2(et.h, nl, bc, pv.z, acc.z * scale, s1.z, s2.z);
+    pv.w = apply_update2(et.h, nl, bc, pv.w, acc.w * scale, s1.w, s2.w);
     *reinterpret_cast<float4*>(et.table + off) = pv;
     if (et.s1) *reinterpret_cast<float4*>(et.s1 + off) = s1;
     if (et.s2) *reinterpret_cast<float4*>(et.s2 + off) = s2;
   }
   if (lig == 0) {
     if (zt.table) {
-      const Hyper h = dyn_hyper(zt.h, p.dyn, 2 + side);
-      zt.table[row] = apply_update(h, zp, zacc * scale, zs1, zs2);
+      const float nl = p.dyn ? p.dyn->neg_lr[2 + side] : zt.h.neg_lr;
+      const float bc = p.dyn ? p.dyn->bc2_sqrt[2 + side] : zt.h.bc2_sqrt;
+      zt.table[row] = apply_update2(zt.h, nl, bc, zp, zacc * scale, zs1, zs2);
       if (zt.s1) zt.s1[row] = zs1;
       if (zt.s2) zt.s2[row] = zs2;
       if (zt.seg_stamp) zt.seg_stamp[row] = step;
