@@ -342,6 +342,7 @@ def main_sharded(args, world, rank, device):
                                             'same tables and global batch on one GPU, fused route',
                 'final_loss': float(loss.item()),
                 'rows_exchanged_per_rank_per_step': model.last_exchange.get('rows_requested'),
+                'gradient_rows_sent_per_rank_per_step': model.last_gradient_rows,
                 'phase_ms_rank0': phases,
             },
             'roofline': None,

@@ -130,6 +130,12 @@ SIGNATURES = {
                                                       POINTER(OptimCfg), POINTER(OptimCfg), c_void_p,
                                                       c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                                       c_void_p, c_void_p]),
+    'collie_sparse_rows_update_pair_indexed': (ctypes.c_int, [c_void_p, c_void_p, c_int64, c_int32,
+                                                              c_void_p, c_int32, c_void_p, c_void_p,
+                                                              c_void_p, c_int64, POINTER(OptimCfg),
+                                                              POINTER(OptimCfg), c_void_p, c_void_p,
+                                                              c_void_p, c_void_p, c_void_p, c_size_t,
+                                                              c_void_p, c_void_p]),
     'collie_shard_plan_workspace_bytes': (c_size_t, [c_int64, c_int64, c_int32]),
     'collie_shard_plan': (ctypes.c_int, [POINTER(Batch), c_int64, c_int64, c_int32, c_int32,
                                          c_void_p, c_size_t, c_void_p, c_void_p, c_void_p,

@@ -710,9 +710,12 @@ __global__ __launch_bounds__(kBlock) void export_touched_kernel(const uint8_t* _
 }
 
 // entries of a stand-alone sparse gradient: key = row id (clamped), code = position in vals
+// (val_index == NULL: entry i owns vals row i; else vals row val_index[i], < 0: a looked-up row with
+// a zero gradient, which is touched but reads nothing)
 __global__ __launch_bounds__(kBlock) void coo_entries_kernel(const void* __restrict__ rows,
                                                              int dtype, int64_t m,
                                                              int64_t num_rows,
+                                                             const int32_t* __restrict__ val_index,
                                                              uint32_t* __restrict__ ekeys,
                                                              uint32_t* __restrict__ ecodes,
                                                              int32_t* __restrict__ status) {
@@ -720,6 +723,7 @@ __global__ __launch_bounds__(kBlock) void coo_entries_kernel(const void* __restr
   if (i >= m) return;
   int64_t r = load_idx(rows, dtype, i);
   uint32_t code = static_cast<uint32_t>(i);
+  if (val_index) code = val_index[i] < 0 ? kCodeNone : static_cast<uint32_t>(val_index[i]);
   if (r < 0 || r >= num_rows) {
     if (status) atomicOr(status, 1);
     r = 0;
@@ -1356,8 +1360,8 @@ extern "C" int collie_sparse_rows_update(float* table, int64_t num_rows, int32_t
                  "workspace too small: need %zu bytes, got %zu", align_up(c.off, 256),
                  workspace_bytes);
   hipLaunchKernelGGL(coo_entries_kernel, dim3(static_cast<unsigned>((m + kBlock - 1) / kBlock)),
-                     dim3(kBlock), 0, stream, rows, rows_dtype, m, num_rows, s.ekeys, s.ecodes,
-                     status);
+                     dim3(kBlock), 0, stream, rows, rows_dtype, m, num_rows, nullptr, s.ekeys,
+                     s.ecodes, status);
   if (check_launch("coo_entries_kernel")) return -2;
   if (sort_and_segment(s, num_rows, 0xffffffffu, stream)) return -1;
   UpdParams p;
@@ -1383,9 +1387,9 @@ extern "C" int collie_sparse_rows_update(float* table, int64_t num_rows, int32_t
   return launch_emb<false>(p, m, stream);
 }
 
-extern "C" int collie_sparse_rows_update_pair(float* table, float* bias_table, int64_t num_rows,
-                                              int32_t dim, const void* rows, int32_t rows_dtype,
-                                              const float* vals, const float* bias_vals, int64_t m,
+extern "C" int collie_sparse_rows_update_pair_indexed(
+    float* table, float* bias_table, int64_t num_rows, int32_t dim, const void* rows,
+    int32_t rows_dtype, const int32_t* val_index, const float* vals, const float* bias_vals, int64_t m,
                                               const collie_optim_cfg* cfg,
                                               const collie_optim_cfg* bias_cfg, float* state1,
                                               float* state2, float* bias_state1, float* bias_state2,
@@ -1406,8 +1410,8 @@ extern "C" int collie_sparse_rows_update_pair(float* table, float* bias_table, i
                  "workspace too small: need %zu bytes, got %zu", align_up(c.off, 256),
                  workspace_bytes);
   hipLaunchKernelGGL(coo_entries_kernel, dim3(static_cast<unsigned>((m + kBlock - 1) / kBlock)),
-                     dim3(kBlock), 0, stream, rows, rows_dtype, m, num_rows, s.ekeys, s.ecodes,
-                     status);
+                     dim3(kBlock), 0, stream, rows, rows_dtype, m, num_rows, val_index, s.ekeys,
+                     s.ecodes, status);
   if (check_launch("coo_entries_kernel")) return -2;
   if (sort_and_segment(s, num_rows, 0xffffffffu, stream)) return -1;
   // the two tables share the row list, so one coalesce serves both updates
@@ -1436,6 +1440,20 @@ extern "C" int collie_sparse_rows_update_pair(float* table, float* bias_table, i
     hipLaunchKernelGGL(piece_bias_kernel<false>, dim3(piece_bias_grid(m)), dim3(kBlock), 0, stream, q);
   hipLaunchKernelGGL(bias_rows_kernel<false>, dim3(bias_grid(m)), dim3(kBlock), 0, stream, q);
   return check_launch("sparse_rows_update_pair");
+}
+
+extern "C" int collie_sparse_rows_update_pair(float* table, float* bias_table, int64_t num_rows,
+                                              int32_t dim, const void* rows, int32_t rows_dtype,
+                                              const float* vals, const float* bias_vals, int64_t m,
+                                              const collie_optim_cfg* cfg,
+                                              const collie_optim_cfg* bias_cfg, float* state1,
+                                              float* state2, float* bias_state1, float* bias_state2,
+                                              void* workspace, size_t workspace_bytes,
+                                              int32_t* status, collie_stream_t stream) {
+  return collie_sparse_rows_update_pair_indexed(table, bias_table, num_rows, dim, rows, rows_dtype,
+                                                nullptr, vals, bias_vals, m, cfg, bias_cfg, state1,
+                                                state2, bias_state1, bias_state2, workspace,
+                                                workspace_bytes, status, stream);
 }
 
 // ---- dense-gradient variants (hybrid head) -----------------------------------
@@ -1500,8 +1518,8 @@ extern "C" int collie_dense_rows_update(float* table, int64_t num_rows, int32_t 
                  "workspace too small: need %zu bytes, got %zu", align_up(c.off, 256),
                  workspace_bytes);
   hipLaunchKernelGGL(coo_entries_kernel, dim3(static_cast<unsigned>((m + kBlock - 1) / kBlock)),
-                     dim3(kBlock), 0, stream, rows, rows_dtype, m, num_rows, s.ekeys, s.ecodes,
-                     status);
+                     dim3(kBlock), 0, stream, rows, rows_dtype, m, num_rows, nullptr, s.ekeys,
+                     s.ecodes, status);
   if (check_launch("coo_entries_kernel")) return -2;
   if (sort_and_segment(s, num_rows, 0xffffffffu, stream)) return -1;
   UpdParams p;

@@ -254,7 +254,7 @@ def sparse_rows_update(table, rows, vals, cfg, state1=None, state2=None, status=
 
 
 def sparse_rows_update_pair(table, bias_table, rows, vals, bias_vals, cfg, bias_cfg, state,
-                            bias_state, status=None, workspace=None):
+                            bias_state, status=None, workspace=None, val_index=None):
     """``sparse_rows_update`` for an embedding table and its bias table over one row list: one
     coalesce, two updates (``collie_sparse_rows_update_pair``).  state = (state1, state2)."""
     require_hip(table, 'table')
@@ -268,11 +268,14 @@ def sparse_rows_update_pair(table, bias_table, rows, vals, bias_vals, cfg, bias_
     need = int(load().collie_sparse_rows_workspace_bytes(m, dim))
     if workspace is None or workspace.numel() < need:
         workspace = torch.empty(need, dtype=torch.uint8, device=table.device)
-    check(load().collie_sparse_rows_update_pair(
-        ptr(table), ptr(bias_table), table.shape[0], dim, ptr(rows), idx_dtype(rows), ptr(vals),
-        ptr(bias_vals), m, byref(cfg), byref(bias_cfg), ptr(state[0]), ptr(state[1]),
-        ptr(bias_state[0]), ptr(bias_state[1]), ptr(workspace), workspace.numel(), ptr(status),
-        stream_ptr()), 'collie_sparse_rows_update_pair')
+    if val_index is not None:
+        assert val_index.dtype == torch.int32 and val_index.shape[0] == m
+        val_index = val_index.contiguous()
+    check(load().collie_sparse_rows_update_pair_indexed(
+        ptr(table), ptr(bias_table), table.shape[0], dim, ptr(rows), idx_dtype(rows),
+        ptr(val_index), ptr(vals), ptr(bias_vals), m, byref(cfg), byref(bias_cfg), ptr(state[0]),
+        ptr(state[1]), ptr(bias_state[0]), ptr(bias_state[1]), ptr(workspace), workspace.numel(),
+        ptr(status), stream_ptr()), 'collie_sparse_rows_update_pair_indexed')
     return workspace
 
 

@@ -153,13 +153,19 @@ class HipEngine:
         self._rows_ws = ops.sparse_rows_update(table, rows, vals, cfg, s1, s2, self._status,
                                                self._rows_ws)
 
-    def rows_update_pair(self, emb, bias, rows, gemb, gbias, algos, step, lrs, states, hypers):
-        """Embedding rows and their bias rows share the row list: one coalesce, two updates."""
+    def rows_update_pair(self, emb, bias, rows, gemb, gbias, algos, step, lrs, states, hypers,
+                         val_index=None):
+        """Embedding rows and their bias rows share the row list: one coalesce, two updates.
+        val_index: row of gemb / gbias that belongs to each entry of ``rows`` (-1: zero gradient)."""
+        if val_index is not None and gemb.shape[0] == 0:
+            gemb = torch.zeros(1, emb.shape[1], dtype=torch.float32, device=emb.device)
+            gbias = torch.zeros(1, dtype=torch.float32, device=emb.device)
         cfgs = [ops.optim_cfg(a, step, lr, h.get('beta1', 0.9), h.get('beta2', 0.999), h['eps'], 0.0,
                               h.get('lr_decay', 0.0)) for a, lr, h in zip(algos, lrs, hypers)]
         st = [(s.get('exp_avg', s.get('sum')), s.get('exp_avg_sq')) for s in states]
         self._rows_ws = ops.sparse_rows_update_pair(emb, bias, rows, gemb, gbias, cfgs[0], cfgs[1],
-                                                    st[0], st[1], self._status, self._rows_ws)
+                                                    st[0], st[1], self._status, self._rows_ws,
+                                                    val_index=val_index)
 
     # ---- catalog-sharded evaluation --------------------------------------------------------------
     def _eval_tables(self, utile, ubias, iemb, ibias):
@@ -211,6 +217,13 @@ class HipEngine:
 
 
 # ---- collectives ---------------------------------------------------------------------------------
+def _cumsum(values):
+    total = 0
+    for v in values:
+        total += v
+        yield total
+
+
 class _Comm:
     """
     The few collectives the path needs; world size 1 needs no process group at all.  Backend
@@ -381,6 +394,10 @@ class ShardedMatrixFactorizationModel:
         self._codes, self._weights = loss_mod.metadata_to_codes(
             metadata_for_loss, metadata_for_loss_weights, dev)
         self.last_exchange = {}
+        # send home only the gradient rows that are not zero (see _send_nonzero_gradients); with one
+        # rank nothing travels, so the dense hand-over stays
+        self.compress_gradients = self.comm.world > 1
+        self.last_gradient_rows = None
         self._ahead = None          # (batch tensors, plan, ready event) of plan_ahead()
         self._plan_stream = None
 
@@ -658,17 +675,31 @@ class ShardedMatrixFactorizationModel:
                                             self._weights, scale)
         # 5. gradients home
         mark('gradient_exchange')
-        grows = comm.all_to_all(gemb, p['send_splits'], p['recv_splits'])
-        gb = comm.all_to_all(gbias, p['send_splits'], p['recv_splits'])
+        val_index = None
+        if self.compress_gradients:
+            grows, gb, val_index = self._send_nonzero_gradients(p, gemb, gbias, crow)
+        else:
+            grows = comm.all_to_all(gemb, p['send_splits'], p['recv_splits'])
+            gb = comm.all_to_all(gbias, p['send_splits'], p['recv_splits'])
         # 6. owners update
         mark('owner_update')
         self.steps += 1
         hp = self.hparams
-        if crow.shape[0] > 0 and hasattr(eng, 'rows_update_pair') and D >= 2:
+        pair = hasattr(eng, 'rows_update_pair') and D >= 2
+        if val_index is not None and not pair:
+            # engines without the indexed update: the received rows back in request order
+            full = torch.zeros(crow.shape[0], D, dtype=torch.float32, device=dev)
+            fullb = torch.zeros(crow.shape[0], dtype=torch.float32, device=dev)
+            at = torch.nonzero(val_index >= 0).reshape(-1)
+            full[at] = grows[val_index[at].long()]
+            fullb[at] = gb[val_index[at].long()]
+            grows, gb, val_index = full, fullb, None
+        if crow.shape[0] > 0 and pair:
             eng.rows_update_pair(self.emb, self.bias, crow, grows, gb,
                                  (hp['optimizer'], hp['bias_optimizer']), self.steps,
                                  (hp['lr'], hp['bias_lr']), (self.state['emb'], self.state['bias']),
-                                 (self._HYPER[hp['optimizer']], self._HYPER[hp['bias_optimizer']]))
+                                 (self._HYPER[hp['optimizer']], self._HYPER[hp['bias_optimizer']]),
+                                 val_index=val_index)
         elif crow.shape[0] > 0:
             eng.rows_update(self.emb, crow, grows, hp['optimizer'], self.steps, hp['lr'],
                             self.state['emb'], self._HYPER[hp['optimizer']])
@@ -679,6 +710,42 @@ class ShardedMatrixFactorizationModel:
         self.last_exchange = dict(rows_requested=n, rows_served=int(crow.shape[0]),
                                   bytes_each_way=n * (D + 1) * 4)
         return total.reshape(())
+
+    def _send_nonzero_gradients(self, p, gemb, gbias, crow):
+        """
+        Step 5 with only the gradient rows that are not zero on the wire.  Every loss gives at most
+        one negative of a sample a gradient, so of the (2 + K) rows a sample looks up only three
+        can carry one: with K = 10 three quarters of the dense exchange would be zeros.  The owner
+        already knows which rows were looked up (the request lists of step 2: those are the rows
+        SparseAdam must touch), so a requester sends, per owner, the positions inside its request
+        list whose gradient is not zero, and those rows.  Costs one more count exchange and host
+        read-back per step.  Returns (rows [mv, D], bias values [mv], val_index [len(crow)] int32:
+        the received row of every served row, -1 = zero gradient).
+        """
+        comm, G, dev = self.comm, self.comm.world, gemb.device
+        n = gemb.shape[0]
+        nz = (gemb != 0).any(dim=1) | (gbias != 0)
+        bounds = torch.tensor([0] + list(_cumsum(p['send_splits'])), dtype=torch.int64, device=dev)
+        csum = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(nz, 0, out=csum[1:])
+        cnt_send = csum[bounds[1:]] - csum[bounds[:-1]]
+        cnt_recv = comm.all_to_all(cnt_send, [1] * G, [1] * G)
+        send_c, recv_c = torch.stack([cnt_send, cnt_recv]).cpu().tolist()
+        idx = torch.nonzero(nz).reshape(-1)               # ascending = grouped by owner
+        owner = torch.bucketize(idx, bounds[1:], right=True)
+        pos = idx - bounds[owner]                         # position inside that owner's request list
+        rpos = comm.all_to_all(pos, send_c, recv_c)
+        grows = comm.all_to_all(gemb.index_select(0, idx), send_c, recv_c)
+        gb = comm.all_to_all(gbias.index_select(0, idx), send_c, recv_c)
+        # served row of every received gradient row: offset of the peer's request list + position
+        roff = torch.tensor([0] + list(_cumsum(p['recv_splits']))[:-1], dtype=torch.int64, device=dev)
+        peer = torch.repeat_interleave(torch.arange(G, device=dev),
+                                       torch.tensor(recv_c, dtype=torch.int64, device=dev))
+        served = roff[peer] + rpos
+        val_index = torch.full((crow.shape[0],), -1, dtype=torch.int32, device=dev)
+        val_index[served] = torch.arange(served.shape[0], dtype=torch.int32, device=dev)
+        self.last_gradient_rows = int(idx.shape[0])
+        return grows, gb, val_index
 
     # ---- evaluation --------------------------------------------------------------------------------
     def _user_tile(self, uids):

@@ -329,6 +329,22 @@ int collie_sparse_rows_update_pair(float* table, float* bias_table, int64_t num_
                                    float* bias_state1, float* bias_state2, void* workspace,
                                    size_t workspace_bytes, int32_t* status, collie_stream_t stream);
 
+/* collie_sparse_rows_update_pair with the gradient values given indirectly: entry e of `rows` owns
+ * row val_index[e] of vals / bias_vals, or no value at all if val_index[e] < 0 -- a row that was
+ * looked up but received a zero gradient: it is still touched (SparseAdam decays its moments), but
+ * nothing is read for it.  The row-sharded step sends home only the gradient rows that are not zero
+ * (about a quarter of the looked-up rows with 10 negatives per positive) and the owner marks the
+ * rest of the rows it served this way.  val_index == NULL: the identity. */
+int collie_sparse_rows_update_pair_indexed(float* table, float* bias_table, int64_t num_rows,
+                                           int32_t dim, const void* rows, int32_t rows_dtype,
+                                           const int32_t* val_index, const float* vals,
+                                           const float* bias_vals, int64_t m,
+                                           const collie_optim_cfg* cfg,
+                                           const collie_optim_cfg* bias_cfg, float* state1,
+                                           float* state2, float* bias_state1, float* bias_state2,
+                                           void* workspace, size_t workspace_bytes, int32_t* status,
+                                           collie_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Row-sharded training, requester side (no counterpart in the reference, which has no multi-GPU
  * path for the tables: SURVEY.md 8e).  Replaces, for one rank's batch

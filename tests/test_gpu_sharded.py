@@ -36,10 +36,12 @@ def _step(model, opts, batch):
     return loss
 
 
+@pytest.mark.parametrize('compress', [False, True])
 @pytest.mark.parametrize('loss,optimizer,K,D', [('bpr', 'sparse_adam', 10, 64),
                                                 ('warp', 'adagrad', 5, 32),
                                                 ('hinge', 'sgd', 1, 10)])
-def test_world_1_sharded_step_matches_single_gpu_model(loss, optimizer, K, D):
+def test_world_1_sharded_step_matches_single_gpu_model(loss, optimizer, K, D, compress):
+    """compress: only the non-zero gradient rows go home (what world > 1 does by default)."""
     from collie_amd.model import MatrixFactorizationModel
     from collie_amd.sharded import ShardedMatrixFactorizationModel
     dev = torch.device('cuda:0')
@@ -53,6 +55,7 @@ def test_world_1_sharded_step_matches_single_gpu_model(loss, optimizer, K, D):
         single.item_embeddings.weight.mul_(10.0)
         single.item_biases.weight.normal_(0, 0.01)
     sharded = ShardedMatrixFactorizationModel.from_model(single, K, device=dev)
+    sharded.compress_gradients = compress
     opts = single.configure_optimizers()
     rng = np.random.default_rng(4)
     for it in range(3):
@@ -63,6 +66,9 @@ def test_world_1_sharded_step_matches_single_gpu_model(loss, optimizer, K, D):
         l2 = sharded.train_step(((users, pos), neg))
         np.testing.assert_allclose(l2.item(), l1.item(), rtol=1e-6)
     single.check_status()
+    if compress:        # at most user + positive + one negative per sample carry a gradient
+        assert 0 < sharded.last_gradient_rows <= 3 * B
+        assert sharded.last_gradient_rows < sharded.last_exchange['rows_requested'] or K == 1
     sd = sharded.state_dict()
     for name in NAMES:
         want = getattr(single, name).weight.detach().cpu().numpy()
