@@ -446,20 +446,21 @@ struct SmallParams {
   int step;
 };
 
-template <int LPR>
-__global__ __launch_bounds__(kBlock) void small_rows_kernel(const SmallParams p) {
+template <int LPR, int THREADS>
+__global__ __launch_bounds__(THREADS) void small_rows_kernel(const SmallParams p) {
   constexpr int GPW = kWave / LPR;
   constexpr int U = 4;               // scan iterations whose LDS reads are issued together
+  constexpr int kKeys = kSmallRowsMax + 4 * U * kWave;
   // (padded so that the unrolled scan may read past m: padding never equals a key)
-  __shared__ __attribute__((aligned(16))) uint32_t keys[kSmallMax + 4 * U * kWave];
+  __shared__ __attribute__((aligned(16))) uint32_t keys[kKeys];
   const int tid = threadIdx.x;
   const int lane = lane_id();
   const int grp = lane / LPR;
   const int lig = lane % LPR;
   const int m = p.m;
-  for (int i = tid; i < kSmallMax + 4 * U * kWave; i += kBlock)
-    keys[i] = i < m ? p.ekeys[i] : 0xffffffffu;
-  const int i = (blockIdx.x * kWavesPerBlock + tid / kWave) * GPW + grp;
+  const int m_pad = (m + 4 * U * kWave + 3) & ~3;      // what the scan can touch
+  for (int i = tid; i < m_pad; i += THREADS) keys[i] = i < m ? p.ekeys[i] : 0xffffffffu;
+  const int i = (blockIdx.x * (THREADS / kWave) + tid / kWave) * GPW + grp;
   const bool active = i < m;
   const uint32_t key = active ? p.ekeys[i] : 0xfffffffeu;   // matches nothing (keys < 2^32 - 2)
   const int side = key >= p.split ? 1 : 0;
@@ -474,26 +475,43 @@ __global__ __launch_bounds__(kBlock) void small_rows_kernel(const SmallParams p)
 
   float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   float zacc = 0.0f;
-  auto add_entry = [&](int j) {
-    const uint32_t c = p.ecodes[j];
-    if (c == kCodeNone) return;
-    const float sg = (c & kCodeNeg) ? -1.0f : 1.0f;
-    const int64_t src = c & kCodeMask;
-    if (estage && on) {
-      const float4 x = *reinterpret_cast<const float4*>(estage + src * D + chunk * 4);
-      acc.x += sg * x.x;
-      acc.y += sg * x.y;
-      acc.z += sg * x.z;
-      acc.w += sg * x.w;
+  // up to four entries at a time: their codes, then their staged rows, are loaded together (a hot
+  // row's segment would otherwise be a chain of two dependent loads per entry); added in order
+  auto add_entries = [&](const int (&js)[4], int n) {
+    uint32_t c[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) c[q] = q < n ? p.ecodes[js[q]] : kCodeNone;
+    float4 x[4];
+    float gv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      x[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      gv[q] = 0.0f;
+      if (c[q] != kCodeNone) {
+        const int64_t src = c[q] & kCodeMask;
+        if (estage && on) x[q] = *reinterpret_cast<const float4*>(estage + src * D + chunk * 4);
+        if (zstage && lig == 0) gv[q] = zstage[src];
+      }
     }
-    if (zstage && lig == 0) {
-      const float gv = zstage[src];
-      zacc += (c & kCodeNeg) ? -gv : gv;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (c[q] == kCodeNone) continue;
+      const float sg = (c[q] & kCodeNeg) ? -1.0f : 1.0f;
+      acc.x += sg * x[q].x;
+      acc.y += sg * x[q].y;
+      acc.z += sg * x[q].z;
+      acc.w += sg * x[q].w;
+      zacc += (c[q] & kCodeNeg) ? -gv[q] : gv[q];
     }
   };
+  int pend[4] = {0, 0, 0, 0};
+  int npend = 0;
   // speculative (wasted only for the few entries that are not the first of their row): the entry's
   // own gradient row and the row of the tables it will update are in flight during the scan
-  if (active) add_entry(i);
+  if (active) {
+    pend[0] = i;
+    add_entries(pend, 1);
+  }
   const int64_t off = row * D + chunk * 4;
   float4 pv = make_float4(0, 0, 0, 0), s1 = pv, s2 = pv;
   if (et.table && on) {
@@ -547,11 +565,23 @@ __global__ __launch_bounds__(kBlock) void small_rows_kernel(const SmallParams p)
         any_later &= any_later - 1ull;
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-          if ((later[c] >> l) & 1ull) add_entry(4 * (t * LPR + l) + c);
+          if ((later[c] >> l) & 1ull) {
+            const int j = 4 * (t * LPR + l) + c;
+            // (static indexing: the list stays in registers)
+            pend[0] = npend == 0 ? j : pend[0];
+            pend[1] = npend == 1 ? j : pend[1];
+            pend[2] = npend == 2 ? j : pend[2];
+            pend[3] = npend == 3 ? j : pend[3];
+            if (++npend == 4) {
+              add_entries(pend, 4);
+              npend = 0;
+            }
+          }
       }
     }
   }
   if (!first) return;
+  if (npend > 0) add_entries(pend, npend);
 
   const float scale = p.grad_scale ? *p.grad_scale : 1.0f;
   const int step = p.dyn ? p.dyn->step : p.step;
@@ -1013,7 +1043,7 @@ int sweep_kind(const KindPlan& k, const collie_mf_tables* t, const TrainWs& ws, 
 // The sort-free kernel serves sparse algorithms on coalesces of at most kSmallMax entries whose
 // embedding rows are float4 chunks, at most 64 of them (dim <= 256).
 bool small_rows_ok(const collie_mf_tables* t, const collie_mf_batch* b, int dense) {
-  return !dense && small_coalesce(3 * b->batch) && t->dim % 4 == 0 && t->dim <= 4 * kWave;
+  return !dense && 3 * b->batch <= kSmallRowsMax && t->dim % 4 == 0 && t->dim <= 4 * kWave;
 }
 
 bool small_descs_ok(const KindPlan* emb) {
@@ -1046,12 +1076,24 @@ int launch_small_rows(const collie_mf_tables* t, const collie_mf_batch* b, const
   const int nchunks = emb ? t->dim / 4 : 1;
   int lpr = 16;                      // at least 16 lanes per entry: the scan is split among them
   while (lpr < nchunks) lpr *= 2;
-  const int per_block = kWavesPerBlock * (kWave / lpr);
+  // every workgroup stages all m keys: beyond a few thousand entries 1,024-thread workgroups (four
+  // times fewer of them) keep that traffic down
+  const bool big = q.m > kSmallMax;
+  const int threads = big ? 1024 : kBlock;
+  const int per_block = (threads / kWave) * (kWave / lpr);
   const dim3 grid(static_cast<unsigned>((q.m + per_block - 1) / per_block));
-  switch (lpr) {
-    case 16: hipLaunchKernelGGL(small_rows_kernel<16>, grid, dim3(kBlock), 0, stream, q); break;
-    case 32: hipLaunchKernelGGL(small_rows_kernel<32>, grid, dim3(kBlock), 0, stream, q); break;
-    default: hipLaunchKernelGGL(small_rows_kernel<64>, grid, dim3(kBlock), 0, stream, q); break;
+  if (big) {
+    switch (lpr) {
+      case 16: hipLaunchKernelGGL((small_rows_kernel<16, 1024>), grid, dim3(1024), 0, stream, q); break;
+      case 32: hipLaunchKernelGGL((small_rows_kernel<32, 1024>), grid, dim3(1024), 0, stream, q); break;
+      default: hipLaunchKernelGGL((small_rows_kernel<64, 1024>), grid, dim3(1024), 0, stream, q); break;
+    }
+  } else {
+    switch (lpr) {
+      case 16: hipLaunchKernelGGL((small_rows_kernel<16, kBlock>), grid, dim3(kBlock), 0, stream, q); break;
+      case 32: hipLaunchKernelGGL((small_rows_kernel<32, kBlock>), grid, dim3(kBlock), 0, stream, q); break;
+      default: hipLaunchKernelGGL((small_rows_kernel<64, kBlock>), grid, dim3(kBlock), 0, stream, q); break;
+    }
   }
   return check_launch("small_rows_kernel");
 }

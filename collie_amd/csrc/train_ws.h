@@ -75,6 +75,11 @@ struct DynCtl {
 // (rowsort.hip): callers skip the piece kernels for them.
 constexpr int kSmallMax = 4096;
 inline bool small_coalesce(int64_t m) { return m <= kSmallMax; }
+// The sort-free row kernel (mf_update.hip: small_rows_kernel) takes up to this many entries: every
+// entry's lane group scans all keys in LDS, which stays cheaper than the ~15 launches of the
+// general coalesce up to about this size (B <= 4,096; measured, one call per step: B = 4,096 63 us
+// against 84 us, B = 5,461 no longer a gain for callers that update embeddings and biases apart).
+constexpr int kSmallRowsMax = 12288;
 
 constexpr int kPieceLen = 256;
 constexpr uint32_t kNoPiece = 0xffffffffu;

@@ -277,7 +277,7 @@ int collie_mf_train_advance_step(const collie_mf_tables* t, const collie_mf_batc
                                  int32_t* status, collie_stream_t stream);
 
 /* Whether collie_mf_train_update of this batch reads the segments (1) or not (0): sparse
- * algorithms on batches of at most 1,365 samples (the reference's default is 1,024) with
+ * algorithms on batches of at most 4,096 samples (the reference's default is 1,024) with
  * embedding_dim % 4 == 0 and <= 256 are coalesced inside the update launch itself, and
  * collie_mf_train_build_segments may be skipped for them (it is harmless to call it).
  * collie_mf_train_export_grad always needs the segments. */
