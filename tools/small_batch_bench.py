@@ -16,6 +16,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--batch', type=int, default=1024)
     ap.add_argument('--steps', type=int, default=3000)
+    ap.add_argument('--zipf', action='store_true', help='Zipf(1.05) ids: hot rows own long segments')
     ap.add_argument('--same-buffers', action='store_true',
                     help='feed the recording\'s own input buffers (no per-step batch copy)')
     args = ap.parse_args()
@@ -37,9 +38,13 @@ def main():
         model.to(dev).train()
         opts = model.configure_optimizers()
         opts = list(opts) if isinstance(opts, (list, tuple)) else [opts]
-        batches = [((torch.randint(0, U, (B,), device=dev, dtype=torch.int32),
-                     torch.randint(0, N, (B,), device=dev, dtype=torch.int32)),
-                    torch.randint(0, N, (B, K), device=dev)) for _ in range(8)]
+        if args.zipf:
+            import bench
+            batches = bench.synthetic_batches(8, B, dev, 'zipf', 3)
+        else:
+            batches = [((torch.randint(0, U, (B,), device=dev, dtype=torch.int32),
+                         torch.randint(0, N, (B,), device=dev, dtype=torch.int32)),
+                        torch.randint(0, N, (B, K), device=dev)) for _ in range(8)]
         replay = CapturedTrainStep(model, opts, mode='call' if mode == 'one_call' else 'graph')
 
         def step(i):
