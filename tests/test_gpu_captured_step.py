@@ -121,3 +121,34 @@ def test_trainer_replays_small_batches_and_matches_the_ordinary_loop():
         results.append({k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
     for k in results[0]:
         assert torch.equal(results[0][k], results[1][k]), k
+
+
+def test_batch_copy_handles_strides_and_id_dtypes():
+    """collie_mf_batch_copy: any strides of the negatives, int32 / int64 ids on either side."""
+    from collie_amd import ops
+    dev = torch.device('cuda:0')
+    B, K = 777, 7
+    g = torch.Generator().manual_seed(2)
+    users = torch.randint(0, 1000, (B,), generator=g).to(dev)                     # int64
+    pos = torch.randint(0, 1000, (B,), generator=g, dtype=torch.int32).to(dev)
+    neg_t = torch.randint(0, 1000, (K, B), generator=g).to(dev)                   # [K, B] storage
+    neg = neg_t.t()                                                               # strided [B, K] view
+    du = torch.zeros(B, dtype=torch.int32, device=dev)
+    dp = torch.zeros(B, dtype=torch.int64, device=dev)
+    dn = torch.zeros(B, K, dtype=torch.int64, device=dev)
+    ops.batch_copy(ops.make_batch(users, pos, neg), ops.make_batch(du, dp, dn))
+    assert torch.equal(du.long(), users) and torch.equal(dp, pos.long()) and torch.equal(dn, neg)
+
+
+@pytest.mark.parametrize('B,dense,D,want', [(1024, False, 64, False), (4096, False, 64, False),
+                                            (4097, False, 64, True), (1024, True, 64, True),
+                                            (1024, False, 62, True), (1024, False, 260, True)])
+def test_update_needs_segments_rule(B, dense, D, want):
+    from collie_amd import _lib, ops
+    dev = torch.device('cuda:0')
+    t = _lib.make_tables(torch.zeros(10, D, device=dev), torch.zeros(10, D, device=dev),
+                         torch.zeros(10, 1, device=dev), torch.zeros(10, 1, device=dev))
+    b = ops.make_batch(torch.zeros(B, dtype=torch.int32, device=dev),
+                       torch.zeros(B, dtype=torch.int32, device=dev),
+                       torch.zeros(B, 3, dtype=torch.int64, device=dev))
+    assert ops.train_update_needs_segments(t, b, dense) is want
