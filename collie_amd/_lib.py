@@ -103,6 +103,8 @@ SIGNATURES = {
     'collie_mf_train_export_grad': (ctypes.c_int, [POINTER(Tables), POINTER(Batch), c_void_p,
                                                    c_size_t, c_int32, c_int32, c_int32, c_void_p,
                                                    c_void_p, c_void_p, c_void_p, c_void_p]),
+    'collie_mf_train_gradient_rows': (ctypes.c_int, [POINTER(Tables), POINTER(Batch), c_void_p,
+                                                     c_size_t, c_void_p, c_void_p, c_void_p]),
     'collie_mf_train_update_needs_segments': (ctypes.c_int, [POINTER(Tables), POINTER(Batch),
                                                              c_int32]),
     'collie_mf_train_update_all': (ctypes.c_int, [POINTER(Tables), POINTER(Batch), c_void_p,

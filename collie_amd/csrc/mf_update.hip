@@ -739,6 +739,19 @@ __global__ __launch_bounds__(kBlock) void export_touched_kernel(const uint8_t* _
   if (i < rows) out[i] = touch[i] == touch_tag(step) ? 1 : 0;
 }
 
+// rows that own a segment of the sorted batch = rows some (sample, role) entry points at: the only
+// rows whose gradient can differ from zero (the row-sharded step sends just these home)
+__global__ __launch_bounds__(kBlock) void mark_gradient_rows_kernel(
+    const uint32_t* __restrict__ keys, const uint32_t* __restrict__ seg_start,
+    const uint32_t* __restrict__ nseg, uint32_t split, uint8_t* __restrict__ user_mask,
+    uint8_t* __restrict__ item_mask) {
+  const uint32_t s = blockIdx.x * kBlock + threadIdx.x;
+  if (s >= nseg[0]) return;
+  const uint32_t key = keys[seg_start[s]];
+  if (key < split) user_mask[key] = 1;
+  else item_mask[key - split] = 1;
+}
+
 // entries of a stand-alone sparse gradient: key = row id (clamped), code = position in vals
 // (val_index == NULL: entry i owns vals row i; else vals row val_index[i], < 0: a looked-up row with
 // a zero gradient, which is touched but reads nothing)
@@ -1375,6 +1388,24 @@ extern "C" int collie_mf_train_export_grad(const collie_mf_tables* t, const coll
     return check_launch("export_touched_kernel");
   }
   return 0;
+}
+
+extern "C" int collie_mf_train_gradient_rows(const collie_mf_tables* t, const collie_mf_batch* b,
+                                             void* workspace, size_t workspace_bytes,
+                                             uint8_t* user_mask, uint8_t* item_mask,
+                                             collie_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (validate_tables(t) || validate_batch(b)) return -1;
+  COLLIE_REQUIRE(user_mask && item_mask, "gradient_rows: NULL mask");
+  TrainWs ws = carve_train_ws(workspace, b->batch, b->num_neg, t->dim, t->num_users, t->num_items);
+  COLLIE_REQUIRE(workspace != nullptr && workspace_bytes >= ws.bytes,
+                 "workspace too small: need %zu bytes, got %zu", ws.bytes, workspace_bytes);
+  const int64_t m = 3 * b->batch;
+  const int64_t nkeys = t->num_users + t->num_items;
+  hipLaunchKernelGGL(mark_gradient_rows_kernel, dim3(static_cast<unsigned>((m + kBlock - 1) / kBlock)),
+                     dim3(kBlock), 0, stream, sorted_keys(ws.sort, nkeys), ws.sort.seg_start,
+                     ws.sort.nseg, static_cast<uint32_t>(t->num_users), user_mask, item_mask);
+  return check_launch("mark_gradient_rows_kernel");
 }
 
 extern "C" size_t collie_sparse_rows_workspace_bytes(int64_t m, int32_t dim) {

@@ -233,6 +233,13 @@ def train_export_grad(tables, batch, ws_buf, side, is_bias, step_id):
     return all_rows, full
 
 
+def train_gradient_rows(tables, batch, ws_buf, user_mask, item_mask):
+    """Marks (uint8 = 1) the rows that own gradient entries of the segmented batch."""
+    check(load().collie_mf_train_gradient_rows(
+        byref(tables), byref(batch), ptr(ws_buf), ws_buf.numel(), ptr(user_mask), ptr(item_mask),
+        stream_ptr()), 'collie_mf_train_gradient_rows')
+
+
 def sparse_rows_update(table, rows, vals, cfg, state1=None, state2=None, status=None,
                        workspace=None):
     """``optimizer.step()`` of SGD / Adagrad / SparseAdam on an uncoalesced COO gradient."""

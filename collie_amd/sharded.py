@@ -106,6 +106,7 @@ class HipEngine:
         self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
         self._acc = ops.optim_cfg('sgd', 1, -1.0)
         self._planner = None
+        self.gradient_row_mask = None
 
     # requester-side plan of one step (collie_shard_plan)
     def plan(self, model, users, pos_items, neg_items):
@@ -142,6 +143,9 @@ class HipEngine:
                 _lib.SIDE_ITEM: (self._acc, None, None, None)}
         ops.train_update(gt, batch, buf, False, False, step_id, both, scale)
         ops.train_update(gt, batch, buf, True, False, step_id, both, scale)
+        # rows that own gradient entries: what the compressed gradient exchange sends home
+        self.gradient_row_mask = torch.zeros(n, dtype=torch.uint8, device=self.device)
+        ops.train_gradient_rows(tables, batch, buf, self.gradient_row_mask, self.gradient_row_mask)
         return loss, gemb, gbias
 
     # optimizer.step() of one combined shard table on an uncoalesced COO gradient
@@ -724,7 +728,11 @@ class ShardedMatrixFactorizationModel:
         """
         comm, G, dev = self.comm, self.comm.world, gemb.device
         n = gemb.shape[0]
-        nz = (gemb != 0).any(dim=1) | (gbias != 0)
+        mask = getattr(self.engine, 'gradient_row_mask', None)
+        if mask is not None:        # rows with gradient entries (a superset of the non-zero rows)
+            nz = mask.bool()
+        else:
+            nz = (gemb != 0).any(dim=1) | (gbias != 0)
         bounds = torch.tensor([0] + list(_cumsum(p['send_splits'])), dtype=torch.int64, device=dev)
         csum = torch.zeros(n + 1, dtype=torch.int64, device=dev)
         torch.cumsum(nz, 0, out=csum[1:])

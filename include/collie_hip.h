@@ -306,6 +306,16 @@ int collie_mf_train_export_grad(const collie_mf_tables* t, const collie_mf_batch
                                 float* vals_out, int32_t* count_out, uint8_t* touched_out,
                                 collie_stream_t stream);
 
+/* Rows that own gradient entries of the batch, after collie_mf_train_build_segments: sets
+ * user_mask[u] = 1 / item_mask[i] = 1 (uint8 [num_users] / [num_items], zeroed by the caller; both
+ * may be one array when the two id ranges share a table) for the users, positives and the one
+ * negative per sample a loss selected -- a superset of the rows whose gradient is not zero.  The
+ * row-sharded step (reference: the sparse gradient of nn.Embedding(sparse=True),
+ * collie/model/matrix_factorization.py:105-118, whose COO rows these are) sends only these home. */
+int collie_mf_train_gradient_rows(const collie_mf_tables* t, const collie_mf_batch* b,
+                                  void* workspace, size_t workspace_bytes, uint8_t* user_mask,
+                                  uint8_t* item_mask, collie_stream_t stream);
+
 /* torch.optim.{SparseAdam,Adagrad,SGD}.step on an UNCOALESCED sparse COO gradient of one table
  * (torch/optim/_functional.py:41-84): rows [m] (int32/int64) with values vals [m, dim].  Sorts,
  * sums duplicates in input order (deterministic) and updates the rows in place.  Used by the

@@ -12,9 +12,13 @@ from collie_amd.sharded import ShardedMatrixFactorizationModel  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+if len(sys.argv) > 3:
+    bench.set_shape(sys.argv[3])            # c2 (default) | c4
+compress = len(sys.argv) > 4 and sys.argv[4] == 'compress'
 dev = torch.device('cuda:0')
 m = ShardedMatrixFactorizationModel(bench.NUM_USERS, bench.NUM_ITEMS, bench.NUM_NEG,
                                     embedding_dim=bench.DIM, loss='bpr', device=dev)
+m.compress_gradients = compress      # what world > 1 does by default
 batches = bench.synthetic_batches(8, B, dev, 'uniform', 1)
 for i in range(5):
     m.train_step(batches[i % 8])
