@@ -276,8 +276,24 @@ __global__ __launch_bounds__(kBlock) void eval_gemm_kernel(const EvalParams p) {
 //     is an XOR swizzle applied on the per-lane SOURCE address instead: 16-byte chunk c of tile row
 //     r lives at slot r * CPR + (c ^ (r % S)), S = min(16, CPR), and the A-fragment reads apply the
 //     same XOR.
-typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
+
+// LDS-DMA through inline asm.  After __builtin_amdgcn_global_load_lds the compiler's wait-count pass
+// makes every later LDS read wait for ALL outstanding DMA (it cannot tell the two tile buffers
+// apart): it placed an s_waitcnt vmcnt(0) right after the issue of tile t+1, so the DMA never
+// overlapped the MFMAs of tile t inside a workgroup.  The asm form is invisible to that pass; the
+// explicit s_waitcnt vmcnt(0) at the top of the tile loop is the only wait.  `lds` is wave-uniform.
+template <int BYTES>
+__device__ __forceinline__ void dma_to_lds(const void* g, const void* lds) {
+  const uint32_t l = __builtin_amdgcn_readfirstlane(
+      static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lptr_t)lds)));
+  if (BYTES == 16)
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(l)
+                 : "memory", "m0");
+  else
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(g), "s"(l)
+                 : "memory", "m0");
+}
 
 constexpr int kBlockDma = 512;
 constexpr int kWavesDma = kBlockDma / kWave;
@@ -488,16 +504,23 @@ __global__ __launch_bounds__(kBlockDma) void eval_gemm_dma_kernel(const EvalPara
       const int c = (i % CPR) ^ (r & (S - 1));
       int64_t item = base + r;
       if (item > last_row) item = last_row;
-      __builtin_amdgcn_global_load_lds((gptr_t)(p.t.item_emb + item * D + c * 4),
-                                       (lptr_t)(dst + I * kWave), 16, 0, 0);
+      dma_to_lds<16>(p.t.item_emb + item * D + c * 4, dst + I * kWave);
     }
     if (wave == 0) {
       int64_t item = base + lane;
       if (item > last_row) item = last_row;
-      __builtin_amdgcn_global_load_lds((gptr_t)(p.t.item_bias + item), (lptr_t)(dst + kTileF4), 4,
-                                       0, 0);
+      dma_to_lds<4>(p.t.item_bias + item, dst + kTileF4);
     }
   };
+
+  // Every value loaded from global memory above is made ready HERE: the compiler would otherwise
+  // keep its s_waitcnt vmcnt(n) for them inside the tile loop, and vmcnt is one in-order counter --
+  // such a wait would also drain the DMA instructions it does not know about.
+#pragma unroll
+  for (int q = 0; q < D8; ++q) asm volatile("" : "+v"(ufrag[q]));
+  float ub_ready = ub, cut_s_ready = cut_s;
+  int cut_i_ready = cut_i;
+  asm volatile("" : "+v"(ub_ready), "+v"(cut_s_ready), "+v"(cut_i_ready));
 
   int buf = 0;
   if (chunk_begin < chunk_end) issue(chunk_begin, 0);

@@ -712,6 +712,250 @@ __global__ __launch_bounds__(kWgBlock) void dense_wgrad_fast_kernel(const WgPara
   if (do_bias && nb + tid < p.n_out) out[static_cast<int64_t>(nb + tid) * ldp + p.n_in] = bsum;
 }
 
+// ---- weight gradient, LDS-DMA variant: the 128 x {128, 256, 384} layers -----------------------------
+// Measured on the fast kernel above (configs[4], per 128-column block of dW): its load pipeline alone
+// takes 160 us (it moves 1.1 GB: every column block re-reads dZ and the activation reference), its
+// MFMA + LDS loop alone 230 us, both together 290 us against an MFMA floor of 150 us -- the blocks of a
+// 256- / 384-wide layer read dZ two / three times and the register-staged loads of one slab ahead do
+// not cover the memory latency under that load.  Here ONE workgroup of 8 waves owns all of dW for its
+// row chunk (128 x n_in: wave w holds rows 32 (w & 3) and the k-tiles of half w >> 2, NKT x 16
+// accumulators), so dZ, its reference and X are read once, and no operand passes through VGPRs:
+// global_load_lds_dwordx4 writes 16-row slabs straight into a ring of kWdBuf LDS images, two slabs
+// ahead of the MFMAs, one barrier per slab.  LDS image of a slab: [tile][row][32 floats] for the four
+// 32-column tiles of dZ, of its reference and the n_in / 32 tiles of X -- a DMA instruction fills 8
+// rows of one tile (8 lanes x 16 bytes per row), and the fragment reads (row 2t + h, column = lane)
+// are conflict-free without padding.  LeakyReLU' is applied where the A value is read.  Same MFMA
+// order over the rows and the same chunks as the fast kernel: dW is bit-identical to it; db sums the
+// A values the MFMAs consume (other order than the fast kernel's column sums, deterministic).
+constexpr int kWdBlock = 512;
+constexpr int kWdRows = 16;
+constexpr int kWdBuf = 3;   // the waits below are written for three
+typedef __attribute__((address_space(3))) void* wd_lptr_t;
+
+// LDS-DMA through inline asm.  After __builtin_amdgcn_global_load_lds the compiler's wait-count pass
+// makes EVERY later LDS read (and every fence) wait for ALL outstanding DMA -- it cannot tell the
+// images of a ring apart -- which turns a multi-slab pipeline into load-then-compute.  The asm form
+// is invisible to that pass; the s_waitcnt vmcnt(N) in the loop below are the only waits, and the
+// barrier is the bare instruction (no fence).  `lds` must be wave-uniform.
+template <int BYTES>
+__device__ __forceinline__ void dma_to_lds(const void* g, const void* lds) {
+  const uint32_t l = __builtin_amdgcn_readfirstlane(
+      static_cast<uint32_t>(reinterpret_cast<uintptr_t>((wd_lptr_t)lds)));
+  if (BYTES == 16)
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(l)
+                 : "memory", "m0");
+  else
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(g), "s"(l)
+                 : "memory", "m0");
+}
+
+// the barrier instruction alone: LDS reads are complete once their values are used, the DMA writes
+// once the explicit vmcnt wait before the barrier has passed
+__device__ __forceinline__ void bare_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int NKT, bool ACT>
+__global__ __launch_bounds__(kWdBlock, 2) void dense_wgrad_dma_kernel(const WgParams p) {
+  constexpr int kZF = 4 * kWdRows * 32;                    // floats of the dZ image (and of its reference)
+  constexpr int kXOff = kZF * (ACT ? 2 : 1);
+  constexpr int kSlabF = kXOff + 2 * NKT * kWdRows * 32;
+  constexpr int kQ = 8 + (ACT ? 8 : 0) + 4 * NKT;          // DMA instructions per slab
+  constexpr int J = kQ / 8;                                // ... per wave
+  static_assert(kQ % 8 == 0, "instructions must split evenly over the waves");
+  __shared__ __attribute__((aligned(16))) float smem[kWdBuf * kSlabF];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int col = lane & 31;
+  const int h = lane >> 5;
+  const int nt = wave & 3;
+  const int kh = wave >> 2;
+  const int64_t mbeg = static_cast<int64_t>(blockIdx.x) * p.chunk;
+  int64_t mend = mbeg + p.chunk;
+  if (mend > p.m) mend = p.m;
+  const int nslab = static_cast<int>((mend - mbeg) / kWdRows);
+
+  // this wave's DMA streams: instruction q = wave + 8 j of the slab
+  const char* src[J];        // per lane: address of its 16 bytes in the first slab (dense rows), or of
+                             // the column inside row 0 (gathered rows)
+  const char* idp[J];        // per lane: address of its row's id in the first slab (dummy: a valid word)
+  int64_t step[J];           // bytes from one slab to the next (dense), 0 (gathered)
+  int64_t ldb[J];            // row pitch in bytes (gathered), 0 (dense)
+  int idstep[J];             // bytes from one slab's ids to the next (0: dummy)
+  uint32_t nrows[J];
+  int ldsoff[J];
+  const int lrow = lane >> 3;              // row of the 8-row group
+  const int lcol = (lane & 7) * 4;         // column inside the 32-column tile
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const int q = wave + 8 * j;
+    const int xq = q - (kQ - 4 * NKT);
+    const int tile = xq >= 0 ? xq >> 1 : (q >> 1) & 3;
+    const int row = (q & 1) * 8 + lrow;
+    idp[j] = reinterpret_cast<const char*>(p.dz.s[0].src);
+    idstep[j] = 0;
+    ldb[j] = 0;
+    nrows[j] = 1;
+    if (xq < 0) {
+      const bool ref = ACT && q >= 8;
+      const float* base = ref ? p.dz.s[0].act : p.dz.s[0].src;
+      const int64_t ld = ref ? p.dz.s[0].act_ld : p.dz.s[0].ld;
+      src[j] = reinterpret_cast<const char*>(base + (mbeg + row) * ld + tile * 32 + lcol);
+      step[j] = kWdRows * ld * 4;
+      ldsoff[j] = (ref ? kZF : 0) + tile * (kWdRows * 32) + (q & 1) * 256;
+    } else {
+      const int k = tile * 32;
+      // the segment of this k-tile (segment bounds are multiples of 32: checked by the host)
+      const float* base = p.x.s[0].src;
+      const void* idx = p.x.s[0].idx;
+      int64_t ld = p.x.s[0].ld, rows = p.x.s[0].rows;
+      int dt = p.x.s[0].idx_dtype, begin = 0;
+#pragma unroll
+      for (int si = 1; si < COLLIE_DENSE_MAX_SEGS; ++si) {
+        if (si < p.x.n_seg && k >= p.x.s[si].begin) {
+          base = p.x.s[si].src; idx = p.x.s[si].idx; ld = p.x.s[si].ld; rows = p.x.s[si].rows;
+          dt = p.x.s[si].idx_dtype; begin = p.x.s[si].begin;
+        }
+      }
+      ldsoff[j] = kXOff + tile * (kWdRows * 32) + (q & 1) * 256;
+      if (idx) {
+        const int sh = dt == COLLIE_I64 ? 3 : 2;
+        src[j] = reinterpret_cast<const char*>(base + (k - begin) + lcol);
+        step[j] = 0;
+        ldb[j] = ld * 4;
+        nrows[j] = static_cast<uint32_t>(rows);
+        idp[j] = static_cast<const char*>(idx) + ((mbeg + row) << sh);
+        idstep[j] = kWdRows << sh;
+      } else {
+        src[j] = reinterpret_cast<const char*>(base + (mbeg + row) * ld + (k - begin) + lcol);
+        step[j] = kWdRows * ld * 4;
+      }
+    }
+  }
+
+  // The ids of gathered rows travel by LDS-DMA as well (low word of the index element: tables have
+  // < 2^31 rows, see slot_row()): a load into a VGPR inside the loop makes the compiler wait for
+  // EVERY outstanding memory operation where the value is used (vmcnt counts in order), which would
+  // cut the DMA depth to one slab.  Ring of two per (wave, stream): written one step ahead.
+  __shared__ int32_t idring[2][kWdBlock / kWave][J][kWave];
+  bool any_bad = false;
+  auto fetch_ids = [&](int slot) {
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      if (idstep[j] != 0) {                      // uniform: the stream gathers
+        dma_to_lds<4>(idp[j], &idring[slot][wave][j][0]);
+        idp[j] += idstep[j];
+      }
+    }
+  };
+  auto issue = [&](int buf, int slot) {
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      uint32_t r = 0;
+      if (idstep[j] != 0) {
+        r = static_cast<uint32_t>(idring[slot][wave][j][lane]);
+        const bool bad = r >= nrows[j];          // flagged at the end, row 0 read instead
+        any_bad |= bad;
+        r = bad ? 0u : r;
+      }
+      const char* g = src[j] + static_cast<int64_t>(r) * ldb[j];
+      dma_to_lds<16>(g, smem + buf * kSlabF + ldsoff[j]);
+      src[j] += step[j];
+    }
+  };
+
+  f32x16 acc[NKT];
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[kt][i] = 0.0f;
+  float bsum = 0.0f;
+
+  // step k of the pipeline = ids of slab k + 1, then the J data instructions of slab k -- the data
+  // last, so "all but the last J operations" = everything older than the newest slab
+  fetch_ids(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (1 < nslab) fetch_ids(1);
+  issue(0, 0);
+  if (1 < nslab) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(J) : "memory");
+    if (2 < nslab) fetch_ids(0);
+    issue(1, 1);
+  }
+
+  int buf = 0;
+  for (int s = 0; s < nslab; ++s) {
+    // slab s and the ids of slab s + 2 have landed: everything but the data of slab s + 1
+    if (s + 1 < nslab) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(J) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    bare_barrier();      // everyone's part has; the image of slab s - 1 is free
+    // The two waves of a SIMD (w and w + 4: the two k-halves of one n-tile) leave the barrier
+    // together; the first issues its DMA before its MFMAs, the second after them, so the matrix
+    // pipe has work while either computes addresses.
+    auto next_slab = [&]() {
+      if (s + 2 < nslab) {
+        int nb = buf + 2;
+        if (nb >= kWdBuf) nb -= kWdBuf;
+        // the ids of slab s + 2 are in slot s & 1; those of slab s + 3 go to the other slot
+        if (s + 3 < nslab) fetch_ids((s + 1) & 1);
+        issue(nb, s & 1);
+      }
+    };
+    if (kh == 0) next_slab();
+    const float* zq = smem + buf * kSlabF + nt * (kWdRows * 32) + h * 32 + col;
+    const float* xq = smem + buf * kSlabF + kXOff + kh * NKT * (kWdRows * 32) + h * 32 + col;
+    // operands of step t + 1 are read from LDS before the MFMAs of step t
+    float a = zq[0], r = ACT ? zq[kZF] : 1.0f;
+    float b[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) b[kt] = xq[kt * (kWdRows * 32)];
+#pragma unroll
+    for (int t = 0; t < kWdRows / 2; ++t) {
+      float an = a, rn = r, bn[NKT];
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) bn[kt] = b[kt];
+      if (t + 1 < kWdRows / 2) {
+        an = zq[(t + 1) * 64];
+        if (ACT) rn = zq[kZF + (t + 1) * 64];
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) bn[kt] = xq[kt * (kWdRows * 32) + (t + 1) * 64];
+      }
+      const float av = r > 0.0f ? a : a * p.slope;
+      bsum += av;
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+        acc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[kt], acc[kt], 0, 0, 0);
+      a = an;
+      r = rn;
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) b[kt] = bn[kt];
+    }
+    if (kh != 0) next_slab();
+    buf = buf + 1 == kWdBuf ? 0 : buf + 1;
+  }
+
+  const int ldp = p.n_in + 1;
+  float* out = p.partial + static_cast<int64_t>(blockIdx.x) * p.n_out * ldp;
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) {
+    const int k = (kh * NKT + kt) * 32 + col;
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+      const int n = nt * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
+      out[static_cast<int64_t>(n) * ldp + k] = acc[kt][rr];
+    }
+  }
+  if (any_bad && p.status) atomicOr(p.status, 1);
+  // db: lanes (col, h = 0 / 1) of the waves kh = 0 hold the even- / odd-row sums of column nt * 32 + col
+  const float other = __shfl_xor(bsum, 32);
+  if (kh == 0 && h == 0) out[static_cast<int64_t>(nt * 32 + col) * ldp + p.n_in] = bsum + other;
+}
+
 // Adds the per-chunk partials in a fixed order: 16 lanes per output element each sum the chunks
 // c = lane (mod 16) in increasing order, then a fixed-shape butterfly combines the 16 sums —
 // deterministic, and 16x shorter dependent chains than one thread per element.
@@ -918,6 +1162,20 @@ void launch_fwd(const FwdParams& p, bool vec, hipStream_t stream) {
     hipLaunchKernelGGL(dense_fwd_kernel<4>, dim3(gx, gy), dim3(kFwdBlock), 0, stream, p);
 }
 
+// the LDS-DMA weight gradient takes: dW of exactly 128 x {128, 256, 384}, dZ one dense segment, X in
+// segments that start on 32-column tiles and carry no activation reference, whole 16-row slabs
+bool wgrad_dma_ok(const WgParams& p) {
+  const char* e = getenv("COLLIE_WGRAD_DMA");   // "0": the register-staged kernel (tests compare both)
+  if (e && e[0] == '0') return false;
+  if (p.dz_scalar || p.n_out != 128) return false;
+  if (p.n_in != 128 && p.n_in != 256 && p.n_in != 384) return false;
+  if (p.m % kWdRows || p.chunk % kWdRows) return false;
+  if (p.dz.n_seg != 1 || p.dz.s[0].idx) return false;
+  for (int i = 0; i < p.x.n_seg; ++i)
+    if (p.x.s[i].act || p.x.s[i].begin % 32 || p.x.s[i].end % 32) return false;
+  return true;
+}
+
 int64_t wgrad_chunks(int64_t m, int64_t* chunk_out) {
   int64_t nchunks = (m + 255) / 256;
   if (nchunks > 512) nchunks = 512;  // two resident workgroups per CU: one round of chunks
@@ -1046,6 +1304,17 @@ extern "C" int collie_dense_weight_grad(const collie_dense_operand* dz,
   if (n_out == 1 && lpr_x && narrow_operand(p.dz, 1) && narrow_operand(p.x, n_in)) {
     hipLaunchKernelGGL(narrow_wgrad_kernel, dim3(static_cast<unsigned>(nchunks)), dim3(kNarrowBlock), 0,
                        stream, p, lpr_x);
+  } else if (vec && wgrad_dma_ok(p)) {
+    const dim3 grid(static_cast<unsigned>(nchunks));
+    const bool act = p.dz.s[0].act != nullptr;
+    switch (n_in / 64 * 2 + (act ? 1 : 0)) {
+      case 4: hipLaunchKernelGGL((dense_wgrad_dma_kernel<2, false>), grid, dim3(kWdBlock), 0, stream, p); break;
+      case 5: hipLaunchKernelGGL((dense_wgrad_dma_kernel<2, true>), grid, dim3(kWdBlock), 0, stream, p); break;
+      case 8: hipLaunchKernelGGL((dense_wgrad_dma_kernel<4, false>), grid, dim3(kWdBlock), 0, stream, p); break;
+      case 9: hipLaunchKernelGGL((dense_wgrad_dma_kernel<4, true>), grid, dim3(kWdBlock), 0, stream, p); break;
+      case 12: hipLaunchKernelGGL((dense_wgrad_dma_kernel<6, false>), grid, dim3(kWdBlock), 0, stream, p); break;
+      default: hipLaunchKernelGGL((dense_wgrad_dma_kernel<6, true>), grid, dim3(kWdBlock), 0, stream, p); break;
+    }
   } else if (vec) {
     const dim3 grid(static_cast<unsigned>((n_in + kWgTile - 1) / kWgTile), static_cast<unsigned>(nchunks), gz);
     if (p.dz_scalar) hipLaunchKernelGGL(dense_wgrad_fast_kernel<true>, grid, dim3(kWgBlock), 0, stream, p);

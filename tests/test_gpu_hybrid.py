@@ -148,6 +148,12 @@ WG_CASES = [
     (70000, [16], [True], 8),
     (5000, [32], [False], 1),
     (1111, [130], [True], 140),
+    # whole 16-row slabs, dW of 128 x {128, 256, 384}: the LDS-DMA kernel
+    (3008, [128, 128, 128], [True, True, False], 128),
+    (4096, [256], [True], 128),
+    (2064, [128], [False], 128),
+    (16, [64, 64], [True, True], 128),
+    (45056, [128, 256], [False, True], 128),
 ]
 
 
@@ -164,6 +170,44 @@ def test_dense_weight_grad_vs_float64(dev, case):
     # deterministic: a second run is bit-identical
     dw2, db2, _ = ops.dense_weight_grad(dz_op, x_op, m, n_out, x.shape[1])
     assert torch.equal(dw, dw2) and torch.equal(db, db2)
+
+
+@pytest.mark.parametrize('case', [c for c in WG_CASES if c[3] == 128 and c[0] % 16 == 0])
+@pytest.mark.parametrize('masked', [True, False])
+def test_dense_weight_grad_dma_equals_register_kernel(dev, case, masked, monkeypatch):
+    """The LDS-DMA weight gradient feeds the MFMAs the same rows in the same order over the same
+    chunks as the register-staged kernel: dW bit for bit, db (another summation order) to 1e-5."""
+    from collie_amd import ops
+    m, widths, gathered, n_out = case
+    rng = np.random.default_rng(m + 1)
+    x_op, x = _operand_case(rng, m, widths, gathered, [False] * len(widths), dev)
+    dz_op, dz = _operand_case(rng, m, [n_out], [False], [masked], dev)
+    dw, db, _ = ops.dense_weight_grad(dz_op, x_op, m, n_out, x.shape[1])
+    monkeypatch.setenv('COLLIE_WGRAD_DMA', '0')
+    dw0, db0, _ = ops.dense_weight_grad(dz_op, x_op, m, n_out, x.shape[1])
+    assert torch.equal(dw, dw0)
+    close(db.cpu().numpy(), db0.cpu().numpy())
+    close(dw.cpu().numpy(), dz.T @ x)
+
+
+def test_dense_weight_grad_dma_flags_out_of_range_rows(dev):
+    from collie_amd import ops
+    m = 64
+    src = torch.ones(10, 128, device=dev)
+    idx = torch.arange(m, device=dev) % 10
+    idx[17] = 10
+    dz = torch.ones(m, 128, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    ops.dense_weight_grad(ops.dense_operand((dz, None, None)), ops.dense_operand((src, idx, None)),
+                          m, 128, 128, status=status)
+    assert int(status.item()) == 1
+    status.zero_()
+    idx[17] = 3
+    dw, db, _ = ops.dense_weight_grad(ops.dense_operand((dz, None, None)),
+                                      ops.dense_operand((src, idx, None)), m, 128, 128,
+                                      status=status)
+    assert int(status.item()) == 0
+    assert float(dw.min()) == float(dw.max()) == m and float(db.min()) == m
 
 
 @pytest.mark.parametrize('algo,kw', [('adam', dict(lr=1e-2, weight_decay=1e-3)),
