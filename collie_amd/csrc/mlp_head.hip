@@ -728,7 +728,6 @@ __global__ __launch_bounds__(kWgBlock) void dense_wgrad_fast_kernel(const WgPara
 // order over the rows and the same chunks as the fast kernel: dW is bit-identical to it; db sums the
 // A values the MFMAs consume (other order than the fast kernel's column sums, deterministic).
 constexpr int kWdBlock = 512;
-constexpr int kWdRows = 16;
 constexpr int kWdBuf = 3;   // the waits below are written for three
 typedef __attribute__((address_space(3))) void* wd_lptr_t;
 
@@ -755,14 +754,27 @@ __device__ __forceinline__ void bare_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int NKT, bool ACT>
+// NT x KT = 32-column tiles of dZ (n_out / 32) and of X (n_in / 32); R = operand rows per slab.
+// The 8 waves split the NT x KT output tiles: wave -> (n-tile, group of KT / KH k-tiles); when there
+// are fewer tiles than waves (32 x 64: two), the waves also split the rows of a slab (RG row groups)
+// and their accumulators are added in fixed order at the end.
+template <int NT, int KT, int R, bool ACT>
 __global__ __launch_bounds__(kWdBlock, 2) void dense_wgrad_dma_kernel(const WgParams p) {
-  constexpr int kZF = 4 * kWdRows * 32;                    // floats of the dZ image (and of its reference)
+  constexpr int kWaves = kWdBlock / kWave;
+  constexpr int KH = NT * KT >= kWaves ? kWaves / NT : KT;
+  constexpr int NKT = KT / KH;                             // k-tiles (accumulator tiles) per wave
+  constexpr int RG = kWaves / (NT * KH);
+  constexpr int TS = R / 2 / RG;                           // MFMA steps per wave and slab
+  constexpr int kParts = R / 8;                            // DMA instructions per tile and slab
+  constexpr int kTileF = R * 32;
+  constexpr int kZF = NT * kTileF;                         // floats of the dZ image (and of its reference)
   constexpr int kXOff = kZF * (ACT ? 2 : 1);
-  constexpr int kSlabF = kXOff + 2 * NKT * kWdRows * 32;
-  constexpr int kQ = 8 + (ACT ? 8 : 0) + 4 * NKT;          // DMA instructions per slab
-  constexpr int J = kQ / 8;                                // ... per wave
-  static_assert(kQ % 8 == 0, "instructions must split evenly over the waves");
+  constexpr int kSlabF = kXOff + KT * kTileF;
+  constexpr int kQ = (NT * (ACT ? 2 : 1) + KT) * kParts;   // DMA instructions per slab
+  constexpr int J = (kQ + kWaves - 1) / kWaves;            // ... per wave (the last ones may repeat
+                                                           // instruction q - kQ: same bytes, same place)
+  static_assert(NT * KH * RG == kWaves && KH * NKT == KT && TS * RG * 2 == R, "bad tiling");
+  static_assert(RG == 1 || kWdBuf * kSlabF >= kWaves * (NKT * 1024 + 64), "the exchange area of the row groups");
   __shared__ __attribute__((aligned(16))) float smem[kWdBuf * kSlabF];
 
   const int tid = threadIdx.x;
@@ -770,42 +782,46 @@ __global__ __launch_bounds__(kWdBlock, 2) void dense_wgrad_dma_kernel(const WgPa
   const int wave = tid >> 6;
   const int col = lane & 31;
   const int h = lane >> 5;
-  const int nt = wave & 3;
-  const int kh = wave >> 2;
+  const int nt = wave % NT;
+  const int kh = wave / NT % KH;
+  const int rg = wave / (NT * KH);
   const int64_t mbeg = static_cast<int64_t>(blockIdx.x) * p.chunk;
   int64_t mend = mbeg + p.chunk;
   if (mend > p.m) mend = p.m;
-  const int nslab = static_cast<int>((mend - mbeg) / kWdRows);
+  const int nslab = static_cast<int>((mend - mbeg) / R);
 
   // this wave's DMA streams: instruction q = wave + 8 j of the slab
   const char* src[J];        // per lane: address of its 16 bytes in the first slab (dense rows), or of
                              // the column inside row 0 (gathered rows)
-  const char* idp[J];        // per lane: address of its row's id in the first slab (dummy: a valid word)
+  const char* idp[J];        // per lane: address of its row's id in the first slab
   int64_t step[J];           // bytes from one slab to the next (dense), 0 (gathered)
   int64_t ldb[J];            // row pitch in bytes (gathered), 0 (dense)
-  int idstep[J];             // bytes from one slab's ids to the next (0: dummy)
+  int idstep[J];             // bytes from one slab's ids to the next; 0: the stream does not gather
   uint32_t nrows[J];
   int ldsoff[J];
   const int lrow = lane >> 3;              // row of the 8-row group
   const int lcol = (lane & 7) * 4;         // column inside the 32-column tile
 #pragma unroll
   for (int j = 0; j < J; ++j) {
-    const int q = wave + 8 * j;
-    const int xq = q - (kQ - 4 * NKT);
-    const int tile = xq >= 0 ? xq >> 1 : (q >> 1) & 3;
-    const int row = (q & 1) * 8 + lrow;
-    idp[j] = reinterpret_cast<const char*>(p.dz.s[0].src);
+    int q = wave + kWaves * j;
+    if (q >= kQ) q -= kQ;
+    const int ti = q / kParts;             // tile: dZ tiles, reference tiles, X tiles
+    const int part = q % kParts;
+    const int row = part * 8 + lrow;
+    idp[j] = nullptr;
     idstep[j] = 0;
     ldb[j] = 0;
     nrows[j] = 1;
-    if (xq < 0) {
-      const bool ref = ACT && q >= 8;
+    if (ti < NT * (ACT ? 2 : 1)) {
+      const bool ref = ti >= NT;
+      const int tile = ref ? ti - NT : ti;
       const float* base = ref ? p.dz.s[0].act : p.dz.s[0].src;
       const int64_t ld = ref ? p.dz.s[0].act_ld : p.dz.s[0].ld;
       src[j] = reinterpret_cast<const char*>(base + (mbeg + row) * ld + tile * 32 + lcol);
-      step[j] = kWdRows * ld * 4;
-      ldsoff[j] = (ref ? kZF : 0) + tile * (kWdRows * 32) + (q & 1) * 256;
+      step[j] = R * ld * 4;
+      ldsoff[j] = (ref ? kZF : 0) + tile * kTileF + part * 256;
     } else {
+      const int tile = ti - NT * (ACT ? 2 : 1);
       const int k = tile * 32;
       // the segment of this k-tile (segment bounds are multiples of 32: checked by the host)
       const float* base = p.x.s[0].src;
@@ -819,7 +835,7 @@ __global__ __launch_bounds__(kWdBlock, 2) void dense_wgrad_dma_kernel(const WgPa
           dt = p.x.s[si].idx_dtype; begin = p.x.s[si].begin;
         }
       }
-      ldsoff[j] = kXOff + tile * (kWdRows * 32) + (q & 1) * 256;
+      ldsoff[j] = kXOff + tile * kTileF + part * 256;
       if (idx) {
         const int sh = dt == COLLIE_I64 ? 3 : 2;
         src[j] = reinterpret_cast<const char*>(base + (k - begin) + lcol);
@@ -827,10 +843,10 @@ __global__ __launch_bounds__(kWdBlock, 2) void dense_wgrad_dma_kernel(const WgPa
         ldb[j] = ld * 4;
         nrows[j] = static_cast<uint32_t>(rows);
         idp[j] = static_cast<const char*>(idx) + ((mbeg + row) << sh);
-        idstep[j] = kWdRows << sh;
+        idstep[j] = R << sh;
       } else {
         src[j] = reinterpret_cast<const char*>(base + (mbeg + row) * ld + (k - begin) + lcol);
-        step[j] = kWdRows * ld * 4;
+        step[j] = R * ld * 4;
       }
     }
   }
@@ -839,7 +855,7 @@ __global__ __launch_bounds__(kWdBlock, 2) void dense_wgrad_dma_kernel(const WgPa
   // < 2^31 rows, see slot_row()): a load into a VGPR inside the loop makes the compiler wait for
   // EVERY outstanding memory operation where the value is used (vmcnt counts in order), which would
   // cut the DMA depth to one slab.  Ring of two per (wave, stream): written one step ahead.
-  __shared__ int32_t idring[2][kWdBlock / kWave][J][kWave];
+  __shared__ int32_t idring[2][kWaves][J][kWave];
   bool any_bad = false;
   auto fetch_ids = [&](int slot) {
 #pragma unroll
@@ -894,36 +910,30 @@ __global__ __launch_bounds__(kWdBlock, 2) void dense_wgrad_dma_kernel(const WgPa
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     bare_barrier();      // everyone's part has; the image of slab s - 1 is free
-    // The two waves of a SIMD (w and w + 4: the two k-halves of one n-tile) leave the barrier
-    // together; the first issues its DMA before its MFMAs, the second after them, so the matrix
-    // pipe has work while either computes addresses.
-    auto next_slab = [&]() {
-      if (s + 2 < nslab) {
-        int nb = buf + 2;
-        if (nb >= kWdBuf) nb -= kWdBuf;
-        // the ids of slab s + 2 are in slot s & 1; those of slab s + 3 go to the other slot
-        if (s + 3 < nslab) fetch_ids((s + 1) & 1);
-        issue(nb, s & 1);
-      }
-    };
-    if (kh == 0) next_slab();
-    const float* zq = smem + buf * kSlabF + nt * (kWdRows * 32) + h * 32 + col;
-    const float* xq = smem + buf * kSlabF + kXOff + kh * NKT * (kWdRows * 32) + h * 32 + col;
+    if (s + 2 < nslab) {
+      int nb = buf + 2;
+      if (nb >= kWdBuf) nb -= kWdBuf;
+      // the ids of slab s + 2 are in slot s & 1; those of slab s + 3 go to the other slot
+      if (s + 3 < nslab) fetch_ids((s + 1) & 1);
+      issue(nb, s & 1);
+    }
+    const float* zq = smem + buf * kSlabF + nt * kTileF + rg * (TS * 64) + h * 32 + col;
+    const float* xq = smem + buf * kSlabF + kXOff + kh * NKT * kTileF + rg * (TS * 64) + h * 32 + col;
     // operands of step t + 1 are read from LDS before the MFMAs of step t
     float a = zq[0], r = ACT ? zq[kZF] : 1.0f;
     float b[NKT];
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) b[kt] = xq[kt * (kWdRows * 32)];
+    for (int kt = 0; kt < NKT; ++kt) b[kt] = xq[kt * kTileF];
 #pragma unroll
-    for (int t = 0; t < kWdRows / 2; ++t) {
+    for (int t = 0; t < TS; ++t) {
       float an = a, rn = r, bn[NKT];
 #pragma unroll
       for (int kt = 0; kt < NKT; ++kt) bn[kt] = b[kt];
-      if (t + 1 < kWdRows / 2) {
+      if (t + 1 < TS) {
         an = zq[(t + 1) * 64];
         if (ACT) rn = zq[kZF + (t + 1) * 64];
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) bn[kt] = xq[kt * (kWdRows * 32) + (t + 1) * 64];
+        for (int kt = 0; kt < NKT; ++kt) bn[kt] = xq[kt * kTileF + (t + 1) * 64];
       }
       const float av = r > 0.0f ? a : a * p.slope;
       bsum += av;
@@ -935,25 +945,49 @@ __global__ __launch_bounds__(kWdBlock, 2) void dense_wgrad_dma_kernel(const WgPa
 #pragma unroll
       for (int kt = 0; kt < NKT; ++kt) b[kt] = bn[kt];
     }
-    if (kh != 0) next_slab();
     buf = buf + 1 == kWdBuf ? 0 : buf + 1;
+  }
+
+  if (RG > 1) {
+    // row groups: accumulators through LDS, added in group order by the waves of group 0
+    bare_barrier();                             // every wave is done with the slab images
+    float* ex = smem + wave * (NKT * 1024 + 64);
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) ex[kt * 1024 + i * 64 + lane] = acc[kt][i];
+    ex[NKT * 1024 + lane] = bsum;
+    bare_barrier();
+    if (rg == 0) {
+#pragma unroll
+      for (int g = 1; g < RG; ++g) {
+        const float* o = smem + (g * NT * KH + wave) * (NKT * 1024 + 64);
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[kt][i] += o[kt * 1024 + i * 64 + lane];
+        bsum += o[NKT * 1024 + lane];
+      }
+    }
   }
 
   const int ldp = p.n_in + 1;
   float* out = p.partial + static_cast<int64_t>(blockIdx.x) * p.n_out * ldp;
+  if (rg == 0) {
 #pragma unroll
-  for (int kt = 0; kt < NKT; ++kt) {
-    const int k = (kh * NKT + kt) * 32 + col;
+    for (int kt = 0; kt < NKT; ++kt) {
+      const int k = (kh * NKT + kt) * 32 + col;
 #pragma unroll
-    for (int rr = 0; rr < 16; ++rr) {
-      const int n = nt * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
-      out[static_cast<int64_t>(n) * ldp + k] = acc[kt][rr];
+      for (int rr = 0; rr < 16; ++rr) {
+        const int n = nt * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
+        out[static_cast<int64_t>(n) * ldp + k] = acc[kt][rr];
+      }
     }
   }
   if (any_bad && p.status) atomicOr(p.status, 1);
   // db: lanes (col, h = 0 / 1) of the waves kh = 0 hold the even- / odd-row sums of column nt * 32 + col
   const float other = __shfl_xor(bsum, 32);
-  if (kh == 0 && h == 0) out[static_cast<int64_t>(nt * 32 + col) * ldp + p.n_in] = bsum + other;
+  if (rg == 0 && kh == 0 && h == 0) out[static_cast<int64_t>(nt * 32 + col) * ldp + p.n_in] = bsum + other;
 }
 
 // Adds the per-chunk partials in a fixed order: 16 lanes per output element each sum the chunks
@@ -1162,14 +1196,21 @@ void launch_fwd(const FwdParams& p, bool vec, hipStream_t stream) {
     hipLaunchKernelGGL(dense_fwd_kernel<4>, dim3(gx, gy), dim3(kFwdBlock), 0, stream, p);
 }
 
-// the LDS-DMA weight gradient takes: dW of exactly 128 x {128, 256, 384}, dZ one dense segment, X in
-// segments that start on 32-column tiles and carry no activation reference, whole 16-row slabs
+// the LDS-DMA weight gradient takes: dW of 128 x {128, 256, 384}, 64 x 128 or 32 x 64 (the layers of
+// the reference's default head), dZ one dense segment, X in segments that start on 32-column tiles
+// and carry no activation reference, whole slabs of rows
+int wgrad_dma_rows(int n_out, int n_in) {
+  if (n_out == 128 && (n_in == 128 || n_in == 256 || n_in == 384)) return 16;
+  if ((n_out == 64 && n_in == 128) || (n_out == 32 && n_in == 64)) return 32;
+  return 0;
+}
+
 bool wgrad_dma_ok(const WgParams& p) {
   const char* e = getenv("COLLIE_WGRAD_DMA");   // "0": the register-staged kernel (tests compare both)
   if (e && e[0] == '0') return false;
-  if (p.dz_scalar || p.n_out != 128) return false;
-  if (p.n_in != 128 && p.n_in != 256 && p.n_in != 384) return false;
-  if (p.m % kWdRows || p.chunk % kWdRows) return false;
+  const int rows = wgrad_dma_rows(p.n_out, p.n_in);
+  if (p.dz_scalar || rows == 0) return false;
+  if (p.m % rows || p.chunk % rows) return false;
   if (p.dz.n_seg != 1 || p.dz.s[0].idx) return false;
   for (int i = 0; i < p.x.n_seg; ++i)
     if (p.x.s[i].act || p.x.s[i].begin % 32 || p.x.s[i].end % 32) return false;
@@ -1305,16 +1346,17 @@ extern "C" int collie_dense_weight_grad(const collie_dense_operand* dz,
     hipLaunchKernelGGL(narrow_wgrad_kernel, dim3(static_cast<unsigned>(nchunks)), dim3(kNarrowBlock), 0,
                        stream, p, lpr_x);
   } else if (vec && wgrad_dma_ok(p)) {
-    const dim3 grid(static_cast<unsigned>(nchunks));
+    const dim3 grid(static_cast<unsigned>(nchunks)), block(kWdBlock);
     const bool act = p.dz.s[0].act != nullptr;
-    switch (n_in / 64 * 2 + (act ? 1 : 0)) {
-      case 4: hipLaunchKernelGGL((dense_wgrad_dma_kernel<2, false>), grid, dim3(kWdBlock), 0, stream, p); break;
-      case 5: hipLaunchKernelGGL((dense_wgrad_dma_kernel<2, true>), grid, dim3(kWdBlock), 0, stream, p); break;
-      case 8: hipLaunchKernelGGL((dense_wgrad_dma_kernel<4, false>), grid, dim3(kWdBlock), 0, stream, p); break;
-      case 9: hipLaunchKernelGGL((dense_wgrad_dma_kernel<4, true>), grid, dim3(kWdBlock), 0, stream, p); break;
-      case 12: hipLaunchKernelGGL((dense_wgrad_dma_kernel<6, false>), grid, dim3(kWdBlock), 0, stream, p); break;
-      default: hipLaunchKernelGGL((dense_wgrad_dma_kernel<6, true>), grid, dim3(kWdBlock), 0, stream, p); break;
-    }
+#define COLLIE_WD(NT, KT, R)                                                                       \
+  if (act) hipLaunchKernelGGL((dense_wgrad_dma_kernel<NT, KT, R, true>), grid, block, 0, stream, p); \
+  else hipLaunchKernelGGL((dense_wgrad_dma_kernel<NT, KT, R, false>), grid, block, 0, stream, p)
+    if (n_out == 128 && n_in == 384) { COLLIE_WD(4, 12, 16); }
+    else if (n_out == 128 && n_in == 256) { COLLIE_WD(4, 8, 16); }
+    else if (n_out == 128) { COLLIE_WD(4, 4, 16); }
+    else if (n_out == 64) { COLLIE_WD(2, 4, 32); }
+    else { COLLIE_WD(1, 2, 32); }
+#undef COLLIE_WD
   } else if (vec) {
     const dim3 grid(static_cast<unsigned>((n_in + kWgTile - 1) / kWgTile), static_cast<unsigned>(nchunks), gz);
     if (p.dz_scalar) hipLaunchKernelGGL(dense_wgrad_fast_kernel<true>, grid, dim3(kWgBlock), 0, stream, p);
