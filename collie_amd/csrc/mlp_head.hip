@@ -990,6 +990,245 @@ __global__ __launch_bounds__(kWdBlock, 2) void dense_wgrad_dma_kernel(const WgPa
   if (rg == 0 && kh == 0 && h == 0) out[static_cast<int64_t>(nt * 32 + col) * ldp + p.n_in] = bsum + other;
 }
 
+// ---- forward / data gradient, LDS-DMA variant: 128 output columns, n_in = 128 NCH ------------------
+// The register-staged kernel above synchronises its workgroup twice per 32-column chunk and its loads
+// are one chunk ahead; SQ counters put it at 2x its MFMA time.  Here the W fragments of a wave (its 32
+// output columns x all of n_in) stay in REGISTERS for the whole kernel, a workgroup of 8 waves walks a
+// run of 64-row tiles, and the operand arrives by LDS-DMA in 64 x 128 images (a ring of three, two
+// ahead of the MFMAs; with an activation reference -- the data gradients -- two images of operand +
+// reference, one ahead), one barrier per image.  Image layout: [k-tile][row][8 slots of 16 bytes]; a
+// DMA destination is wave-linear, so the conflict-free image is an XOR swizzle on the per-lane SOURCE
+// address (slot s of row r holds chunk s ^ (r & 7)), and the A-fragment reads apply the same XOR.
+// Same k order and pairing as the register-staged kernel: results are bit-identical to it.
+// Stores of a finished tile are issued after the NEXT barrier, before that iteration's DMA, so the
+// newest J memory operations are always the DMA of the newest image (what the vmcnt waits assume).
+constexpr int kDfBlock = 512;
+constexpr int kDfRows = 64;
+constexpr int kDfTileF4 = 4 * kDfRows * 8;
+
+// KS = 2 (n_in = 384: the W fragments of a 32 x 384 block do not fit one wave's registers): the two
+// waves of a column tile split the K-TILES of every image instead of its rows -- each holds half of W
+// and both 32-row sub-tiles -- and the second hands its sums to the first through LDS at the end of a
+// tile (one more rounding order than the register-staged kernel: compared to 1e-5, not bit for bit).
+template <int NCH, bool ACT, int KS>
+__global__ __launch_bounds__(kDfBlock, 2) void dense_fwd_dma_kernel(const FwdParams p) {
+  constexpr int NB = ACT ? 2 : 3;
+  constexpr int kSlabF4 = kDfTileF4 * (ACT ? 2 : 1);
+  constexpr int J = 4 * (ACT ? 2 : 1);
+  constexpr int kWaves = kDfBlock / kWave;
+  constexpr int NW = NCH * 16 / KS;        // W fragments (float4) per wave
+  constexpr int NA = KS;                   // accumulator tiles per wave
+  __shared__ f32x4 smem[NB * kSlabF4];
+  __shared__ int32_t idring[2][kWaves][kWave];
+  __shared__ float xbuf[KS == 2 ? 4 * 2 * 16 * kWave : 1];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int col = lane & 31;
+  const int h = lane >> 5;
+  const int nt = wave & 3;                 // this wave's 32 output columns
+  const int rh = wave >> 2;                // KS = 1: its 32 rows of the tile; KS = 2: its k-tiles
+  const int lrow = wave * 8 + (lane >> 3); // DMA: this lane's row of the tile
+  const int lslot = lane & 7;
+
+  const int64_t ntiles = (p.m + kDfRows - 1) / kDfRows;
+  const int64_t per = (ntiles + gridDim.x - 1) / gridDim.x;
+  const int64_t t0 = static_cast<int64_t>(blockIdx.x) * per;
+  int64_t t1 = t0 + per;
+  if (t1 > ntiles) t1 = ntiles;
+  if (t0 >= t1) return;
+  const int nslab = static_cast<int>(t1 - t0) * NCH;
+
+  // W fragments: W[n][k = 8 qq + 4 h + e], the k pairing of the register-staged kernel; fragment i
+  // of a wave is qq = i (KS = 1), or chunk i / 8, k-tile 2 rh + (i / 4 & 1), q = i & 3 (KS = 2)
+  f32x4 wf[NW];
+  {
+    const int n = nt * 32 + col;
+    const float* wrow = p.w + static_cast<int64_t>(n) * p.w_ld_out;
+    const bool wvec = p.w_ld_in == 1 && reinterpret_cast<uintptr_t>(p.w) % 16 == 0 && p.w_ld_out % 4 == 0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const int qq = KS == 1 ? i : (i / 8) * 16 + (2 * rh + (i / 4 & 1)) * 4 + (i & 3);
+      if (wvec) {
+        wf[i] = *reinterpret_cast<const f32x4*>(wrow + qq * 8 + 4 * h);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wf[i][e] = wrow[static_cast<int64_t>(qq * 8 + 4 * h + e) * p.w_ld_in];
+      }
+    }
+  }
+  float bias_n = p.bias ? p.bias[nt * 32 + col] : 0.0f;
+
+  // the segment of each 128-column chunk (segment bounds are multiples of 128: checked by the host)
+  const float* c_src[NCH];
+  const float* c_act[NCH];
+  const char* c_idx[NCH];
+  int64_t c_ld[NCH], c_act_ld[NCH];
+  uint32_t c_rows[NCH];
+  int c_sh[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    int si = 0;
+#pragma unroll
+    for (int j = 1; j < COLLIE_DENSE_MAX_SEGS; ++j)
+      if (j < p.x.n_seg && c * 128 >= p.x.s[j].begin) si = j;
+    const Seg& sg = p.x.s[si];
+    c_src[c] = sg.src + (c * 128 - sg.begin);
+    c_act[c] = sg.act ? sg.act + (c * 128 - sg.begin) : nullptr;
+    c_idx[c] = static_cast<const char*>(sg.idx);
+    c_ld[c] = sg.ld;
+    c_act_ld[c] = sg.act_ld;
+    c_rows[c] = static_cast<uint32_t>(sg.rows);
+    c_sh[c] = sg.idx_dtype == COLLIE_I64 ? 3 : 2;
+  }
+
+  // everything loaded into registers so far is made ready before the first DMA: a compiler-placed
+  // s_waitcnt vmcnt(n) inside the loop would drain the DMA it does not know about
+#pragma unroll
+  for (int i = 0; i < NW; ++i) asm volatile("" : "+v"(wf[i]));
+  asm volatile("" : "+v"(bias_n));
+
+  bool any_bad = false;
+  auto row_of = [&](int64_t tile) {                 // operand row of this lane, clamped into [0, m)
+    int64_t m = tile * kDfRows + lrow;
+    return m < p.m ? m : p.m - 1;
+  };
+  auto fetch_ids = [&](int64_t tile, int c, int slot) {
+    if (c_idx[c]) dma_to_lds<4>(c_idx[c] + (row_of(tile) << c_sh[c]), &idring[slot][wave][0]);
+  };
+  auto issue = [&](int64_t tile, int c, int buf, int slot) {
+    const int64_t m = row_of(tile);
+    int64_t row = m;
+    if (c_idx[c]) {
+      uint32_t r = static_cast<uint32_t>(idring[slot][wave][lane]);
+      const bool bad = r >= c_rows[c];               // flagged at the end, row 0 read instead
+      any_bad |= bad;
+      row = bad ? 0 : r;
+    }
+    const int sw = (lslot ^ (lrow & 7)) * 4;
+    const float* g = c_src[c] + row * c_ld[c] + sw;
+    f32x4* dst = smem + buf * kSlabF4 + wave * 64;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dma_to_lds<16>(g + j * 32, dst + j * 512);
+    if (ACT) {
+      const float* a = c_act[c] + m * c_act_ld[c] + sw;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dma_to_lds<16>(a + j * 32, dst + kDfTileF4 + j * 512);
+    }
+  };
+  // slab s = (tile t0 + s / NCH, chunk s % NCH); its ids live in idring slot s & 1
+  auto fetch_ids_slab = [&](int s) { fetch_ids(t0 + s / NCH, s % NCH, s & 1); };
+  auto issue_slab = [&](int s) { issue(t0 + s / NCH, s % NCH, s % NB, s & 1); };
+
+  fetch_ids_slab(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (1 < nslab) fetch_ids_slab(1);
+  issue_slab(0);
+  if (NB == 3 && 1 < nslab) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(J) : "memory");
+    if (2 < nslab) fetch_ids_slab(2);
+    issue_slab(1);
+  }
+
+  f32x16 acc[NA];
+#pragma unroll
+  for (int a = 0; a < NA; ++a)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[a][i] = 0.0f;
+  // store of a finished tile (KS = 2: the first wave of a pair, after adding the second's sums)
+  auto store_tile = [&](int64_t tile) {
+    const int n = nt * 32 + col;
+    if (KS == 2 && rh != 0) return;
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t m = tile * kDfRows + (KS == 1 ? rh : a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        float v = acc[a][r];
+        if (KS == 2) v += xbuf[((nt * 2 + a) * 16 + r) * kWave + lane];
+        v += bias_n;
+        if (p.leaky) v = v > 0.0f ? v : v * p.slope;
+        if (m < p.m) p.y[m * p.y_ld + n] = v;
+      }
+    }
+  };
+  auto hand_over = [&]() {                 // KS = 2, second wave of a pair: sums to LDS, start again
+    if (KS == 2 && rh != 0) {
+#pragma unroll
+      for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          xbuf[((nt * 2 + a) * 16 + r) * kWave + lane] = acc[a][r];
+          acc[a][r] = 0.0f;
+        }
+    }
+  };
+
+  int s = 0;
+  for (int64_t tile = t0; tile < t1; ++tile) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c, ++s) {
+      // image s (and the ids of the next image to issue) has landed: everything but the DMA of
+      // the image after it
+      if (NB == 3 && s + 1 < nslab) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(J) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      bare_barrier();
+      if (c == 0 && tile > t0) {
+        store_tile(tile - 1);
+        if (KS == 1 || rh == 0) {
+#pragma unroll
+          for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][i] = 0.0f;
+        }
+      }
+      if (s + NB - 1 < nslab) {
+        if (s + NB < nslab) fetch_ids_slab(s + NB);
+        issue_slab(s + NB - 1);
+      }
+      const f32x4* img = smem + (s % NB) * kSlabF4;
+      // A fragments two steps ahead of the MFMAs that consume them.  Step -> (accumulator / row
+      // sub-tile, k-tile, q): KS = 1: rows rh, k-tile step / 4; KS = 2: rows step / 8, k-tile
+      // 2 rh + (step / 4 & 1)
+      auto frag = [&](int step) {
+        const int a_i = KS == 1 ? 0 : step >> 3;
+        const int j = KS == 1 ? step >> 2 : 2 * rh + (step >> 2 & 1);
+        const int q = step & 3;
+        const int arow = (KS == 1 ? rh : a_i) * 32 + col;
+        const int at = j * 512 + arow * 8 + ((2 * q + h) ^ (arow & 7));
+        f32x4 a = img[at];
+        if (ACT) {
+          const f32x4 r = img[kDfTileF4 + at];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a[e] = r[e] > 0.0f ? a[e] : a[e] * p.slope;
+        }
+        return a;
+      };
+      f32x4 a0 = frag(0), a1 = frag(1);
+#pragma unroll
+      for (int step = 0; step < 16; ++step) {
+        const f32x4 a = a0;
+        a0 = a1;
+        if (step + 2 < 16) a1 = frag(step + 2);
+        const f32x4 w = wf[KS == 1 ? c * 16 + step : c * 8 + (step & 7)];
+        const int a_i = KS == 1 ? 0 : step >> 3;
+        acc[a_i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], w[0], acc[a_i], 0, 0, 0);
+        acc[a_i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], w[1], acc[a_i], 0, 0, 0);
+        acc[a_i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], w[2], acc[a_i], 0, 0, 0);
+        acc[a_i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], w[3], acc[a_i], 0, 0, 0);
+      }
+      if (c == NCH - 1) hand_over();      // read by the partner after the next barrier
+    }
+  }
+  if (KS == 2) bare_barrier();
+  store_tile(t1 - 1);
+  if (any_bad && p.status) atomicOr(p.status, 1);
+}
+
 // Adds the per-chunk partials in a fixed order: 16 lanes per output element each sum the chunks
 // c = lane (mod 16) in increasing order, then a fixed-shape butterfly combines the 16 sums —
 // deterministic, and 16x shorter dependent chains than one thread per element.
@@ -1161,9 +1400,31 @@ int build_operand(Operand& op, const collie_dense_operand* in, int64_t m, bool& 
   return 0;
 }
 
+// the LDS-DMA forward takes: exactly 128 output columns, n_in of 128 / 256 / 384 in segments that start
+// on 128-column chunks, no per-row bias tables; with an activation reference only n_in = 128
+bool fwd_dma_ok(const FwdParams& p) {
+  const char* e = getenv("COLLIE_FWD_DMA");     // "0": the register-staged kernel (tests compare both)
+  if (e && e[0] == '0') return false;
+  if (p.n_out != 128 || (p.n_in != 128 && p.n_in != 256 && p.n_in != 384)) return false;
+  if (p.user_bias || p.m < 1) return false;
+  if (p.has_act && p.n_in != 128) return false;
+  for (int i = 0; i < p.x.n_seg; ++i)
+    if (p.x.s[i].begin % 128 || p.x.s[i].end % 128) return false;
+  return true;
+}
+
 void launch_fwd(const FwdParams& p, bool vec, hipStream_t stream) {
   const unsigned gx = static_cast<unsigned>((p.m + kFwdRows - 1) / kFwdRows);
   const unsigned gy = static_cast<unsigned>((p.n_out + 127) / 128);
+  if (vec && fwd_dma_ok(p)) {
+    const int64_t ntiles = (p.m + kDfRows - 1) / kDfRows;
+    const dim3 grid(static_cast<unsigned>(ntiles < 256 ? ntiles : 256)), block(kDfBlock);
+    if (p.has_act) hipLaunchKernelGGL((dense_fwd_dma_kernel<1, true, 1>), grid, block, 0, stream, p);
+    else if (p.n_in == 128) hipLaunchKernelGGL((dense_fwd_dma_kernel<1, false, 1>), grid, block, 0, stream, p);
+    else if (p.n_in == 256) hipLaunchKernelGGL((dense_fwd_dma_kernel<2, false, 1>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((dense_fwd_dma_kernel<3, false, 2>), grid, block, 0, stream, p);
+    return;
+  }
   if (vec) {
     const unsigned gx = static_cast<unsigned>((p.m + kFRows - 1) / kFRows);
     // weights load as 16-byte slots when their contiguous direction is float4-aligned

@@ -70,6 +70,63 @@ FWD_CASES = [
 ]
 
 
+FWD_DMA_CASES = [
+    # 128 output columns, 128-column segments: the LDS-DMA kernel
+    (4096, [128, 128], [True, False], [False, False], 128, True),
+    (1000, [256], [True], [False], 128, True),
+    (64, [128], [False], [False], 128, False),
+    (77, [128], [True], [False], 128, True),
+    (30000, [128], [False], [True], 128, False),
+    (129, [128], [True], [True], 128, False),
+    # n_in = 384: the two waves of a column tile split K (one more rounding order: 1e-5, not bits)
+    (5000, [128, 128, 128], [True, True, False], [False, False, False], 128, True),
+    (64 * 300 + 5, [384], [False], [False], 128, False),
+]
+
+
+@pytest.mark.parametrize('case', FWD_DMA_CASES)
+def test_dense_forward_dma_equals_register_kernel(dev, case, monkeypatch):
+    """Same k order and pairing as the register-staged kernel: bit-identical outputs."""
+    from collie_amd import ops
+    m, widths, gathered, act, n_out, leaky = case
+    rng = np.random.default_rng(m + 7)
+    op, x = _operand_case(rng, m, widths, gathered, act, dev)
+    n_in = x.shape[1]
+    w = (rng.normal(size=(n_out, n_in)) / np.sqrt(n_in)).astype(np.float32)
+    b = rng.normal(size=n_out).astype(np.float32)
+    wt, bt = torch.tensor(w, device=dev), torch.tensor(b, device=dev)
+    y = ops.dense_forward(op, m, wt, bt, leaky)
+    # transposed weights (the data-gradient form): W read through swapped strides
+    wt2 = torch.tensor(np.ascontiguousarray(w.T), device=dev)
+    y2 = ops.dense_forward(op, m, wt2, None, False, transposed=True)
+    monkeypatch.setenv('COLLIE_FWD_DMA', '0')
+    y0 = ops.dense_forward(op, m, wt, bt, leaky)
+    y20 = ops.dense_forward(op, m, wt2, None, False, transposed=True)
+    if n_in == 384:
+        close(y.cpu().numpy(), y0.cpu().numpy())
+        close(y2.cpu().numpy(), y20.cpu().numpy())
+    else:
+        assert torch.equal(y, y0) and torch.equal(y2, y20)
+    # deterministic
+    assert torch.equal(ops.dense_forward(op, m, wt, bt, leaky), y0 if n_in != 384 else
+                       ops.dense_forward(op, m, wt, bt, leaky))
+    ref = x @ w.astype(np.float64).T + b
+    if leaky:
+        ref = np.where(ref > 0, ref, ref * np.float64(np.float32(SLOPE)))
+    close(y.cpu().numpy(), ref)
+
+
+def test_dense_forward_dma_flags_out_of_range_rows(dev):
+    from collie_amd import ops
+    src = torch.ones(10, 128, device=dev)
+    idx = torch.arange(200, device=dev) % 10
+    idx[150] = 10
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    w = torch.ones(128, 128, device=dev)
+    ops.dense_forward(ops.dense_operand((src, idx, None)), 200, w, None, False, status=status)
+    assert int(status.item()) == 1
+
+
 @pytest.mark.parametrize('case', FWD_CASES)
 def test_dense_forward_vs_float64(dev, case):
     from collie_amd import ops

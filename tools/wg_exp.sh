@@ -11,8 +11,8 @@ import csv, sys, collections, re
 d = collections.defaultdict(list)
 for r in csv.DictReader(open(sys.argv[1])):
     n = r['Kernel_Name']
-    if 'dense_wgrad' in n or 'dense_fwd_fast' in n:
-        short = re.search(r'dense_\w+(<[^>]*>)?', n).group(0)
+    if 'dense_' in n or 'narrow_' in n:
+        short = re.search(r'(dense|narrow)_\w+(<[^>]*>)?', n).group(0)
         key = (short, r['Grid_Size_X'], r['Grid_Size_Y'])
         d[key].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
 for k, v in sorted(d.items()):
