@@ -1004,19 +1004,22 @@ __global__ __launch_bounds__(kWdBlock, 2) void dense_wgrad_dma_kernel(const WgPa
 // newest J memory operations are always the DMA of the newest image (what the vmcnt waits assume).
 constexpr int kDfBlock = 512;
 constexpr int kDfRows = 64;
-constexpr int kDfTileF4 = 4 * kDfRows * 8;
 
 // KS = 2 (n_in = 384: the W fragments of a 32 x 384 block do not fit one wave's registers): the two
 // waves of a column tile split the K-TILES of every image instead of its rows -- each holds half of W
 // and both 32-row sub-tiles -- and the second hands its sums to the first through LDS at the end of a
 // tile (one more rounding order than the register-staged kernel: compared to 1e-5, not bit for bit).
-template <int NCH, bool ACT, int KS>
+template <int NCH, bool ACT, int KS, int KT>
 __global__ __launch_bounds__(kDfBlock, 2) void dense_fwd_dma_kernel(const FwdParams p) {
   constexpr int NB = ACT ? 2 : 3;
-  constexpr int kSlabF4 = kDfTileF4 * (ACT ? 2 : 1);
-  constexpr int J = 4 * (ACT ? 2 : 1);
+  constexpr int kImgF4 = KT * kDfRows * 8;  // one image: KT k-tiles of 32 columns
+  constexpr int kSlabF4 = kImgF4 * (ACT ? 2 : 1);
+  constexpr int J = KT * (ACT ? 2 : 1);
+  constexpr int CW = KT * 32;              // operand columns per image
+  constexpr int NS = KT * 4;               // MFMA steps (of 4) per image
+  static_assert(KS == 1 || KT == 4, "the K split is written for 128-column images");
   constexpr int kWaves = kDfBlock / kWave;
-  constexpr int NW = NCH * 16 / KS;        // W fragments (float4) per wave
+  constexpr int NW = NCH * NS / KS;        // W fragments (float4) per wave
   constexpr int NA = KS;                   // accumulator tiles per wave
   __shared__ f32x4 smem[NB * kSlabF4];
   __shared__ int32_t idring[2][kWaves][kWave];
@@ -1049,7 +1052,7 @@ __global__ __launch_bounds__(kDfBlock, 2) void dense_fwd_dma_kernel(const FwdPar
     const bool wvec = p.w_ld_in == 1 && reinterpret_cast<uintptr_t>(p.w) % 16 == 0 && p.w_ld_out % 4 == 0;
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
-      const int qq = KS == 1 ? i : (i / 8) * 16 + (2 * rh + (i / 4 & 1)) * 4 + (i & 3);
+      const int qq = KS == 1 ? i : (i / 8) * 16 + (2 * rh + (i / 4 & 1)) * 4 + (i & 3);  // KS = 2: KT = 4
       if (wvec) {
         wf[i] = *reinterpret_cast<const f32x4*>(wrow + qq * 8 + 4 * h);
       } else {
@@ -1060,7 +1063,7 @@ __global__ __launch_bounds__(kDfBlock, 2) void dense_fwd_dma_kernel(const FwdPar
   }
   float bias_n = p.bias ? p.bias[nt * 32 + col] : 0.0f;
 
-  // the segment of each 128-column chunk (segment bounds are multiples of 128: checked by the host)
+  // the segment of each image's columns (segment bounds are multiples of the image width: checked by the host)
   const float* c_src[NCH];
   const float* c_act[NCH];
   const char* c_idx[NCH];
@@ -1072,10 +1075,10 @@ __global__ __launch_bounds__(kDfBlock, 2) void dense_fwd_dma_kernel(const FwdPar
     int si = 0;
 #pragma unroll
     for (int j = 1; j < COLLIE_DENSE_MAX_SEGS; ++j)
-      if (j < p.x.n_seg && c * 128 >= p.x.s[j].begin) si = j;
+      if (j < p.x.n_seg && c * CW >= p.x.s[j].begin) si = j;
     const Seg& sg = p.x.s[si];
-    c_src[c] = sg.src + (c * 128 - sg.begin);
-    c_act[c] = sg.act ? sg.act + (c * 128 - sg.begin) : nullptr;
+    c_src[c] = sg.src + (c * CW - sg.begin);
+    c_act[c] = sg.act ? sg.act + (c * CW - sg.begin) : nullptr;
     c_idx[c] = static_cast<const char*>(sg.idx);
     c_ld[c] = sg.ld;
     c_act_ld[c] = sg.act_ld;
@@ -1110,11 +1113,11 @@ __global__ __launch_bounds__(kDfBlock, 2) void dense_fwd_dma_kernel(const FwdPar
     const float* g = c_src[c] + row * c_ld[c] + sw;
     f32x4* dst = smem + buf * kSlabF4 + wave * 64;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) dma_to_lds<16>(g + j * 32, dst + j * 512);
+    for (int j = 0; j < KT; ++j) dma_to_lds<16>(g + j * 32, dst + j * 512);
     if (ACT) {
       const float* a = c_act[c] + m * c_act_ld[c] + sw;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) dma_to_lds<16>(a + j * 32, dst + kDfTileF4 + j * 512);
+      for (int j = 0; j < KT; ++j) dma_to_lds<16>(a + j * 32, dst + kImgF4 + j * 512);
     }
   };
   // slab s = (tile t0 + s / NCH, chunk s % NCH); its ids live in idring slot s & 1
@@ -1202,7 +1205,7 @@ __global__ __launch_bounds__(kDfBlock, 2) void dense_fwd_dma_kernel(const FwdPar
         const int at = j * 512 + arow * 8 + ((2 * q + h) ^ (arow & 7));
         f32x4 a = img[at];
         if (ACT) {
-          const f32x4 r = img[kDfTileF4 + at];
+          const f32x4 r = img[kImgF4 + at];
 #pragma unroll
           for (int e = 0; e < 4; ++e) a[e] = r[e] > 0.0f ? a[e] : a[e] * p.slope;
         }
@@ -1210,11 +1213,11 @@ __global__ __launch_bounds__(kDfBlock, 2) void dense_fwd_dma_kernel(const FwdPar
       };
       f32x4 a0 = frag(0), a1 = frag(1);
 #pragma unroll
-      for (int step = 0; step < 16; ++step) {
+      for (int step = 0; step < NS; ++step) {
         const f32x4 a = a0;
         a0 = a1;
-        if (step + 2 < 16) a1 = frag(step + 2);
-        const f32x4 w = wf[KS == 1 ? c * 16 + step : c * 8 + (step & 7)];
+        if (step + 2 < NS) a1 = frag(step + 2);
+        const f32x4 w = wf[KS == 1 ? c * NS + step : c * 8 + (step & 7)];
         const int a_i = KS == 1 ? 0 : step >> 3;
         acc[a_i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], w[0], acc[a_i], 0, 0, 0);
         acc[a_i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], w[1], acc[a_i], 0, 0, 0);
@@ -1400,16 +1403,18 @@ int build_operand(Operand& op, const collie_dense_operand* in, int64_t m, bool& 
   return 0;
 }
 
-// the LDS-DMA forward takes: exactly 128 output columns, n_in of 128 / 256 / 384 in segments that start
-// on 128-column chunks, no per-row bias tables; with an activation reference only n_in = 128
+// the LDS-DMA forward takes: exactly 128 output columns, n_in of 64 / 128 / 256 / 384 in segments that
+// start on image boundaries (64 columns for n_in = 64, else 128), no per-row bias tables; with an
+// activation reference only n_in <= 128
 bool fwd_dma_ok(const FwdParams& p) {
   const char* e = getenv("COLLIE_FWD_DMA");     // "0": the register-staged kernel (tests compare both)
   if (e && e[0] == '0') return false;
-  if (p.n_out != 128 || (p.n_in != 128 && p.n_in != 256 && p.n_in != 384)) return false;
+  if (p.n_out != 128 || (p.n_in != 64 && p.n_in != 128 && p.n_in != 256 && p.n_in != 384)) return false;
   if (p.user_bias || p.m < 1) return false;
-  if (p.has_act && p.n_in != 128) return false;
+  if (p.has_act && p.n_in > 128) return false;
+  const int cw = p.n_in == 64 ? 64 : 128;
   for (int i = 0; i < p.x.n_seg; ++i)
-    if (p.x.s[i].begin % 128 || p.x.s[i].end % 128) return false;
+    if (p.x.s[i].begin % cw || p.x.s[i].end % cw) return false;
   return true;
 }
 
@@ -1419,10 +1424,14 @@ void launch_fwd(const FwdParams& p, bool vec, hipStream_t stream) {
   if (vec && fwd_dma_ok(p)) {
     const int64_t ntiles = (p.m + kDfRows - 1) / kDfRows;
     const dim3 grid(static_cast<unsigned>(ntiles < 256 ? ntiles : 256)), block(kDfBlock);
-    if (p.has_act) hipLaunchKernelGGL((dense_fwd_dma_kernel<1, true, 1>), grid, block, 0, stream, p);
-    else if (p.n_in == 128) hipLaunchKernelGGL((dense_fwd_dma_kernel<1, false, 1>), grid, block, 0, stream, p);
-    else if (p.n_in == 256) hipLaunchKernelGGL((dense_fwd_dma_kernel<2, false, 1>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((dense_fwd_dma_kernel<3, false, 2>), grid, block, 0, stream, p);
+#define COLLIE_DF(NCH, KS, KT)                                                                         \
+  if (p.has_act) hipLaunchKernelGGL((dense_fwd_dma_kernel<NCH, true, KS, KT>), grid, block, 0, stream, p); \
+  else hipLaunchKernelGGL((dense_fwd_dma_kernel<NCH, false, KS, KT>), grid, block, 0, stream, p)
+    if (p.n_in == 64) { COLLIE_DF(1, 1, 2); }
+    else if (p.n_in == 128) { COLLIE_DF(1, 1, 4); }
+    else if (p.n_in == 256) hipLaunchKernelGGL((dense_fwd_dma_kernel<2, false, 1, 4>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((dense_fwd_dma_kernel<3, false, 2, 4>), grid, block, 0, stream, p);
+#undef COLLIE_DF
     return;
   }
   if (vec) {

@@ -78,6 +78,9 @@ FWD_DMA_CASES = [
     (77, [128], [True], [False], 128, True),
     (30000, [128], [False], [True], 128, False),
     (129, [128], [True], [True], 128, False),
+    # n_in = 64: 64-column images
+    (3000, [64], [False], [True], 128, False),
+    (100, [64], [True], [False], 128, True),
     # n_in = 384: the two waves of a column tile split K (one more rounding order: 1e-5, not bits)
     (5000, [128, 128, 128], [True, True, False], [False, False, False], 128, True),
     (64 * 300 + 5, [384], [False], [False], 128, False),
