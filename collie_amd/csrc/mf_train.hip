@@ -643,13 +643,18 @@ __device__ __forceinline__ float wave_max_from_groups(float v) {
 // N LDS-DMA loads of 16 bytes per lane: source src + I * SRC_BYTES, destination dst + I * DST_F4
 // float4 slots (+ lane * 16 by the hardware).  The instruction's immediate offset is added to the
 // global address AND to the LDS address, so the LDS base passed for load I is pulled back by it.
+// Issued through inline asm: after __builtin_amdgcn_global_load_lds the compiler makes every later
+// LDS read wait for ALL outstanding LDS-DMA, which would serialise the two parking areas below (the
+// gather of sample b + 1 is in flight while sample b is read back).  The waits are explicit.
 template <int I, int N, int SRC_BYTES, int DST_F4>
 __device__ __forceinline__ void glds_chunks(const float* src, float4* dst) {
   static_assert(DST_F4 * 16 >= SRC_BYTES, "LDS base would move below the parking area");
   if constexpr (I < N) {
-    __builtin_amdgcn_global_load_lds(
-        (gptr_t)src, (lptr_t)(reinterpret_cast<char*>(dst) + I * (DST_F4 * 16 - SRC_BYTES)), 16,
-        I * SRC_BYTES, 0);
+    const uint32_t l = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(
+        (lptr_t)(reinterpret_cast<char*>(dst) + I * (DST_F4 * 16 - SRC_BYTES)))));
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off offset:%2"
+                 ::"v"(src), "s"(l), "n"(I * SRC_BYTES)
+                 : "memory", "m0");
     glds_chunks<I + 1, N, SRC_BYTES, DST_F4>(src, dst);
   }
 }
@@ -679,12 +684,18 @@ __device__ __forceinline__ LdsIds<NP> load_lds_ids(const LdsParams& p, int64_t b
 // NP = 2 the lane groups are wider (LPR = 8 at K = 10), so every wave-instruction of the gather
 // reads 128 contiguous bytes of each row (a full cache line) instead of 64.
 template <int CH, int LPR, int NP, int KIND, bool META>
-__global__ __launch_bounds__(kBlock, (CH * NP <= 4 ? 8 : 4)) void mf_train_fwd_lds(const LdsParams p) {
+__global__ __launch_bounds__(kBlock, 4) void mf_train_fwd_lds(const LdsParams p) {
+  // Small rows (<= 4 chunk instructions per sample): two parking areas per wave and a software
+  // pipeline, 4 waves per SIMD (ML-20M shape: forward kernel 582 -> 554 us).  Larger rows keep one
+  // area and 4 waves per SIMD: on HBM-resident tables the kernel runs at the chip's request rate
+  // and the halved occupancy of a second area costs more than the overlap gives (1.79 -> 1.84 ms).
+  constexpr bool PIPE = CH * NP <= 4;
   constexpr int G = kWave / LPR;
   constexpr int kPassF4 = CH * kWave;      // float4 slots of one pass of the item parking area
   constexpr int kItemF4 = NP * kPassF4;
   constexpr int kUserF4 = CH * LPR;
-  __shared__ float4 park[kWavesPerBlock][kItemF4 + kUserF4];
+  // PIPE: two parking areas per wave, the gather of sample b + 1 lands while sample b is read back
+  __shared__ float4 park[kWavesPerBlock][PIPE ? 2 : 1][kItemF4 + kUserF4];
 
   const int lane = lane_id();
   const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
@@ -695,8 +706,6 @@ __global__ __launch_bounds__(kBlock, (CH * NP <= 4 ? 8 : 4)) void mf_train_fwd_l
   const int64_t B = p.batch;
   const uint32_t key_off = static_cast<uint32_t>(p.num_users);
   const int tag = p.dyn ? p.dyn->tag : touch_tag(p.step_id);
-  float4* const items_l = &park[wave_in_block][0];
-  float4* const user_l = &park[wave_in_block][kItemF4];
   bool row_lane[NP], neg_lane[NP];
   int64_t neg_lane_off[NP];
 #pragma unroll
@@ -748,56 +757,125 @@ __global__ __launch_bounds__(kBlock, (CH * NP <= 4 ? 8 : 4)) void mf_train_fwd_l
     }
   };
 
-  LdsIds<NP> next;
-  next.u = next.pos = 0;
-#pragma unroll
-  for (int q = 0; q < NP; ++q) next.neg[q] = 0;
-  if (b < b_end) next = load_lds_ids<NP>(p, b, neg_lane_off);
-  for (; b < b_end; ++b) {
-    const LdsIds<NP> cur = next;
-    const int u = __builtin_amdgcn_readfirstlane(cur.u);
-    const int pos_item = __builtin_amdgcn_readfirstlane(cur.pos);
+  // A sample in flight: its ids decoded, its gathers and scalar loads issued (nothing consumed).
+  struct Flight {
+    int u, pos_item;
     int item[NP];
+    bool bad;
+    float ub;
+    float ib[NP];
+    int stamp[NP];
+  };
+  auto launch = [&](const LdsIds<NP>& ids, int buf) {
+    Flight f;
+    f.u = __builtin_amdgcn_readfirstlane(ids.u);
+    f.pos_item = __builtin_amdgcn_readfirstlane(ids.pos);
     bool bad_lane = false;
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
-      const int64_t item64 = (q == 0 && grp == 0) ? static_cast<int64_t>(pos_item) : cur.neg[q];
+      const int64_t item64 = (q == 0 && grp == 0) ? static_cast<int64_t>(f.pos_item) : ids.neg[q];
       bad_lane |= static_cast<uint64_t>(item64) >= static_cast<uint64_t>(p.num_items);
-      item[q] = static_cast<int>(item64);
+      f.item[q] = static_cast<int>(item64);
     }
-    const bool bad = static_cast<uint32_t>(u) >= static_cast<uint32_t>(p.num_users) ||
-                     (__ballot(bad_lane) != 0ull);
-    if (bad) {  // wave-uniform: never touch memory through a bad id
-      if (b + 1 < b_end) next = load_lds_ids<NP>(p, b + 1, neg_lane_off);
-      if (lane == 0 && p.status) atomicOr(p.status, 1);
-      if (p.need_grad) collect(b, 0u, key_off, key_off, false, 0.0f);
-      continue;
-    }
-
-    // ---- gathers: LDS-DMA, nothing lands in a VGPR -------------------------------------------
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // last sample's parking reads are done
+    f.bad = static_cast<uint32_t>(f.u) >= static_cast<uint32_t>(p.num_users) ||
+            (__ballot(bad_lane) != 0ull);
+    f.ub = 0.0f;
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
-      const float* irow = p.item_emb + static_cast<int64_t>(item[q]) * D + lig * 4;
-      glds_chunks<0, CH, LPR * 16, kWave>(irow, items_l + q * kPassF4);
+      f.ib[q] = 0.0f;
+      f.stamp[q] = 0;
+    }
+    if (f.bad) return f;  // wave-uniform: never touch memory through a bad id
+    // ---- gathers: LDS-DMA, nothing lands in a VGPR -------------------------------------------
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // earlier reads of this parking area are done
+    float4* const il = &park[wave_in_block][buf][0];
+    float4* const ul = &park[wave_in_block][buf][kItemF4];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const float* irow = p.item_emb + static_cast<int64_t>(f.item[q]) * D + lig * 4;
+      glds_chunks<0, CH, LPR * 16, kWave>(irow, il + q * kPassF4);
     }
     if (grp == 0) {
-      const float* urow = p.user_emb + static_cast<int64_t>(u) * D + lig * 4;
-      glds_chunks<0, CH, LPR * 16, LPR>(urow, user_l);
+      const float* urow = p.user_emb + static_cast<int64_t>(f.u) * D + lig * 4;
+      glds_chunks<0, CH, LPR * 16, LPR>(urow, ul);
     }
-    const float ub = p.user_bias[u];
+    f.ub = p.user_bias[f.u];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      f.ib[q] = p.item_bias[f.item[q]];
+      // the item's stamp: most items of a large batch were already stamped by another sample of
+      // this step; a stale read only costs a redundant store
+      if (p.need_grad) f.stamp[q] = p.touch_item[f.item[q]];
+    }
+    return f;
+  };
+
+  // Software pipeline over the wave's samples: at the top of iteration b everything issued so far
+  // has landed (gather of b, its scalars, the ids of b + 1); the gather of b + 1 and the ids of
+  // b + 2 are then issued BEFORE sample b is computed from its parking area.  The compiler's own
+  // waits for the VGPR loads are forced to the top of the loop (the "+v" touches): a wait placed
+  // later would also drain the DMA it cannot see -- vmcnt is one in-order counter.
+  LdsIds<NP> ids_next;
+  ids_next.u = ids_next.pos = 0;
+#pragma unroll
+  for (int q = 0; q < NP; ++q) ids_next.neg[q] = 0;
+  Flight fl;
+  fl.u = fl.pos_item = 0;
+  fl.bad = true;
+  fl.ub = 0.0f;
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {
+    fl.item[q] = 0;
+    fl.ib[q] = 0.0f;
+    fl.stamp[q] = 0;
+  }
+  if (b < b_end) {
+    LdsIds<NP> first = load_lds_ids<NP>(p, b, neg_lane_off);
+    asm volatile("" : "+v"(first.u), "+v"(first.pos));
+#pragma unroll
+    for (int q = 0; q < NP; ++q) asm volatile("" : "+v"(first.neg[q]));
+    if (PIPE) {
+      fl = launch(first, 0);
+      if (b + 1 < b_end) ids_next = load_lds_ids<NP>(p, b + 1, neg_lane_off);
+    } else {
+      ids_next = first;
+    }
+  }
+  int pbuf = 0;
+  for (; b < b_end; ++b, pbuf ^= (PIPE ? 1 : 0)) {
+    if (!PIPE) {  // one parking area: issue, then wait (other waves fill the gap)
+      fl = launch(ids_next, 0);
+      if (b + 1 < b_end) ids_next = load_lds_ids<NP>(p, b + 1, neg_lane_off);
+    }
+    asm volatile("" : "+v"(fl.ub), "+v"(ids_next.u), "+v"(ids_next.pos));
+#pragma unroll
+    for (int q = 0; q < NP; ++q)
+      asm volatile("" : "+v"(fl.ib[q]), "+v"(fl.stamp[q]), "+v"(ids_next.neg[q]));
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const Flight cur = fl;
+    if (PIPE && b + 1 < b_end) {
+      fl = launch(ids_next, pbuf ^ 1);
+      if (b + 2 < b_end) ids_next = load_lds_ids<NP>(p, b + 2, neg_lane_off);
+    }
+    const int u = cur.u;
+    const int pos_item = cur.pos_item;
+    int item[NP];
     float ib[NP];
     int stamp[NP];
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
-      ib[q] = p.item_bias[item[q]];
-      // the item's stamp: most items of a large batch were already stamped by another sample of
-      // this step; a stale read only costs a redundant store
-      stamp[q] = 0;
-      if (p.need_grad) stamp[q] = p.touch_item[item[q]];
+      item[q] = cur.item[q];
+      ib[q] = cur.ib[q];
+      stamp[q] = cur.stamp[q];
     }
-    if (b + 1 < b_end) next = load_lds_ids<NP>(p, b + 1, neg_lane_off);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const float ub = cur.ub;
+    if (cur.bad) {
+      if (lane == 0 && p.status) atomicOr(p.status, 1);
+      if (p.need_grad) collect(b, 0u, key_off, key_off, false, 0.0f);
+      continue;
+    }
+    float4* const items_l = &park[wave_in_block][pbuf][0];
+    float4* const user_l = &park[wave_in_block][pbuf][kItemF4];
 
     // ---- dot products: chunk order i, then across the LPR lanes of the row ----------------------
     float s[NP];
