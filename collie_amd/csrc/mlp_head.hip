@@ -867,16 +867,19 @@ __global__ __launch_bounds__(kWdBlock, 2) void dense_wgrad_dma_kernel(const WgPa
     }
   };
   auto issue = [&](int buf, int slot) {
+    // all id reads first: an asm statement is a barrier for the compiler's scheduling, and a read
+    // placed between two DMA instructions would expose its LDS latency once per stream
+    uint32_t r[J];
 #pragma unroll
     for (int j = 0; j < J; ++j) {
-      uint32_t r = 0;
-      if (idstep[j] != 0) {
-        r = static_cast<uint32_t>(idring[slot][wave][j][lane]);
-        const bool bad = r >= nrows[j];          // flagged at the end, row 0 read instead
-        any_bad |= bad;
-        r = bad ? 0u : r;
-      }
-      const char* g = src[j] + static_cast<int64_t>(r) * ldb[j];
+      r[j] = 0;
+      if (idstep[j] != 0) r[j] = static_cast<uint32_t>(idring[slot][wave][j][lane]);
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const bool bad = idstep[j] != 0 && r[j] >= nrows[j];   // flagged at the end, row 0 read instead
+      any_bad |= bad;
+      const char* g = src[j] + static_cast<int64_t>(bad ? 0u : r[j]) * ldb[j];
       dma_to_lds<16>(g, smem + buf * kSlabF + ldsoff[j]);
       src[j] += step[j];
     }
@@ -1480,16 +1483,18 @@ bool wgrad_dma_ok(const WgParams& p) {
   if (e && e[0] == '0') return false;
   const int rows = wgrad_dma_rows(p.n_out, p.n_in);
   if (p.dz_scalar || rows == 0) return false;
-  if (p.m % rows || p.chunk % rows) return false;
+  if (p.m % rows) return false;   // chunks are multiples of 32 rows
   if (p.dz.n_seg != 1 || p.dz.s[0].idx) return false;
   for (int i = 0; i < p.x.n_seg; ++i)
     if (p.x.s[i].act || p.x.s[i].begin % 32 || p.x.s[i].end % 32) return false;
   return true;
 }
 
-int64_t wgrad_chunks(int64_t m, int64_t* chunk_out) {
+int64_t wgrad_chunks(int64_t m, int64_t* chunk_out, int64_t max_chunks = 512) {
   int64_t nchunks = (m + 255) / 256;
-  if (nchunks > 512) nchunks = 512;  // two resident workgroups per CU: one round of chunks
+  // register-staged kernel: two resident workgroups per CU; LDS-DMA kernel: one (max_chunks 256) --
+  // one round of chunks either way, and half the partial sums to write and add for the latter
+  if (nchunks > max_chunks) nchunks = max_chunks;
   if (nchunks < 1) nchunks = 1;
   int64_t chunk = (m + nchunks - 1) / nchunks;
   chunk = (chunk + 31) / 32 * 32;
@@ -1602,7 +1607,7 @@ extern "C" int collie_dense_weight_grad(const collie_dense_operand* dz,
                  p.dz.width, p.x.width, n_out, n_in);
   if (n_in % 4) vec = false;  // the ones column must start a 16-byte slot
   int64_t chunk;
-  const int64_t nchunks = wgrad_chunks(m, &chunk);
+  int64_t nchunks = wgrad_chunks(m, &chunk);
   p.m = m;
   p.chunk = chunk;
   p.n_out = n_out;
@@ -1610,12 +1615,17 @@ extern "C" int collie_dense_weight_grad(const collie_dense_operand* dz,
   p.slope = slope;
   p.partial = static_cast<float*>(workspace);
   p.status = status;
+  const bool dma = vec && wgrad_dma_ok(p);
+  if (dma) {
+    nchunks = wgrad_chunks(m, &chunk, 256);
+    p.chunk = chunk;
+  }
   const unsigned gz = static_cast<unsigned>((n_out + kWgTile - 1) / kWgTile);
   const int lpr_x = narrow_lpr(n_in);
   if (n_out == 1 && lpr_x && narrow_operand(p.dz, 1) && narrow_operand(p.x, n_in)) {
     hipLaunchKernelGGL(narrow_wgrad_kernel, dim3(static_cast<unsigned>(nchunks)), dim3(kNarrowBlock), 0,
                        stream, p, lpr_x);
-  } else if (vec && wgrad_dma_ok(p)) {
+  } else if (dma) {
     const dim3 grid(static_cast<unsigned>(nchunks)), block(kWdBlock);
     const bool act = p.dz.s[0].act != nullptr;
 #define COLLIE_WD(NT, KT, R)                                                                       \

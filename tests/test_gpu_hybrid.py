@@ -214,6 +214,7 @@ WG_CASES = [
     (2064, [128], [False], 128),
     (16, [64, 64], [True, True], 128),
     (45056, [128, 256], [False, True], 128),
+    (256 * 256 + 4096, [128], [True], 128),
     # the narrow layers of the default head (32-row slabs; 32 x 64: the waves also split the rows)
     (4128, [128], [False], 64),
     (2080, [64, 64], [True, False], 64),
@@ -240,9 +241,10 @@ def test_dense_weight_grad_vs_float64(dev, case):
 @pytest.mark.parametrize('case', [c for c in WG_CASES if c[3] in (32, 64, 128) and c[0] % 16 == 0])
 @pytest.mark.parametrize('masked', [True, False])
 def test_dense_weight_grad_dma_equals_register_kernel(dev, case, masked, monkeypatch):
-    """The LDS-DMA weight gradient feeds the MFMAs the same rows in the same order over the same
-    chunks as the register-staged kernel: dW bit for bit (32 x 64, where the waves split the rows of
-    a slab: to 1e-5), db (another summation order) to 1e-5."""
+    """The LDS-DMA weight gradient feeds the MFMAs the same rows in the same order as the
+    register-staged kernel: dW bit for bit while both cut the batch into the same chunks (up to
+    256 x 256 rows; beyond that the DMA kernel uses half as many, and 32 x 64 splits the rows of a
+    slab over its waves: 1e-5), db (another summation order) to 1e-5."""
     from collie_amd import ops
     m, widths, gathered, n_out = case
     rng = np.random.default_rng(m + 1)
@@ -251,7 +253,7 @@ def test_dense_weight_grad_dma_equals_register_kernel(dev, case, masked, monkeyp
     dw, db, _ = ops.dense_weight_grad(dz_op, x_op, m, n_out, x.shape[1])
     monkeypatch.setenv('COLLIE_WGRAD_DMA', '0')
     dw0, db0, _ = ops.dense_weight_grad(dz_op, x_op, m, n_out, x.shape[1])
-    if n_out == 32:
+    if n_out == 32 or m > 256 * 256:
         close(dw.cpu().numpy(), dw0.cpu().numpy())
     else:
         assert torch.equal(dw, dw0)
