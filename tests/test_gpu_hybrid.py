@@ -455,6 +455,61 @@ def test_hybrid_forward_and_trajectory_vs_torch_path(dev, case):
                 assert np.median(diff) <= 2e-4 * max(np.abs(want).max(), 1e-30), name
 
 
+@pytest.mark.parametrize('loss', ['adaptive_bpr', 'adaptive', 'warp'])
+@pytest.mark.parametrize('frozen', [True, False])
+def test_hybrid_backward_on_active_rows_equals_full_backward(dev, loss, frozen, monkeypatch):
+    """Under the one-negative losses the backward runs on the 2 B rows whose score gradient can
+    differ from zero (``_compact_rows``); every gradient must equal the backward over all
+    (1 + K) B rows, which is what the reference's autograd computes."""
+    from collie_amd.hybrid import HybridPretrainedModel
+    U, N, D, K, B = 300, 200, 128, 6, 512
+    rng = np.random.default_rng(3)
+    inter, mf = _mf_model(dev, U, N, D, K, 5)
+    item_md = torch.tensor(rng.normal(size=(N, 256)).astype(np.float32))
+    model = HybridPretrainedModel(train=inter, trained_model=mf, item_metadata=item_md,
+                                  item_metadata_layers_dims=[128], freeze_embeddings=frozen,
+                                  loss=loss, lr_scheduler_func=None).to(dev)
+    model.train()
+    batch = ((torch.tensor(rng.integers(0, U, B), dtype=torch.int32, device=dev),
+              torch.tensor(rng.integers(0, N, B), dtype=torch.int32, device=dev)),
+             torch.tensor(rng.integers(0, N, (B, K)), device=dev))
+
+    def grads():
+        model._staged_rows.clear()
+        for p in model.parameters():
+            p.grad = None
+        model.calculate_loss(batch).backward()
+        out = {}
+        for name, p in model.named_parameters():
+            if not p.requires_grad:
+                continue
+            staged = model._staged_rows.get(id(p))
+            if staged is not None:
+                ids, vals = staged
+                dense = np.zeros(p.shape, np.float64)
+                np.add.at(dense, ids.cpu().numpy(), vals.cpu().numpy().reshape(len(ids), -1))
+                out[name] = (dense, len(ids))
+            else:
+                out[name] = (p.grad.cpu().numpy().astype(np.float64), None)
+        return out
+
+    got = grads()
+    monkeypatch.setattr(HybridPretrainedModel, '_ONE_NEGATIVE_LOSSES', ())
+    want = grads()
+    assert got.keys() == want.keys()
+    for name in want:
+        g, n_rows = got[name]
+        w, n_rows_full = want[name]
+        if n_rows is not None:       # staged (row, value) lists: 2 B entries instead of (1 + K) B
+            assert (n_rows, n_rows_full) == (2 * B, (1 + K) * B)
+        # entries that cancel analytically (+g and -g of every sample: user biases, the last
+        # Linear bias) are rounding residue of 2 B terms of size ~|g| in the full backward and
+        # cancel pair by pair in the compact one: the floor of the scale covers that residue
+        scale = max(np.abs(w).max(), 0.05)
+        np.testing.assert_allclose(g, w, rtol=1e-5, atol=1e-4 * scale, err_msg=name)
+    model.check_status()
+
+
 def test_hybrid_evaluate_save_load(dev, tmp_path):
     """evaluate_in_batches takes the generic get_preds route for the hybrid model; save_model /
     load_model_path round-trip predictions (tests/test_model.py:1346-1385 in the reference)."""
