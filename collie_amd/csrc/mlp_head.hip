@@ -109,6 +109,10 @@ struct FwdParams {
   int64_t y_ld;
   int32_t* status;
   int has_act;  // some segment of x carries an activation reference
+  // optional: + addend[(m mod add_period), n] before the activation (a partial product that only
+  // depends on m mod add_period, computed once: collie_dense_forward_add)
+  const float* addend;
+  int64_t add_ld, add_period;
 };
 
 // 8 waves x 32 operand rows; every wave multiplies its rows by the same NTILES x 32 output columns.
@@ -193,6 +197,7 @@ __global__ __launch_bounds__(kFwdBlock) void dense_fwd_kernel(const FwdParams p)
       const int64_t m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
       if (m >= p.m) continue;
       float v = acc[nt][r] + bn;
+      if (p.addend) v += p.addend[(m % p.add_period) * p.add_ld + n];
       if (p.leaky) v = v > 0.0f ? v : v * p.slope;
       if (p.user_bias) {
         const int64_t u = load_idx(p.users, p.users_dtype, m);
@@ -409,6 +414,7 @@ __global__ __launch_bounds__(kFBlock, (NTILES == 4 && WVEC && !ACT ? 3 : 1)) voi
       const int64_t m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
       if (m >= p.m) continue;
       float v = acc[nt][r] + bn;
+      if (p.addend) v += p.addend[(m % p.add_period) * p.add_ld + n];
       if (p.leaky) v = v > 0.0f ? v : v * p.slope;
       if (p.user_bias) {
         const int64_t u = load_idx(p.users, p.users_dtype, m);
@@ -736,16 +742,22 @@ typedef __attribute__((address_space(3))) void* wd_lptr_t;
 // images of a ring apart -- which turns a multi-slab pipeline into load-then-compute.  The asm form
 // is invisible to that pass; the s_waitcnt vmcnt(N) in the loop below are the only waits, and the
 // barrier is the bare instruction (no fence).  `lds` must be wave-uniform.
+// `lds`: byte address inside the workgroup's LDS (lds_address() of a __shared__ array + offset).
 template <int BYTES>
-__device__ __forceinline__ void dma_to_lds(const void* g, const void* lds) {
-  const uint32_t l = __builtin_amdgcn_readfirstlane(
-      static_cast<uint32_t>(reinterpret_cast<uintptr_t>((wd_lptr_t)lds)));
+__device__ __forceinline__ void dma_to_lds(const void* g, uint32_t lds) {
+  const uint32_t l = __builtin_amdgcn_readfirstlane(lds);
   if (BYTES == 16)
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(l)
                  : "memory", "m0");
   else
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(g), "s"(l)
                  : "memory", "m0");
+}
+
+// LDS byte address of a __shared__ array (taken of the array itself, so the cast folds to a constant)
+template <typename T>
+__device__ __forceinline__ uint32_t lds_address(T* array) {
+  return static_cast<uint32_t>(reinterpret_cast<uintptr_t>((wd_lptr_t)array));
 }
 
 // the barrier instruction alone: LDS reads are complete once their values are used, the DMA writes
@@ -856,12 +868,13 @@ __global__ __launch_bounds__(kWdBlock, 2) void dense_wgrad_dma_kernel(const WgPa
   // EVERY outstanding memory operation where the value is used (vmcnt counts in order), which would
   // cut the DMA depth to one slab.  Ring of two per (wave, stream): written one step ahead.
   __shared__ int32_t idring[2][kWaves][J][kWave];
+  const uint32_t smem_at = lds_address(smem), idring_at = lds_address(&idring[0][0][0][0]);
   bool any_bad = false;
   auto fetch_ids = [&](int slot) {
 #pragma unroll
     for (int j = 0; j < J; ++j) {
       if (idstep[j] != 0) {                      // uniform: the stream gathers
-        dma_to_lds<4>(idp[j], &idring[slot][wave][j][0]);
+        dma_to_lds<4>(idp[j], idring_at + (((slot * kWaves + wave) * J + j) * kWave) * 4);
         idp[j] += idstep[j];
       }
     }
@@ -880,7 +893,7 @@ __global__ __launch_bounds__(kWdBlock, 2) void dense_wgrad_dma_kernel(const WgPa
       const bool bad = idstep[j] != 0 && r[j] >= nrows[j];   // flagged at the end, row 0 read instead
       any_bad |= bad;
       const char* g = src[j] + static_cast<int64_t>(bad ? 0u : r[j]) * ldb[j];
-      dma_to_lds<16>(g, smem + buf * kSlabF + ldsoff[j]);
+      dma_to_lds<16>(g, smem_at + (buf * kSlabF + ldsoff[j]) * 4);
       src[j] += step[j];
     }
   };
@@ -1012,7 +1025,7 @@ constexpr int kDfRows = 64;
 // waves of a column tile split the K-TILES of every image instead of its rows -- each holds half of W
 // and both 32-row sub-tiles -- and the second hands its sums to the first through LDS at the end of a
 // tile (one more rounding order than the register-staged kernel: compared to 1e-5, not bit for bit).
-template <int NCH, bool ACT, int KS, int KT>
+template <int NCH, bool ACT, int KS, int KT, bool ADD>
 __global__ __launch_bounds__(kDfBlock, 2) void dense_fwd_dma_kernel(const FwdParams p) {
   constexpr int NB = ACT ? 2 : 3;
   constexpr int kImgF4 = KT * kDfRows * 8;  // one image: KT k-tiles of 32 columns
@@ -1095,13 +1108,15 @@ __global__ __launch_bounds__(kDfBlock, 2) void dense_fwd_dma_kernel(const FwdPar
   for (int i = 0; i < NW; ++i) asm volatile("" : "+v"(wf[i]));
   asm volatile("" : "+v"(bias_n));
 
+  const uint32_t smem_at = lds_address(smem), idring_at = lds_address(&idring[0][0][0]);
   bool any_bad = false;
   auto row_of = [&](int64_t tile) {                 // operand row of this lane, clamped into [0, m)
     int64_t m = tile * kDfRows + lrow;
     return m < p.m ? m : p.m - 1;
   };
   auto fetch_ids = [&](int64_t tile, int c, int slot) {
-    if (c_idx[c]) dma_to_lds<4>(c_idx[c] + (row_of(tile) << c_sh[c]), &idring[slot][wave][0]);
+    if (c_idx[c])
+      dma_to_lds<4>(c_idx[c] + (row_of(tile) << c_sh[c]), idring_at + ((slot * kWaves + wave) * kWave) * 4);
   };
   auto issue = [&](int64_t tile, int c, int buf, int slot) {
     const int64_t m = row_of(tile);
@@ -1114,13 +1129,13 @@ __global__ __launch_bounds__(kDfBlock, 2) void dense_fwd_dma_kernel(const FwdPar
     }
     const int sw = (lslot ^ (lrow & 7)) * 4;
     const float* g = c_src[c] + row * c_ld[c] + sw;
-    f32x4* dst = smem + buf * kSlabF4 + wave * 64;
+    const uint32_t dst = smem_at + (buf * kSlabF4 + wave * 64) * 16;
 #pragma unroll
-    for (int j = 0; j < KT; ++j) dma_to_lds<16>(g + j * 32, dst + j * 512);
+    for (int j = 0; j < KT; ++j) dma_to_lds<16>(g + j * 32, dst + j * 512 * 16);
     if (ACT) {
       const float* a = c_act[c] + m * c_act_ld[c] + sw;
 #pragma unroll
-      for (int j = 0; j < KT; ++j) dma_to_lds<16>(a + j * 32, dst + kImgF4 + j * 512);
+      for (int j = 0; j < KT; ++j) dma_to_lds<16>(a + j * 32, dst + (kImgF4 + j * 512) * 16);
     }
   };
   // slab s = (tile t0 + s / NCH, chunk s % NCH); its ids live in idring slot s & 1
@@ -1143,6 +1158,28 @@ __global__ __launch_bounds__(kDfBlock, 2) void dense_fwd_dma_kernel(const FwdPar
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[a][i] = 0.0f;
   // store of a finished tile (KS = 2: the first wave of a pair, after adding the second's sums)
+  // Addend rows of a tile are loaded into registers one tile early -- right after the previous
+  // tile's stores and BEFORE that iteration's DMA issue -- and consumed after the next tile's first
+  // barrier: the compiler's wait for them then only covers DMA that is a whole iteration old.  (A load
+  // consumed where it is issued would drain the DMA ring once per tile: measured +200 us.)
+  // ADD: the kernel instances with an addend (every load below is unconditional: a load inside a
+  // branch makes the compiler wait for it at the join)
+  int64_t add_row0 = ADD ? (t0 * kDfRows) % p.add_period : 0;   // period >= 256: host check
+  float addv[ADD ? NA : 1][16];
+  auto load_addend = [&]() {
+    if (ADD) {
+      static_assert(!ADD || KS == 1, "addend instances keep one accumulator tile per wave");
+      const float* arow = p.addend + nt * 32 + col;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int64_t ar = add_row0 + rh * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (ar >= p.add_period) ar -= p.add_period;
+        addv[0][r] = arow[ar * p.add_ld];      // rows past m: a valid row, never stored
+      }
+      add_row0 += kDfRows;
+      if (add_row0 >= p.add_period) add_row0 -= p.add_period;
+    }
+  };
   auto store_tile = [&](int64_t tile) {
     const int n = nt * 32 + col;
     if (KS == 2 && rh != 0) return;
@@ -1150,10 +1187,12 @@ __global__ __launch_bounds__(kDfBlock, 2) void dense_fwd_dma_kernel(const FwdPar
     for (int a = 0; a < NA; ++a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int64_t m = tile * kDfRows + (KS == 1 ? rh : a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int lr = (KS == 1 ? rh : a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int64_t m = tile * kDfRows + lr;
         float v = acc[a][r];
         if (KS == 2) v += xbuf[((nt * 2 + a) * 16 + r) * kWave + lane];
         v += bias_n;
+        if (ADD) v += addv[0][r];
         if (p.leaky) v = v > 0.0f ? v : v * p.slope;
         if (m < p.m) p.y[m * p.y_ld + n] = v;
       }
@@ -1192,6 +1231,7 @@ __global__ __launch_bounds__(kDfBlock, 2) void dense_fwd_dma_kernel(const FwdPar
             for (int i = 0; i < 16; ++i) acc[a][i] = 0.0f;
         }
       }
+      if (c == 0) load_addend();
       if (s + NB - 1 < nslab) {
         if (s + NB < nslab) fetch_ids_slab(s + NB);
         issue_slab(s + NB - 1);
@@ -1415,6 +1455,7 @@ bool fwd_dma_ok(const FwdParams& p) {
   if (p.n_out != 128 || (p.n_in != 64 && p.n_in != 128 && p.n_in != 256 && p.n_in != 384)) return false;
   if (p.user_bias || p.m < 1) return false;
   if (p.has_act && p.n_in > 128) return false;
+  if (p.addend && (p.has_act || (p.n_in != 128 && p.n_in != 256))) return false;
   const int cw = p.n_in == 64 ? 64 : 128;
   for (int i = 0; i < p.x.n_seg; ++i)
     if (p.x.s[i].begin % cw || p.x.s[i].end % cw) return false;
@@ -1428,12 +1469,14 @@ void launch_fwd(const FwdParams& p, bool vec, hipStream_t stream) {
     const int64_t ntiles = (p.m + kDfRows - 1) / kDfRows;
     const dim3 grid(static_cast<unsigned>(ntiles < 256 ? ntiles : 256)), block(kDfBlock);
 #define COLLIE_DF(NCH, KS, KT)                                                                         \
-  if (p.has_act) hipLaunchKernelGGL((dense_fwd_dma_kernel<NCH, true, KS, KT>), grid, block, 0, stream, p); \
-  else hipLaunchKernelGGL((dense_fwd_dma_kernel<NCH, false, KS, KT>), grid, block, 0, stream, p)
-    if (p.n_in == 64) { COLLIE_DF(1, 1, 2); }
+  if (p.has_act) hipLaunchKernelGGL((dense_fwd_dma_kernel<NCH, true, KS, KT, false>), grid, block, 0, stream, p); \
+  else hipLaunchKernelGGL((dense_fwd_dma_kernel<NCH, false, KS, KT, false>), grid, block, 0, stream, p)
+    if (p.addend && p.n_in == 128) hipLaunchKernelGGL((dense_fwd_dma_kernel<1, false, 1, 4, true>), grid, block, 0, stream, p);
+    else if (p.addend) hipLaunchKernelGGL((dense_fwd_dma_kernel<2, false, 1, 4, true>), grid, block, 0, stream, p);
+    else if (p.n_in == 64) { COLLIE_DF(1, 1, 2); }
     else if (p.n_in == 128) { COLLIE_DF(1, 1, 4); }
-    else if (p.n_in == 256) hipLaunchKernelGGL((dense_fwd_dma_kernel<2, false, 1, 4>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((dense_fwd_dma_kernel<3, false, 2, 4>), grid, block, 0, stream, p);
+    else if (p.n_in == 256) hipLaunchKernelGGL((dense_fwd_dma_kernel<2, false, 1, 4, false>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((dense_fwd_dma_kernel<3, false, 2, 4, false>), grid, block, 0, stream, p);
 #undef COLLIE_DF
     return;
   }
@@ -1515,7 +1558,23 @@ extern "C" int collie_dense_forward(const collie_dense_operand* x, int64_t m, co
                                     int64_t num_users, const void* items, int32_t items_dtype,
                                     const float* item_bias, int64_t num_items, float* y,
                                     int64_t y_ld, int32_t* status, collie_stream_t stream_) {
+  return collie_dense_forward_add(x, m, w, w_ld_out, w_ld_in, bias, n_in, n_out, leaky, slope, users,
+                                  users_dtype, user_bias, num_users, items, items_dtype, item_bias,
+                                  num_items, nullptr, 0, 0, y, y_ld, status, stream_);
+}
+
+extern "C" int collie_dense_forward_add(const collie_dense_operand* x, int64_t m, const float* w,
+                                        int64_t w_ld_out, int64_t w_ld_in, const float* bias,
+                                        int32_t n_in, int32_t n_out, int32_t leaky, float slope,
+                                        const void* users, int32_t users_dtype,
+                                        const float* user_bias, int64_t num_users, const void* items,
+                                        int32_t items_dtype, const float* item_bias,
+                                        int64_t num_items, const float* addend, int64_t add_ld,
+                                        int64_t add_period, float* y, int64_t y_ld, int32_t* status,
+                                        collie_stream_t stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
+  COLLIE_REQUIRE(!addend || (add_ld >= n_out && add_period >= 256),
+                 "dense_forward_add: addend needs add_ld >= n_out and add_period >= 256");
   COLLIE_REQUIRE(m >= 1 && m < (int64_t{1} << 39), "dense_forward: bad row count %lld",
                  static_cast<long long>(m));
   COLLIE_REQUIRE(w && y && n_in >= 1 && n_out >= 1 && y_ld >= n_out, "dense_forward: bad W / Y");
@@ -1539,6 +1598,9 @@ extern "C" int collie_dense_forward(const collie_dense_operand* x, int64_t m, co
   p.w_ld_out = w_ld_out;
   p.w_ld_in = w_ld_in;
   p.bias = bias;
+  p.addend = addend;
+  p.add_ld = add_ld;
+  p.add_period = add_period;
   p.n_in = n_in;
   p.n_out = n_out;
   p.leaky = leaky;
@@ -1557,14 +1619,14 @@ extern "C" int collie_dense_forward(const collie_dense_operand* x, int64_t m, co
   for (int i = 0; i < p.x.n_seg; ++i)
     if (p.x.s[i].act) p.has_act = 1;
   const int lpr_in = narrow_lpr(n_in), lpr_out = narrow_lpr(n_out);
-  if (n_out == 1 && lpr_in && narrow_operand(p.x, n_in) && w_ld_in == 1 &&
+  if (!addend && n_out == 1 && lpr_in && narrow_operand(p.x, n_in) && w_ld_in == 1 &&
       reinterpret_cast<uintptr_t>(w) % 16 == 0) {
     const int64_t rows_per_block = kNarrowBlock / lpr_in;
     hipLaunchKernelGGL(narrow_gemv_kernel, dim3(static_cast<unsigned>((m + rows_per_block - 1) / rows_per_block)),
                        dim3(kNarrowBlock), 0, stream, p, lpr_in);
     return check_launch("narrow_gemv_kernel");
   }
-  if (n_in == 1 && lpr_out && narrow_operand(p.x, 1) && !bias && !leaky && !p.user_bias &&
+  if (!addend && n_in == 1 && lpr_out && narrow_operand(p.x, 1) && !bias && !leaky && !p.user_bias &&
       y_ld % 4 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0) {
     const int64_t rows_per_block = kNarrowBlock / lpr_out;
     hipLaunchKernelGGL(narrow_outer_kernel, dim3(static_cast<unsigned>((m + rows_per_block - 1) / rows_per_block)),

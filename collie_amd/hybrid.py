@@ -44,6 +44,7 @@ class _HeadScore(torch.autograd.Function):
         # set by calculate_loss for this one call: (B, K) of a batch whose loss gives at most one
         # negative per sample a gradient
         ctx.active_hint, model._active_rows_hint = model._active_rows_hint, None
+        model._user_period_hint = None
         return scores
 
     @staticmethod
@@ -112,6 +113,8 @@ class HybridPretrainedModel(MatrixFactorizationModel):
     """
     _mf_eval_fast = False       # evaluation goes through get_preds (the score is not a dot product)
     _active_rows_hint = None    # see calculate_loss / _head_backward
+    _user_period_hint = None    # see calculate_loss / _head_forward
+    _USER_SHARE_ONCE = True     # tests switch it off to compare with the plain first layer
     # losses of this library under which only the positive and ONE negative of a sample receive a
     # score gradient (adaptive: the arg-max negative, bpr.py:153-167 / hinge.py:157-171; WARP: the
     # first violation, warp.py:73-154)
@@ -395,8 +398,11 @@ class HybridPretrainedModel(MatrixFactorizationModel):
             if (K > 1 and kind in self._ONE_NEGATIVE_LOSSES
                     and self.loss_function is loss_mod.LOSS_FUNCTIONS.get(kind)):
                 self._active_rows_hint = (B, K)
+            # rows b, B + b, 2 B + b, ... share their user: the user embedding's share of the first
+            # combined layer is computed once per sample (_head_forward)
+            self._user_period_hint = B if (self._USER_SHARE_ONCE and B >= 256) else None
             preds = self(all_users, all_items)
-            self._active_rows_hint = None
+            self._active_rows_hint = self._user_period_hint = None
             pos_preds = preds[:B]
             neg_preds = preds[B:].view(K, B)
             return self.loss_function(
@@ -443,9 +449,25 @@ class HybridPretrainedModel(MatrixFactorizationModel):
         saved['segments'] = tagged
         x_segs = segs
         outs = []
-        for layer in self.combined_layers[:-1]:
-            out = ops.dense_forward(ops.dense_operand(*x_segs), m, layer.weight.data,
-                                    layer.bias.data, True, status=self._status_flag())
+        for li, layer in enumerate(self.combined_layers[:-1]):
+            period = self._user_period_hint
+            if (li == 0 and period is not None and m % period == 0 and m > period
+                    and tagged[0][0] == 'user_emb' and len(tagged) > 1):
+                # users = u.repeat(1 + K): X W^T = U[u] W_u^T + (rest of the row) W_rest^T, and the
+                # first term is the same for the 1 + K rows of a sample -- one small GEMM over B
+                # rows, added in the epilogue of the layer's GEMM over the remaining columns
+                d = tagged[0][1][0].shape[1]
+                part = ops.dense_forward(
+                    ops.dense_operand((self.embeddings[0].weight.data, users[:period], None)),
+                    period, layer.weight.data, None, False, status=self._status_flag(),
+                    col_range=(0, d))
+                out = ops.dense_forward(ops.dense_operand(*x_segs[1:]), m, layer.weight.data,
+                                        layer.bias.data, True, status=self._status_flag(),
+                                        col_range=(d, layer.weight.shape[1]),
+                                        addend=(part, period))
+            else:
+                out = ops.dense_forward(ops.dense_operand(*x_segs), m, layer.weight.data,
+                                        layer.bias.data, True, status=self._status_flag())
             outs.append((x_segs, out))
             x_segs = [(out, None, None)]
         last = self.combined_layers[-1]

@@ -421,10 +421,12 @@ def dense_operand(*segments):
 
 
 def dense_forward(x_op, m, weight, bias, leaky, transposed=False, out=None, row_bias=None,
-                  status=None, col_range=None):
+                  status=None, col_range=None, addend=None):
     """``F.leaky_relu(nn.Linear)`` (``leaky``) or plain ``nn.Linear`` over an operand;
     ``transposed=True`` multiplies by ``weight.T`` instead (data backward ``dZ @ W``).
-    ``row_bias = (users, user_bias_table, items, item_bias_table)`` adds the two bias-table rows."""
+    ``row_bias = (users, user_bias_table, items, item_bias_table)`` adds the two bias-table rows.
+    ``col_range`` without ``transposed``: the layer only multiplies W's input columns c0:c1.
+    ``addend = (P [period, n_out], period)``: ``+ P[row mod period]`` before the activation."""
     require_hip(weight, 'weight')
     assert weight.dtype == torch.float32 and weight.is_contiguous() and weight.dim() == 2
     w_ptr = ptr(weight)
@@ -435,8 +437,10 @@ def dense_forward(x_op, m, weight, bias, leaky, transposed=False, out=None, row_
         ld_out, ld_in = 1, weight.shape[1]
         w_ptr = c_void_p(weight.data_ptr() + 4 * c0)
     else:
-        n_out, n_in = weight.shape
+        c0, c1 = col_range if col_range is not None else (0, weight.shape[1])
+        n_out, n_in = weight.shape[0], c1 - c0
         ld_out, ld_in = weight.shape[1], 1
+        w_ptr = c_void_p(weight.data_ptr() + 4 * c0)
     if out is None:
         out = torch.empty(m, n_out, dtype=torch.float32, device=weight.device)
     users = items = ub = ib = None
@@ -445,12 +449,18 @@ def dense_forward(x_op, m, weight, bias, leaky, transposed=False, out=None, row_
         users, ub, items, ib = row_bias
         users, items = users.contiguous(), items.contiguous()
         nu, ni = ub.shape[0], ib.shape[0]
-    check(load().collie_dense_forward(
+    add_p, add_ld, add_period = None, 0, 0
+    if addend is not None:
+        add_p, add_period = addend
+        assert (add_p.dtype == torch.float32 and add_p.stride(1) == 1
+                and add_p.shape == (add_period, n_out))
+        add_ld = add_p.stride(0)
+    check(load().collie_dense_forward_add(
         byref(x_op), m, w_ptr, ld_out, ld_in, ptr(bias), n_in, n_out, 1 if leaky else 0,
         LEAKY_SLOPE, ptr(users), idx_dtype(users) if users is not None else 0, ptr(ub), nu,
-        ptr(items), idx_dtype(items) if items is not None else 0, ptr(ib), ni, ptr(out),
-        out.stride(0) if out.shape[0] > 1 else out.shape[1], ptr(status), stream_ptr()),
-        'collie_dense_forward')
+        ptr(items), idx_dtype(items) if items is not None else 0, ptr(ib), ni, ptr(add_p), add_ld,
+        add_period, ptr(out), out.stride(0) if out.shape[0] > 1 else out.shape[1], ptr(status),
+        stream_ptr()), 'collie_dense_forward_add')
     return out
 
 

@@ -602,6 +602,22 @@ int collie_dense_forward(const collie_dense_operand* x, int64_t m, const float* 
                          int32_t items_dtype, const float* item_bias, int64_t num_items, float* y,
                          int64_t y_ld, int32_t* status, collie_stream_t stream);
 
+/* collie_dense_forward with one more term before the activation: y = act(x W^T + b + addend[m mod
+ * add_period, :]), addend [add_period, >= n_out] floats with row pitch add_ld, add_period >= 256.
+ * For operands whose leading column segments only depend on m mod add_period -- calculate_loss feeds
+ * users.repeat(K + 1) (base_pipeline.py:616-621), so the user embedding's share of the first combined
+ * layer (hybrid_pretrained_matrix_factorization.py:430-446) is the same for the 1 + K rows of a
+ * sample: it is computed once per sample and added here, and the layer's GEMM runs over the
+ * remaining columns of W.  addend == NULL: exactly collie_dense_forward. */
+int collie_dense_forward_add(const collie_dense_operand* x, int64_t m, const float* w,
+                             int64_t w_ld_out, int64_t w_ld_in, const float* bias, int32_t n_in,
+                             int32_t n_out, int32_t leaky, float slope, const void* users,
+                             int32_t users_dtype, const float* user_bias, int64_t num_users,
+                             const void* items, int32_t items_dtype, const float* item_bias,
+                             int64_t num_items, const float* addend, int64_t add_ld,
+                             int64_t add_period, float* y, int64_t y_ld, int32_t* status,
+                             collie_stream_t stream);
+
 /* autograd of nn.Linear w.r.t. its parameters: dw[n, k] = sum_j dz[j, n] * x[j, k] ([n_out, n_in]
  * contiguous), db[n] = sum_j dz[j, n]; dz is usually the operand (dY, act_ref = Y).  Either output
  * may be NULL.  Deterministic (fixed chunks of rows, partials added in fixed order). */

@@ -119,6 +119,90 @@ def test_dense_forward_dma_equals_register_kernel(dev, case, monkeypatch):
     close(y.cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize('case', [
+    (4096, [128, 128], [True, False], 128, 512),     # LDS-DMA kernel, period divides the tiles
+    (64 * 37 + 11, [128], [True], 128, 300),         # ... and does not; ragged last tile
+    (5000, [128, 128, 128], [True, True, False], 128, 257),   # the split-K pair
+    (600, [64], [False], 48, 256),                   # register-staged kernel
+    (600, [5, 3], [True, False], 33, 299),           # generic kernel
+])
+def test_dense_forward_periodic_addend(dev, case):
+    """collie_dense_forward_add: y = act(x W^T + b + P[m mod period])."""
+    from collie_amd import ops
+    m, widths, gathered, n_out, period = case
+    rng = np.random.default_rng(m + period)
+    op, x = _operand_case(rng, m, widths, gathered, [False] * len(widths), dev)
+    n_in = x.shape[1]
+    w = (rng.normal(size=(n_out, n_in)) / np.sqrt(n_in)).astype(np.float32)
+    b = rng.normal(size=n_out).astype(np.float32)
+    part = rng.normal(size=(period, n_out)).astype(np.float32)
+    y = ops.dense_forward(op, m, torch.tensor(w, device=dev), torch.tensor(b, device=dev), True,
+                          addend=(torch.tensor(part, device=dev), period))
+    ref = x @ w.astype(np.float64).T + b + part[np.arange(m) % period]
+    ref = np.where(ref > 0, ref, ref * np.float64(np.float32(SLOPE)))
+    close(y.cpu().numpy(), ref)
+    # a column range of W: the layer multiplies only W[:, c0:c1]
+    wide = np.concatenate([rng.normal(size=(n_out, 8)).astype(np.float32), w], 1)
+    y2 = ops.dense_forward(op, m, torch.tensor(wide, device=dev), torch.tensor(b, device=dev), True,
+                           col_range=(8, 8 + n_in), addend=(torch.tensor(part, device=dev), period))
+    close(y2.cpu().numpy(), ref)
+
+
+def test_hybrid_user_share_of_first_layer_once_per_sample(dev, monkeypatch):
+    """calculate_loss feeds users.repeat(1 + K): the user embedding's share of the first combined
+    layer is computed once per sample and added in the epilogue; loss and every gradient must equal
+    the plain evaluation of the layer."""
+    from collie_amd.hybrid import HybridPretrainedModel
+    U, N, D, K, B = 300, 200, 128, 5, 512
+    rng = np.random.default_rng(8)
+    inter, mf = _mf_model(dev, U, N, D, K, 6)
+    item_md = torch.tensor(rng.normal(size=(N, 256)).astype(np.float32))
+    model = HybridPretrainedModel(train=inter, trained_model=mf, item_metadata=item_md,
+                                  item_metadata_layers_dims=[128], freeze_embeddings=False,
+                                  loss='adaptive_bpr', lr_scheduler_func=None).to(dev)
+    model.train()
+    batch = ((torch.tensor(rng.integers(0, U, B), dtype=torch.int32, device=dev),
+              torch.tensor(rng.integers(0, N, B), dtype=torch.int32, device=dev)),
+             torch.tensor(rng.integers(0, N, (B, K)), device=dev))
+    calls = []
+    real = HybridPretrainedModel._head_forward
+
+    def spy(self, users, items):
+        calls.append(self._user_period_hint)
+        return real(self, users, items)
+
+    monkeypatch.setattr(HybridPretrainedModel, '_head_forward', spy)
+
+    def run():
+        model._staged_rows.clear()
+        for p in model.parameters():
+            p.grad = None
+        loss = model.calculate_loss(batch)
+        loss.backward()
+        grads = {n: p.grad.cpu().numpy().copy() for n, p in model.named_parameters()
+                 if p.grad is not None}
+        rows = {n: torch.zeros_like(p).index_add_(0, model._staged_rows[id(p)][0].long(),
+                                                  model._staged_rows[id(p)][1].reshape(
+                                                      model._staged_rows[id(p)][0].shape[0], -1))
+                .cpu().numpy() for n, p in model.named_parameters() if id(p) in model._staged_rows}
+        return float(loss), grads, rows
+
+    l1, g1, r1 = run()
+    assert calls == [B]
+    monkeypatch.setattr(HybridPretrainedModel, '_USER_SHARE_ONCE', False)
+    l0, g0, r0 = run()
+    assert calls == [B, None]
+    assert abs(l1 - l0) <= 2e-6 * abs(l0)
+    assert g1.keys() == g0.keys() and r1.keys() == r0.keys() and len(r0) == 4
+    for k in g0:
+        scale = max(np.abs(g0[k]).max(), 0.05)
+        np.testing.assert_allclose(g1[k], g0[k], rtol=2e-5, atol=1e-4 * scale, err_msg=k)
+    for k in r0:
+        scale = max(np.abs(r0[k]).max(), 0.05)
+        np.testing.assert_allclose(r1[k], r0[k], rtol=2e-5, atol=1e-4 * scale, err_msg=k)
+    model.check_status()
+
+
 def test_dense_forward_dma_flags_out_of_range_rows(dev):
     from collie_amd import ops
     src = torch.ones(10, 128, device=dev)

@@ -24,12 +24,13 @@ sys.path.insert(0, ROOT)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA
 
 
-def step_flops(m, d, meta_cols, meta_dims, comb_dims, unfrozen, m_back=None):
+def step_flops(m, d, meta_cols, meta_dims, comb_dims, unfrozen, m_back=None, user_rows=None):
     """2 * rows * n_in * n_out per GEMM: forward + weight gradient for every layer, data gradient
     for every layer whose input needs one (never the raw metadata; the embedding slices of the
     first combined layer only when the embeddings train).  ``m_back``: rows the backward GEMMs run
     on (default m: what the reference's autograd does; the library runs them on the 2 B rows whose
-    score gradient can differ from zero)."""
+    score gradient can differ from zero).  ``user_rows``: rows the user embedding's share of the first
+    combined layer's forward is computed on (default m; the library: once per sample, B)."""
     mb = m if m_back is None else m_back
     total = 0
     dims = [meta_cols] + meta_dims
@@ -43,6 +44,8 @@ def step_flops(m, d, meta_cols, meta_dims, comb_dims, unfrozen, m_back=None):
         if i > 1:
             total += 2 * mb * comb[i - 1] * comb[i]
     total += 2 * mb * comb[1] * (meta_dims[-1] + (2 * d if unfrozen else 0))
+    if user_rows is not None:
+        total -= 2 * (m - user_rows) * d * comb[1]
     return total
 
 
@@ -102,8 +105,9 @@ def run(argv=None):
     model.check_status()
     m = B * (1 + K)
     ref_flops = step_flops(m, D, MC, [128], [128, 64, 32], args.unfrozen)
-    # executed: the backward runs on the 2 B rows that can carry a score gradient (adaptive BPR)
-    flops = step_flops(m, D, MC, [128], [128, 64, 32], args.unfrozen, m_back=2 * B)
+    # executed: the backward runs on the 2 B rows that can carry a score gradient (adaptive BPR),
+    # the user embedding's share of the first combined layer once per sample
+    flops = step_flops(m, D, MC, [128], [128, 64, 32], args.unfrozen, m_back=2 * B, user_rows=B)
     out = {
         'metric': 'train interactions/sec (pos+negs)', 'value': m / dt, 'unit': 'interactions/s',
         'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt * 1e3,
@@ -121,7 +125,8 @@ def run(argv=None):
                      'reference_autograd_flops_over_time_frac':
                          ref_flops / dt / 1e12 / MFMA_F32_PEAK_TFLOPS,
                      'note': 'whole step (all GEMMs + loss + optimizer) over wall time; flops = '
-                             'the GEMMs EXECUTED: forward on all (1 + K) B rows, backward on the '
+                             'the GEMMs EXECUTED: forward on all (1 + K) B rows (the user share of the first '
+                             'combined layer once per sample), backward on the '
                              '2 B rows whose score gradient can differ from zero (the reference\'s '
                              'autograd runs the backward on all rows, 82 % of them exact zeros: '
                              'reference_autograd_flops_per_step)'},
