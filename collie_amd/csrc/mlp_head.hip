@@ -1019,26 +1019,29 @@ __global__ __launch_bounds__(kWdBlock, 2) void dense_wgrad_dma_kernel(const WgPa
 // Stores of a finished tile are issued after the NEXT barrier, before that iteration's DMA, so the
 // newest J memory operations are always the DMA of the newest image (what the vmcnt waits assume).
 constexpr int kDfBlock = 512;
-constexpr int kDfRows = 64;
 
 // KS = 2 (n_in = 384: the W fragments of a 32 x 384 block do not fit one wave's registers): the two
 // waves of a column tile split the K-TILES of every image instead of its rows -- each holds half of W
 // and both 32-row sub-tiles -- and the second hands its sums to the first through LDS at the end of a
 // tile (one more rounding order than the register-staged kernel: compared to 1e-5, not bit for bit).
-template <int NCH, bool ACT, int KS, int KT, bool ADD>
+// NT = 32-column output tiles (4, 2, 1): the 8 waves are NT column tiles x 8 / NT groups of 32 rows,
+// so a tile has ROWS = 256 / NT operand rows (64, 128, 256).
+template <int NCH, bool ACT, int KS, int KT, bool ADD, int NT>
 __global__ __launch_bounds__(kDfBlock, 2) void dense_fwd_dma_kernel(const FwdParams p) {
   constexpr int NB = ACT ? 2 : 3;
-  constexpr int kImgF4 = KT * kDfRows * 8;  // one image: KT k-tiles of 32 columns
+  constexpr int ROWS = 32 * (8 / NT);      // operand rows per tile
+  constexpr int RP = ROWS / 64;            // 64-row parts of a tile: one DMA instruction per wave each
+  constexpr int kImgF4 = KT * ROWS * 8;    // one image: KT k-tiles of 32 columns
   constexpr int kSlabF4 = kImgF4 * (ACT ? 2 : 1);
-  constexpr int J = KT * (ACT ? 2 : 1);
+  constexpr int J = KT * RP * (ACT ? 2 : 1);
   constexpr int CW = KT * 32;              // operand columns per image
   constexpr int NS = KT * 4;               // MFMA steps (of 4) per image
-  static_assert(KS == 1 || KT == 4, "the K split is written for 128-column images");
+  static_assert(KS == 1 || (KT == 4 && NT == 4), "the K split is written for 128-column images");
   constexpr int kWaves = kDfBlock / kWave;
   constexpr int NW = NCH * NS / KS;        // W fragments (float4) per wave
   constexpr int NA = KS;                   // accumulator tiles per wave
   __shared__ f32x4 smem[NB * kSlabF4];
-  __shared__ int32_t idring[2][kWaves][kWave];
+  __shared__ int32_t idring[2][kWaves][RP][kWave];
   __shared__ float xbuf[KS == 2 ? 4 * 2 * 16 * kWave : 1];
 
   const int tid = threadIdx.x;
@@ -1046,12 +1049,12 @@ __global__ __launch_bounds__(kDfBlock, 2) void dense_fwd_dma_kernel(const FwdPar
   const int wave = tid >> 6;
   const int col = lane & 31;
   const int h = lane >> 5;
-  const int nt = wave & 3;                 // this wave's 32 output columns
-  const int rh = wave >> 2;                // KS = 1: its 32 rows of the tile; KS = 2: its k-tiles
-  const int lrow = wave * 8 + (lane >> 3); // DMA: this lane's row of the tile
+  const int nt = wave % NT;                // this wave's 32 output columns
+  const int rh = wave / NT;                // KS = 1: its 32 rows of the tile; KS = 2: its k-tiles
+  const int lrow = wave * 8 + (lane >> 3); // DMA: this lane's row of a 64-row part of the tile
   const int lslot = lane & 7;
 
-  const int64_t ntiles = (p.m + kDfRows - 1) / kDfRows;
+  const int64_t ntiles = (p.m + ROWS - 1) / ROWS;
   const int64_t per = (ntiles + gridDim.x - 1) / gridDim.x;
   const int64_t t0 = static_cast<int64_t>(blockIdx.x) * per;
   int64_t t1 = t0 + per;
@@ -1108,34 +1111,47 @@ __global__ __launch_bounds__(kDfBlock, 2) void dense_fwd_dma_kernel(const FwdPar
   for (int i = 0; i < NW; ++i) asm volatile("" : "+v"(wf[i]));
   asm volatile("" : "+v"(bias_n));
 
-  const uint32_t smem_at = lds_address(smem), idring_at = lds_address(&idring[0][0][0]);
+  const uint32_t smem_at = lds_address(smem), idring_at = lds_address(&idring[0][0][0][0]);
   bool any_bad = false;
-  auto row_of = [&](int64_t tile) {                 // operand row of this lane, clamped into [0, m)
-    int64_t m = tile * kDfRows + lrow;
+  auto row_of = [&](int64_t tile, int part) {       // operand row of this lane, clamped into [0, m)
+    int64_t m = tile * ROWS + part * 64 + lrow;
     return m < p.m ? m : p.m - 1;
   };
   auto fetch_ids = [&](int64_t tile, int c, int slot) {
-    if (c_idx[c])
-      dma_to_lds<4>(c_idx[c] + (row_of(tile) << c_sh[c]), idring_at + ((slot * kWaves + wave) * kWave) * 4);
+    if (c_idx[c]) {
+#pragma unroll
+      for (int part = 0; part < RP; ++part)
+        dma_to_lds<4>(c_idx[c] + (row_of(tile, part) << c_sh[c]),
+                      idring_at + (((slot * kWaves + wave) * RP + part) * kWave) * 4);
+    }
   };
   auto issue = [&](int64_t tile, int c, int buf, int slot) {
-    const int64_t m = row_of(tile);
-    int64_t row = m;
-    if (c_idx[c]) {
-      uint32_t r = static_cast<uint32_t>(idring[slot][wave][lane]);
-      const bool bad = r >= c_rows[c];               // flagged at the end, row 0 read instead
-      any_bad |= bad;
-      row = bad ? 0 : r;
+    // id reads of all parts first (see the weight-gradient kernel)
+    uint32_t r[RP];
+#pragma unroll
+    for (int part = 0; part < RP; ++part) {
+      r[part] = 0;
+      if (c_idx[c]) r[part] = static_cast<uint32_t>(idring[slot][wave][part][lane]);
     }
     const int sw = (lslot ^ (lrow & 7)) * 4;
-    const float* g = c_src[c] + row * c_ld[c] + sw;
-    const uint32_t dst = smem_at + (buf * kSlabF4 + wave * 64) * 16;
 #pragma unroll
-    for (int j = 0; j < KT; ++j) dma_to_lds<16>(g + j * 32, dst + j * 512 * 16);
-    if (ACT) {
-      const float* a = c_act[c] + m * c_act_ld[c] + sw;
+    for (int part = 0; part < RP; ++part) {
+      const int64_t m = row_of(tile, part);
+      int64_t row = m;
+      if (c_idx[c]) {
+        const bool bad = r[part] >= c_rows[c];          // flagged at the end, row 0 read instead
+        any_bad |= bad;
+        row = bad ? 0 : r[part];
+      }
+      const float* g = c_src[c] + row * c_ld[c] + sw;
+      const uint32_t dst = smem_at + (buf * kSlabF4 + part * 512 + wave * 64) * 16;
 #pragma unroll
-      for (int j = 0; j < KT; ++j) dma_to_lds<16>(a + j * 32, dst + (kImgF4 + j * 512) * 16);
+      for (int j = 0; j < KT; ++j) dma_to_lds<16>(g + j * 32, dst + j * (ROWS * 8) * 16);
+      if (ACT) {
+        const float* a = c_act[c] + m * c_act_ld[c] + sw;
+#pragma unroll
+        for (int j = 0; j < KT; ++j) dma_to_lds<16>(a + j * 32, dst + (kImgF4 + j * (ROWS * 8)) * 16);
+      }
     }
   };
   // slab s = (tile t0 + s / NCH, chunk s % NCH); its ids live in idring slot s & 1
@@ -1164,7 +1180,7 @@ __global__ __launch_bounds__(kDfBlock, 2) void dense_fwd_dma_kernel(const FwdPar
   // consumed where it is issued would drain the DMA ring once per tile: measured +200 us.)
   // ADD: the kernel instances with an addend (every load below is unconditional: a load inside a
   // branch makes the compiler wait for it at the join)
-  int64_t add_row0 = ADD ? (t0 * kDfRows) % p.add_period : 0;   // period >= 256: host check
+  int64_t add_row0 = ADD ? (t0 * ROWS) % p.add_period : 0;   // period >= 256: host check
   float addv[ADD ? NA : 1][16];
   auto load_addend = [&]() {
     if (ADD) {
@@ -1176,7 +1192,7 @@ __global__ __launch_bounds__(kDfBlock, 2) void dense_fwd_dma_kernel(const FwdPar
         if (ar >= p.add_period) ar -= p.add_period;
         addv[0][r] = arow[ar * p.add_ld];      // rows past m: a valid row, never stored
       }
-      add_row0 += kDfRows;
+      add_row0 += ROWS;
       if (add_row0 >= p.add_period) add_row0 -= p.add_period;
     }
   };
@@ -1188,7 +1204,7 @@ __global__ __launch_bounds__(kDfBlock, 2) void dense_fwd_dma_kernel(const FwdPar
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int lr = (KS == 1 ? rh : a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const int64_t m = tile * kDfRows + lr;
+        const int64_t m = tile * ROWS + lr;
         float v = acc[a][r];
         if (KS == 2) v += xbuf[((nt * 2 + a) * 16 + r) * kWave + lane];
         v += bias_n;
@@ -1245,7 +1261,7 @@ __global__ __launch_bounds__(kDfBlock, 2) void dense_fwd_dma_kernel(const FwdPar
         const int j = KS == 1 ? step >> 2 : 2 * rh + (step >> 2 & 1);
         const int q = step & 3;
         const int arow = (KS == 1 ? rh : a_i) * 32 + col;
-        const int at = j * 512 + arow * 8 + ((2 * q + h) ^ (arow & 7));
+        const int at = j * (ROWS * 8) + arow * 8 + ((2 * q + h) ^ (arow & 7));
         f32x4 a = img[at];
         if (ACT) {
           const f32x4 r = img[kImgF4 + at];
@@ -1446,17 +1462,25 @@ int build_operand(Operand& op, const collie_dense_operand* in, int64_t m, bool& 
   return 0;
 }
 
-// the LDS-DMA forward takes: exactly 128 output columns, n_in of 64 / 128 / 256 / 384 in segments that
-// start on image boundaries (64 columns for n_in = 64, else 128), no per-row bias tables; with an
-// activation reference only n_in <= 128
+// the LDS-DMA forward takes: 128 output columns with n_in of 64 / 128 / 256 / 384, 64 output columns with
+// n_in = 128, 32 with n_in = 64 (the shapes of the reference's default head), in segments that start on
+// image boundaries, no per-row bias tables; an activation reference only with 128 outputs and
+// n_in <= 128; an addend only with 128 outputs and n_in = 128 / 256
+int fwd_dma_image_cols(const FwdParams& p) {
+  if (p.n_out == 128 && (p.n_in == 128 || p.n_in == 256 || p.n_in == 384)) return 128;
+  if (p.n_out == 128 && p.n_in == 64) return 64;
+  if (p.n_out == 64 && p.n_in == 128 && !p.has_act && !p.addend) return 64;
+  if (p.n_out == 32 && p.n_in == 64 && !p.has_act && !p.addend) return 32;
+  return 0;
+}
+
 bool fwd_dma_ok(const FwdParams& p) {
   const char* e = getenv("COLLIE_FWD_DMA");     // "0": the register-staged kernel (tests compare both)
   if (e && e[0] == '0') return false;
-  if (p.n_out != 128 || (p.n_in != 64 && p.n_in != 128 && p.n_in != 256 && p.n_in != 384)) return false;
-  if (p.user_bias || p.m < 1) return false;
+  const int cw = fwd_dma_image_cols(p);
+  if (cw == 0 || p.user_bias || p.m < 1) return false;
   if (p.has_act && p.n_in > 128) return false;
   if (p.addend && (p.has_act || (p.n_in != 128 && p.n_in != 256))) return false;
-  const int cw = p.n_in == 64 ? 64 : 128;
   for (int i = 0; i < p.x.n_seg; ++i)
     if (p.x.s[i].begin % cw || p.x.s[i].end % cw) return false;
   return true;
@@ -1466,17 +1490,20 @@ void launch_fwd(const FwdParams& p, bool vec, hipStream_t stream) {
   const unsigned gx = static_cast<unsigned>((p.m + kFwdRows - 1) / kFwdRows);
   const unsigned gy = static_cast<unsigned>((p.n_out + 127) / 128);
   if (vec && fwd_dma_ok(p)) {
-    const int64_t ntiles = (p.m + kDfRows - 1) / kDfRows;
+    const int rows = p.n_out == 128 ? 64 : (p.n_out == 64 ? 128 : 256);
+    const int64_t ntiles = (p.m + rows - 1) / rows;
     const dim3 grid(static_cast<unsigned>(ntiles < 256 ? ntiles : 256)), block(kDfBlock);
 #define COLLIE_DF(NCH, KS, KT)                                                                         \
-  if (p.has_act) hipLaunchKernelGGL((dense_fwd_dma_kernel<NCH, true, KS, KT, false>), grid, block, 0, stream, p); \
-  else hipLaunchKernelGGL((dense_fwd_dma_kernel<NCH, false, KS, KT, false>), grid, block, 0, stream, p)
-    if (p.addend && p.n_in == 128) hipLaunchKernelGGL((dense_fwd_dma_kernel<1, false, 1, 4, true>), grid, block, 0, stream, p);
-    else if (p.addend) hipLaunchKernelGGL((dense_fwd_dma_kernel<2, false, 1, 4, true>), grid, block, 0, stream, p);
+  if (p.has_act) hipLaunchKernelGGL((dense_fwd_dma_kernel<NCH, true, KS, KT, false, 4>), grid, block, 0, stream, p); \
+  else hipLaunchKernelGGL((dense_fwd_dma_kernel<NCH, false, KS, KT, false, 4>), grid, block, 0, stream, p)
+    if (p.n_out == 64) hipLaunchKernelGGL((dense_fwd_dma_kernel<2, false, 1, 2, false, 2>), grid, block, 0, stream, p);
+    else if (p.n_out == 32) hipLaunchKernelGGL((dense_fwd_dma_kernel<2, false, 1, 1, false, 1>), grid, block, 0, stream, p);
+    else if (p.addend && p.n_in == 128) hipLaunchKernelGGL((dense_fwd_dma_kernel<1, false, 1, 4, true, 4>), grid, block, 0, stream, p);
+    else if (p.addend) hipLaunchKernelGGL((dense_fwd_dma_kernel<2, false, 1, 4, true, 4>), grid, block, 0, stream, p);
     else if (p.n_in == 64) { COLLIE_DF(1, 1, 2); }
     else if (p.n_in == 128) { COLLIE_DF(1, 1, 4); }
-    else if (p.n_in == 256) hipLaunchKernelGGL((dense_fwd_dma_kernel<2, false, 1, 4, false>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((dense_fwd_dma_kernel<3, false, 2, 4, false>), grid, block, 0, stream, p);
+    else if (p.n_in == 256) hipLaunchKernelGGL((dense_fwd_dma_kernel<2, false, 1, 4, false, 4>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((dense_fwd_dma_kernel<3, false, 2, 4, false, 4>), grid, block, 0, stream, p);
 #undef COLLIE_DF
     return;
   }

@@ -78,6 +78,11 @@ FWD_DMA_CASES = [
     (77, [128], [True], [False], 128, True),
     (30000, [128], [False], [True], 128, False),
     (129, [128], [True], [True], 128, False),
+    # 64 / 32 output columns (tiles of 128 / 256 rows)
+    (3000, [128], [False], [False], 64, True),
+    (777, [64, 64], [True, False], [False, False], 64, True),
+    (5000, [64], [False], [False], 32, True),
+    (300, [32, 32], [True, True], [False, False], 32, False),
     # n_in = 64: 64-column images
     (3000, [64], [False], [True], 128, False),
     (100, [64], [True], [False], 128, True),
