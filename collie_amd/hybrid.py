@@ -401,8 +401,10 @@ class HybridPretrainedModel(MatrixFactorizationModel):
             # rows b, B + b, 2 B + b, ... share their user: the user embedding's share of the first
             # combined layer is computed once per sample (_head_forward)
             self._user_period_hint = B if (self._USER_SHARE_ONCE and B >= 256) else None
-            preds = self(all_users, all_items)
-            self._active_rows_hint = self._user_period_hint = None
+            try:
+                preds = self(all_users, all_items)
+            finally:        # the hints describe THIS call only, whatever happens inside it
+                self._active_rows_hint = self._user_period_hint = None
             pos_preds = preds[:B]
             neg_preds = preds[B:].view(K, B)
             return self.loss_function(
