@@ -379,9 +379,7 @@ __global__ __launch_bounds__(kFBlock, (NTILES == 4 && WVEC && !ACT ? 3 : 1)) voi
     __syncthreads();  // every wave is done reading the previous chunk
     commit();
     __syncthreads();
-#ifndef COLLIE_EXP_NOFETCH
     if (k0 + kFKC < p.n_in) fetch(k0 + kFKC);  // in flight during the MFMAs below
-#endif
 
     const float* arow = &Xs[(wave * 32 + col) * kFLD + 4 * h];
     const float* brow = &Ws[col * kFLD + 4 * h];
