@@ -188,6 +188,7 @@ SIGNATURES = {
     'collie_mf_eval_metrics': (ctypes.c_int, [c_void_p, c_int32, c_int64, c_int64, c_void_p,
                                               c_void_p, c_void_p, c_void_p, c_int32, c_float,
                                               c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'collie_dense_set_kernels': (ctypes.c_int, [c_int32]),
     'collie_dense_forward': (ctypes.c_int, [POINTER(DenseOperand), c_int64, c_void_p, c_int64,
                                             c_int64, c_void_p, c_int32, c_int32, c_int32, c_float,
                                             c_void_p, c_int32, c_void_p, c_int64, c_void_p, c_int32,

@@ -29,6 +29,9 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// collie_dense_set_kernels(): which kernel family the dense entry points dispatch to
+int g_dense_kernels = COLLIE_DENSE_AUTO;
+
 constexpr int kKC = 32;       // contraction columns staged per step (forward)
 constexpr int kLD = kKC + 4;  // padded LDS row: conflict-free ds_read_b128 of the fragments
 constexpr int kFwdBlock = 512;
@@ -1473,8 +1476,7 @@ int fwd_dma_image_cols(const FwdParams& p) {
 }
 
 bool fwd_dma_ok(const FwdParams& p) {
-  const char* e = getenv("COLLIE_FWD_DMA");     // "0": the register-staged kernel (tests compare both)
-  if (e && e[0] == '0') return false;
+  if (g_dense_kernels == COLLIE_DENSE_REGISTER_STAGED) return false;
   const int cw = fwd_dma_image_cols(p);
   if (cw == 0 || p.user_bias || p.m < 1) return false;
   if (p.has_act && p.n_in > 128) return false;
@@ -1547,8 +1549,7 @@ int wgrad_dma_rows(int n_out, int n_in) {
 }
 
 bool wgrad_dma_ok(const WgParams& p) {
-  const char* e = getenv("COLLIE_WGRAD_DMA");   // "0": the register-staged kernel (tests compare both)
-  if (e && e[0] == '0') return false;
+  if (g_dense_kernels == COLLIE_DENSE_REGISTER_STAGED) return false;
   const int rows = wgrad_dma_rows(p.n_out, p.n_in);
   if (p.dz_scalar || rows == 0) return false;
   if (p.m % rows) return false;   // chunks are multiples of 32 rows
@@ -1575,6 +1576,13 @@ int64_t wgrad_chunks(int64_t m, int64_t* chunk_out, int64_t max_chunks = 512) {
 }  // namespace collie
 
 using namespace collie;
+
+extern "C" int collie_dense_set_kernels(int32_t family) {
+  COLLIE_REQUIRE(family == COLLIE_DENSE_AUTO || family == COLLIE_DENSE_REGISTER_STAGED,
+                 "dense_set_kernels: unknown kernel family %d", family);
+  g_dense_kernels = family;
+  return 0;
+}
 
 extern "C" int collie_dense_forward(const collie_dense_operand* x, int64_t m, const float* w,
                                     int64_t w_ld_out, int64_t w_ld_in, const float* bias,

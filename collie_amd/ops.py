@@ -383,6 +383,14 @@ def loss_forward_backward(loss_cfg, s_pos, s_neg_KB, pos_items=None, neg_items_K
 LEAKY_SLOPE = 0.01      # F.leaky_relu default (hybrid_pretrained_matrix_factorization.py:357,389)
 
 
+DENSE_AUTO, DENSE_REGISTER_STAGED = 0, 1
+
+
+def dense_set_kernels(family):
+    """Kernel family of the dense entry points (comparison runs and tests; see the header)."""
+    check(load().collie_dense_set_kernels(int(family)), 'collie_dense_set_kernels')
+
+
 def dense_operand(*segments):
     """Operand of a dense layer = column-wise concatenation of ``segments``; a segment is
     ``(src [rows, width], idx [m] or None, act_ref [m, width] or None)`` (see include/collie_hip.h)."""

@@ -590,6 +590,17 @@ typedef struct collie_dense_operand {
   collie_dense_seg seg[COLLIE_DENSE_MAX_SEGS];
 } collie_dense_operand;
 
+/* Kernel family behind collie_dense_forward / collie_dense_forward_add / collie_dense_weight_grad:
+ * COLLIE_DENSE_AUTO (default) picks the LDS-DMA kernels for the shapes they take (the layers of the
+ * reference's default head, hybrid_pretrained_matrix_factorization.py:110) and the register-staged
+ * kernels for everything else; COLLIE_DENSE_REGISTER_STAGED always takes the latter.  The two families
+ * give the same bits (except n_in = 384 forwards, 32 x 64 and > 65,536-row weight gradients: 1e-5), so
+ * this exists for comparison runs and tests only.  Process-wide; not to be changed while launches of
+ * another host thread are being issued.  No counterpart in the reference. */
+#define COLLIE_DENSE_AUTO 0
+#define COLLIE_DENSE_REGISTER_STAGED 1
+int collie_dense_set_kernels(int32_t family);
+
 /* nn.Linear (+ F.leaky_relu): y[j, n] = act(sum_k x[j, k] * W[n, k] + bias[n]), W[n, k] read at
  * w[n * w_ld_out + k * w_ld_in] (a Linear weight: w_ld_out = n_in, w_ld_in = 1; its transpose for
  * the data backward dX = dZ W: w_ld_out = 1, w_ld_in = row length of the weight).  bias may be

@@ -107,9 +107,12 @@ def test_dense_forward_dma_equals_register_kernel(dev, case, monkeypatch):
     # transposed weights (the data-gradient form): W read through swapped strides
     wt2 = torch.tensor(np.ascontiguousarray(w.T), device=dev)
     y2 = ops.dense_forward(op, m, wt2, None, False, transposed=True)
-    monkeypatch.setenv('COLLIE_FWD_DMA', '0')
-    y0 = ops.dense_forward(op, m, wt, bt, leaky)
-    y20 = ops.dense_forward(op, m, wt2, None, False, transposed=True)
+    ops.dense_set_kernels(ops.DENSE_REGISTER_STAGED)
+    try:
+        y0 = ops.dense_forward(op, m, wt, bt, leaky)
+        y20 = ops.dense_forward(op, m, wt2, None, False, transposed=True)
+    finally:
+        ops.dense_set_kernels(ops.DENSE_AUTO)
     if n_in == 384:
         close(y.cpu().numpy(), y0.cpu().numpy())
         close(y2.cpu().numpy(), y20.cpu().numpy())
@@ -340,8 +343,11 @@ def test_dense_weight_grad_dma_equals_register_kernel(dev, case, masked, monkeyp
     x_op, x = _operand_case(rng, m, widths, gathered, [False] * len(widths), dev)
     dz_op, dz = _operand_case(rng, m, [n_out], [False], [masked], dev)
     dw, db, _ = ops.dense_weight_grad(dz_op, x_op, m, n_out, x.shape[1])
-    monkeypatch.setenv('COLLIE_WGRAD_DMA', '0')
-    dw0, db0, _ = ops.dense_weight_grad(dz_op, x_op, m, n_out, x.shape[1])
+    ops.dense_set_kernels(ops.DENSE_REGISTER_STAGED)
+    try:
+        dw0, db0, _ = ops.dense_weight_grad(dz_op, x_op, m, n_out, x.shape[1])
+    finally:
+        ops.dense_set_kernels(ops.DENSE_AUTO)
     if n_out == 32 or m > 256 * 256:
         close(dw.cpu().numpy(), dw0.cpu().numpy())
     else:
