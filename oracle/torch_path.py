@@ -183,10 +183,12 @@ class TorchHybrid(torch.nn.Module):
     (``collie/model/hybrid_pretrained_matrix_factorization.py``): table copies ``:243-250``,
     freezing ``:476-484``, metadata layers ``:188-225,327-361``, combined layers ``:297-325``,
     prediction ``:363-399``, forward / concatenation order ``:401-464``.  Module names are the
-    reference's (``embeddings.0`` ... ``combined_layer_3``).  The reference class itself cannot
-    be imported here (``pytorch_lightning`` is not installed), so vectors made with this class are
-    pinned by torch 2.10 run in this container, not by a reference known-answer test (the
-    reference has none for this model: ``tests/test_model.py`` only asserts thresholds).
+    reference's (``embeddings.0`` ... ``combined_layer_3``).  Pinned to the reference's own class:
+    ``tests/golden/ref_hybrid.npz`` holds loss, gradients and scores computed by
+    ``collie.model.hybrid_pretrained_matrix_factorization.HybridPretrainedModel`` itself (imported
+    through ``tests/golden/ref_harness.py`` in the build container), and
+    ``tests/test_oracle_golden.py`` checks this class against them (the reference's own tests hold
+    only statistical thresholds for the model: ``tests/test_model.py``).
     """
 
     def __init__(self, tables, item_metadata=None, user_metadata=None,

@@ -605,6 +605,66 @@ def test_hybrid_backward_on_active_rows_equals_full_backward(dev, loss, frozen, 
     model.check_status()
 
 
+@pytest.mark.parametrize('tag,loss', [('item_meta_adaptive', 'adaptive'),
+                                      ('both_meta_bpr_frozen', 'bpr'), ('raw_meta_warp', 'warp')])
+def test_hybrid_vs_the_reference_hybrid_model(dev, golden_dir, tag, loss):
+    """The product model against vectors made by the REFERENCE'S OWN ``HybridPretrainedModel``
+    (``tests/golden/ref_hybrid.npz``, generated by tests/golden/make_golden_ref_hybrid.py through
+    the import harness): ``calculate_loss``, the gradient of every trainable tensor, pair scores."""
+    from collie_amd.hybrid import HybridPretrainedModel
+    from collie_amd.model import MatrixFactorizationModel
+    from tests.test_oracle_golden import REF_HYBRID_CASES, load_ref_hybrid_case
+    c = load_ref_hybrid_case(golden_dir, tag)
+    kw = dict(REF_HYBRID_CASES[tag])
+    assert str(c['loss_name']) == kw.pop('loss') + '_loss'
+    U, D = c['state|embeddings.0.weight'].shape
+    N = c['state|embeddings.1.weight'].shape[0]
+
+    class Shape:
+        num_users, num_items, num_negative_samples = U, N, c['neg'].shape[1]
+
+    mf = MatrixFactorizationModel(train=Shape(), embedding_dim=D, lr_scheduler_func=None)
+    md = {k: torch.tensor(c[k]) for k in ('item_metadata', 'user_metadata') if k in c}
+    model = HybridPretrainedModel(train=Shape(), trained_model=mf, lr_scheduler_func=None, loss=loss,
+                                  **md, **kw)
+    state = {k[len('state|'):]: torch.as_tensor(v) for k, v in c.items()
+             if k.startswith('state|') and not k.startswith('state|_trained_model')}
+    res = model.load_state_dict(state, strict=False)
+    assert not res.unexpected_keys and all('_trained_model' in k for k in res.missing_keys)
+    model = model.to(dev).train()
+    batch = ((torch.tensor(c['users'], device=dev), torch.tensor(c['pos'], device=dev)),
+             torch.tensor(c['neg'], device=dev))
+    out = model.calculate_loss(batch)
+    out.backward()
+    assert abs(float(out.detach()) - float(c['loss'])) <= 2e-6 * abs(float(c['loss']))
+    checked = 0
+    for name, p in model.named_parameters():
+        key = 'grad|' + name
+        if not p.requires_grad:
+            assert key not in c
+            continue
+        staged = model._staged_rows.get(id(p))
+        if staged is not None:
+            ids, vals = staged
+            got = np.zeros(p.shape, np.float64)
+            np.add.at(got, ids.cpu().numpy(), vals.cpu().numpy().reshape(len(ids), -1))
+        else:
+            got = p.grad.cpu().numpy()
+        want = c[key]
+        # analytically cancelling entries (user biases, the last Linear bias) are rounding residue
+        # on both sides: the floor of the scale is the size of the summed terms
+        scale = max(np.abs(want).max(), 0.05)
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=2e-5 * scale, err_msg=name)
+        checked += 1
+    assert checked == sum(1 for k in c if k.startswith('grad|') and '_trained_model' not in k)
+    model.eval()
+    with torch.no_grad():
+        got = model(torch.tensor(c['pairs_users'], device=dev),
+                    torch.tensor(c['pairs_items'], device=dev)).cpu().numpy()
+    np.testing.assert_allclose(got, c['pairs_scores'], rtol=1e-5, atol=1e-5)
+    model.check_status()
+
+
 def test_hybrid_evaluate_save_load(dev, tmp_path):
     """evaluate_in_batches takes the generic get_preds route for the hybrid model; save_model /
     load_model_path round-trip predictions (tests/test_model.py:1346-1385 in the reference)."""

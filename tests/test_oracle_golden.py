@@ -346,3 +346,61 @@ def test_hybrid_numpy_oracle_matches_torch_restatement():
     close(grads['item_embeddings'], ref.embeddings[1].weight.grad)
     close(grads['user_biases'], ref.biases[0].weight.grad)
     close(grads['item_biases'], ref.biases[1].weight.grad)
+
+
+REF_HYBRID_CASES = {
+    'item_meta_adaptive': dict(item_metadata_layers_dims=[32], combined_layers_dims=[32, 16, 8],
+                               freeze_embeddings=False, loss='adaptive_hinge'),
+    'both_meta_bpr_frozen': dict(item_metadata_layers_dims=[10, 6], user_metadata_layers_dims=[5],
+                                 combined_layers_dims=[20], freeze_embeddings=True,
+                                 loss='adaptive_bpr'),
+    'raw_meta_warp': dict(combined_layers_dims=[16, 4], freeze_embeddings=False, loss='warp'),
+}
+
+
+def load_ref_hybrid_case(golden_dir, tag):
+    """Arrays of one case of ``ref_hybrid.npz`` (made by the REFERENCE'S OWN HybridPretrainedModel,
+    tests/golden/make_golden_ref_hybrid.py): state, batch, loss, gradients, pair scores."""
+    z = np.load(os.path.join(golden_dir, 'ref_hybrid.npz'))
+    pre = tag + '|'
+    return {k[len(pre):]: z[k] for k in z.files if k.startswith(pre)}
+
+
+@pytest.mark.parametrize('tag', sorted(REF_HYBRID_CASES))
+def test_torch_hybrid_restatement_vs_the_reference_hybrid_model(golden_dir, tag):
+    """``oracle/torch_path.py:TorchHybrid`` (what the GPU tests of the hybrid head compare with)
+    against the reference's own class: loss, every gradient, scores of (user, item) pairs."""
+    import torch
+    from oracle import torch_path as T
+    c = load_ref_hybrid_case(golden_dir, tag)
+    kw = dict(REF_HYBRID_CASES[tag])
+    loss_kind = kw.pop('loss')
+    assert str(c['loss_name']) == loss_kind + '_loss'
+    tables = {'user_embeddings': c['state|embeddings.0.weight'],
+              'item_embeddings': c['state|embeddings.1.weight'],
+              'user_biases': c['state|biases.0.weight'], 'item_biases': c['state|biases.1.weight']}
+    ref = T.TorchHybrid(tables, item_metadata=c.get('item_metadata'),
+                        user_metadata=c.get('user_metadata'), **kw)
+    state = {k[len('state|'):]: torch.as_tensor(v) for k, v in c.items()
+             if k.startswith('state|') and not k.startswith('state|_trained_model')}
+    assert set(state) == set(ref.state_dict())
+    ref.load_state_dict(state)
+    batch = ((torch.as_tensor(c['users']), torch.as_tensor(c['pos'])), torch.as_tensor(c['neg']))
+    loss, _, _ = ref.calculate_loss(batch, T.TORCH_LOSSES[loss_kind])
+    loss.backward()
+    assert abs(float(loss) - float(c['loss'])) <= 1e-6 * abs(float(c['loss']))
+    checked = 0
+    for name, p in ref.named_parameters():
+        key = 'grad|' + name
+        if not p.requires_grad:
+            assert key not in c
+            continue
+        want = c[key]
+        np.testing.assert_allclose(p.grad.numpy(), want, rtol=1e-5,
+                                   atol=1e-6 * max(np.abs(want).max(), 1e-3), err_msg=name)
+        checked += 1
+    assert checked == sum(1 for k in c if k.startswith('grad|') and '_trained_model' not in k)
+    ref.eval()
+    with torch.no_grad():
+        got = ref(torch.as_tensor(c['pairs_users']), torch.as_tensor(c['pairs_items'])).numpy()
+    np.testing.assert_allclose(got, c['pairs_scores'], rtol=1e-6, atol=1e-6)
