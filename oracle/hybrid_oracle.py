@@ -6,9 +6,11 @@ layers ``:327-361``, concatenation order ``:430-459``, combined layers + both bi
 
 TEST INFRASTRUCTURE ONLY (see ``oracle/mf_oracle.py`` header for the rule): imported by ``tests/``
 alone.  Pinned against ``oracle/torch_path.py:TorchHybrid`` (the same network written with the
-reference's torch calls, run by torch 2.10 here) in ``tests/test_oracle_golden.py``; the reference
-class itself cannot be imported (``pytorch_lightning`` is absent) and its tests hold no
-known-answer vector for this model, so beyond that cross-check the head is "parity unpinned".
+reference's torch calls) in ``tests/test_oracle_golden.py``, which in turn is pinned to vectors made
+by the reference's OWN class (``tests/golden/ref_hybrid.npz``, generated in the build container by
+``tests/golden/make_golden_ref_hybrid.py`` through the import harness): loss, every gradient and
+pair scores of three configurations.  The reference's own tests hold no known-answer vector for
+this model.
 """
 import numpy as np
 

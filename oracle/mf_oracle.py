@@ -17,8 +17,10 @@ Pinning status ("Oracle"):
   * metrics: pinned against the reference's known answers
     (``tests/test_metrics.py:101-154,230-256``, ``tests/fixtures/metrics_fixtures.py:7-75``) and
     sklearn's ``roc_auc_score`` (the reference's own oracle for AUC, ``tests/test_metrics.py:140-154``).
-    ``collie/metrics.py`` itself cannot be imported here (``pytorch_lightning``/``torchmetrics``
-    are absent), so metric outputs not covered by those known answers are "parity unpinned".
+    Since round 2 also against ``collie/metrics.py`` itself: ``tests/golden/ref_pipeline.npz`` holds
+    per-user AP / RR / AUC, ``get_preds`` rows and top-k ids computed by the reference's own
+    functions (imported through ``tests/golden/ref_harness.py``, ``auroc`` mapped to sklearn as
+    the reference's test does).
   * forward / sparse gradients / optimizers: the reference delegates these to torch
     (``nn.Embedding``, ``torch.optim.*``); pinned against the same torch calls run in the build
     container (``oracle/torch_path.py`` -> ``tests/golden/*.npz``).  The reference holds no
