@@ -96,6 +96,55 @@ def trainer_epoch(out, tag, U, N, D, K, B, nnz, model_kw, seed):
     print(tag, 'loss fn', model.loss_function.__name__, 'epoch losses', captured)
 
 
+class ExplicitBatches(list):
+    """Fixed (users, items, ratings) batches; no ``num_negative_samples``: explicit feedback."""
+
+    def __init__(self, batches, num_users, num_items):
+        super().__init__(batches)
+        self.num_users, self.num_items = num_users, num_items
+
+
+def explicit_epoch(out, tag, U, N, D, B, nb, model_kw, seed):
+    """F6 for the explicit path (base_pipeline.py:635-650): two epochs of the reference's trainer on
+    fixed (users, items, ratings) batches -> per-step losses and final tables."""
+    rng = np.random.default_rng(seed)
+    batches = []
+    for _ in range(nb):
+        batches.append((torch.from_numpy((rng.zipf(1.4, B) % U).astype(np.int32)),
+                        torch.from_numpy(rng.integers(0, N, B).astype(np.int64)),
+                        torch.from_numpy(rng.integers(1, 6, B).astype(np.float64))))
+    torch.manual_seed(seed)
+    model = MatrixFactorizationModel(train=ExplicitBatches(batches, U, N), embedding_dim=D, **model_kw)
+    with torch.no_grad():
+        model.user_embeddings.weight.mul_(30.0)
+        model.item_embeddings.weight.mul_(30.0)
+        model.user_biases.weight.normal_(0, 0.1)
+        model.item_biases.weight.normal_(0, 0.1)
+    for n, v in tables_of(model).items():
+        out[f'{tag}|t0|{n}'] = v
+    losses = []
+    inner = model.calculate_loss
+
+    def recording(batch):
+        loss = inner(batch)
+        losses.append(float(loss.detach()))
+        return loss
+
+    model.calculate_loss = recording
+    trainer = CollieMinimalTrainer(model, max_epochs=2, gpus=0, logger=None, verbosity=0,
+                                   early_stopping_patience=None, enable_model_summary=False)
+    trainer.fit(model)
+    assert len(losses) == 2 * nb
+    out[f'{tag}|step_losses'] = np.asarray(losses, np.float64)
+    for n, v in tables_of(model).items():
+        out[f'{tag}|t1|{n}'] = v
+    out[f'{tag}|n_batches'] = np.int64(nb)
+    for i, (u, it, ra) in enumerate(batches):
+        out[f'{tag}|b{i}|users'], out[f'{tag}|b{i}|items'] = u.numpy(), it.numpy()
+        out[f'{tag}|b{i}|ratings'] = ra.numpy()
+    print(tag, 'explicit losses', np.round(losses, 4))
+
+
 def eval_case_per_user(out):
     z = np.load(os.path.join(HERE, 'eval_case.npz'))
     tables = {n: z[f't|{n}'] for n in NAMES}
@@ -139,6 +188,12 @@ def main():
                   # every default of the reference, except that its default scheduler factory
                   # passes ``verbose=True``, which torch 2.10's ReduceLROnPlateau no longer takes
                   model_kw=dict(lr=1e-2, lr_scheduler_func=partial(ReduceLROnPlateau, patience=1)))
+    explicit_epoch(out, 'explicit_mse_yrange_adam', U=200, N=150, D=10, B=300, nb=3, seed=7,
+                   model_kw=dict(lr=5e-2, bias_lr=5e-2, loss='mse', optimizer='adam',
+                                 bias_optimizer='sgd', y_range=(0.0, 5.0), lr_scheduler_func=None))
+    explicit_epoch(out, 'explicit_mae_sparse_adagrad', U=200, N=150, D=30, B=300, nb=3, seed=8,
+                   model_kw=dict(sparse=True, lr=5e-2, bias_lr=5e-2, loss='mae', optimizer='adagrad',
+                                 bias_optimizer='sgd', lr_scheduler_func=None))
     eval_case_per_user(out)
     np.savez_compressed(os.path.join(HERE, 'ref_pipeline.npz'), **out)
     print('wrote ref_pipeline.npz with', len(out), 'arrays')

@@ -403,6 +403,57 @@ def test_explicit_fused_trajectory_vs_torch_reference_path(loss, y_range, sparse
                               torch.tensor(items, device=dev)))
 
 
+class _ExplicitBatches(list):
+    def __init__(self, batches, U, N):
+        super().__init__(batches)
+        self.num_users, self.num_items = U, N
+
+
+@pytest.mark.parametrize('tag,kw', [
+    ('explicit_mse_yrange_adam', dict(lr=5e-2, bias_lr=5e-2, loss='mse', optimizer='adam',
+                                      bias_optimizer='sgd', y_range=(0.0, 5.0),
+                                      lr_scheduler_func=None)),
+    ('explicit_mae_sparse_adagrad', dict(sparse=True, lr=5e-2, bias_lr=5e-2, loss='mae',
+                                         optimizer='adagrad', bias_optimizer='sgd',
+                                         lr_scheduler_func=None))])
+def test_explicit_trainer_epochs_vs_the_reference_trainer(golden_dir, dev, tag, kw):
+    """Explicit feedback (base_pipeline.py:635-650): two epochs of ``CollieMinimalTrainer`` on the
+    fixed (users, items, ratings) batches of ``ref_pipeline.npz`` against the per-step losses and
+    final tables the REFERENCE'S OWN model and trainer produced on them."""
+    import os
+    from collie_amd.model import MatrixFactorizationModel
+    from collie_amd.trainer import CollieMinimalTrainer
+    r = np.load(os.path.join(golden_dir, 'ref_pipeline.npz'))
+    nb = int(r[f'{tag}|n_batches'])
+    batches = [(torch.tensor(r[f'{tag}|b{i}|users']), torch.tensor(r[f'{tag}|b{i}|items']),
+                torch.tensor(r[f'{tag}|b{i}|ratings'])) for i in range(nb)]
+    U, D = r[f'{tag}|t0|user_embeddings'].shape
+    N = r[f'{tag}|t0|item_embeddings'].shape[0]
+    model = MatrixFactorizationModel(train=_ExplicitBatches(batches, U, N), embedding_dim=D, **kw)
+    with torch.no_grad():
+        for n in NAMES:
+            getattr(model, n).weight.copy_(torch.tensor(r[f'{tag}|t0|{n}']))
+    losses = []
+    inner = model.calculate_loss
+
+    def recording(batch):
+        loss = inner(batch)
+        losses.append(loss.detach())
+        return loss
+
+    model.calculate_loss = recording
+    trainer = CollieMinimalTrainer(model, max_epochs=2, gpus=1, verbosity=0,
+                                   early_stopping_patience=None, enable_model_summary=False)
+    trainer.fit(model)
+    assert model.hparams.num_epochs_completed == 2
+    close([float(x) for x in losses], r[f'{tag}|step_losses'], rtol=2e-5)
+    for n in NAMES:
+        have = getattr(model, n).weight.detach().cpu().numpy()
+        want = r[f'{tag}|t1|{n}']
+        np.testing.assert_allclose(have, want, rtol=2e-4, atol=2e-4 * np.abs(want).max(), err_msg=n)
+    model.check_status()
+
+
 def test_explicit_loader_and_trainer_end_to_end():
     """ExplicitInteractions -> device loader -> CollieMinimalTrainer: MSE falls (base_pipeline.py
     :635-650 through the fused HIP path, ratings generated by a planted low-rank model)."""
