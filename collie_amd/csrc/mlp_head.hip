@@ -1481,6 +1481,7 @@ bool fwd_dma_ok(const FwdParams& p) {
   if (cw == 0 || p.user_bias || p.m < 1) return false;
   if (p.has_act && p.n_in > 128) return false;
   if (p.addend && (p.has_act || (p.n_in != 128 && p.n_in != 256))) return false;
+  if (p.addend && p.add_period < 256) return false;  // the kernel wraps the addend row once per tile
   for (int i = 0; i < p.x.n_seg; ++i)
     if (p.x.s[i].begin % cw || p.x.s[i].end % cw) return false;
   return true;
@@ -1606,8 +1607,8 @@ extern "C" int collie_dense_forward_add(const collie_dense_operand* x, int64_t m
                                         int64_t add_period, float* y, int64_t y_ld, int32_t* status,
                                         collie_stream_t stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  COLLIE_REQUIRE(!addend || (add_ld >= n_out && add_period >= 256),
-                 "dense_forward_add: addend needs add_ld >= n_out and add_period >= 256");
+  COLLIE_REQUIRE(!addend || (add_ld >= n_out && add_period >= 1),
+                 "dense_forward_add: addend needs add_ld >= n_out and add_period >= 1");
   COLLIE_REQUIRE(m >= 1 && m < (int64_t{1} << 39), "dense_forward: bad row count %lld",
                  static_cast<long long>(m));
   COLLIE_REQUIRE(w && y && n_in >= 1 && n_out >= 1 && y_ld >= n_out, "dense_forward: bad W / Y");

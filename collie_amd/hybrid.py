@@ -481,6 +481,71 @@ class HybridPretrainedModel(MatrixFactorizationModel):
         saved['combined'] = outs
         return scores.reshape(-1), saved
 
+    def score_catalogue(self, user_ids, n_items: int) -> torch.Tensor:
+        """Scores of every ``(user, item < n_items)`` pair, ``[len(user_ids), n_items]``: what
+        ``get_preds`` (``metrics.py:77-107``) obtains from ``model(users.repeat_interleave(n),
+        arange(n).repeat(U))``.  On that grid the item side of the first combined layer (item
+        embedding + item metadata stack, ``hybrid_pretrained_matrix_factorization.py:401-464``) does
+        not depend on the user: it is computed once per ITEM and enters the layer's GEMM over the
+        user columns as a periodic addend, so a pair costs the user's 128 columns of the first layer
+        plus the tail layers instead of the whole head.  Returns None when the model's layout does
+        not allow the split (user metadata, a head of one layer): the caller then takes
+        ``model(users, items)``."""
+        if (self.user_metadata is not None or len(self.combined_layers) < 2 or n_items < 1
+                or (self.training and self.hparams.dropout_p > 0)):
+            return None
+        _lib.require_hip(self.embeddings[0].weight, 'HybridPretrainedModel')
+        if self.item_metadata is not None and not self.item_metadata.is_cuda:
+            self._move_any_external_data_to_device()
+        dev = self.embeddings[0].weight.device
+        users = torch.as_tensor(np.asarray(user_ids), dtype=torch.int64, device=dev).contiguous()
+        n_users = users.shape[0]
+        first, last = self.combined_layers[0], self.combined_layers[-1]
+        d = self.embeddings[0].weight.shape[1]
+        step = self._NO_GRAD_CHUNK
+        status = self._status_flag()
+        with torch.no_grad():
+            catalogue = torch.arange(n_items, device=dev)
+            share = torch.empty((n_items, first.weight.shape[0]), dtype=torch.float32, device=dev)
+            for i0 in range(0, n_items, step):
+                ids = catalogue[i0:i0 + step]
+                n = ids.shape[0]
+                segs = [(self.embeddings[1].weight.data, ids, None)]
+                meta = self._metadata_stack('item', ids, n, {})
+                if meta is not None:
+                    segs.append(meta)
+                ops.dense_forward(ops.dense_operand(*segs), n, first.weight.data, None, False,
+                                  status=status, col_range=(d, first.weight.shape[1]),
+                                  out=share[i0:i0 + n])
+            scores = torch.empty((n_users, n_items), dtype=torch.float32, device=dev)
+            width = min(n_items, step)
+            for i0 in range(0, n_items, width):
+                ni = min(width, n_items - i0)
+                per = max(1, step // ni)
+                for u0 in range(0, n_users, per):
+                    nu = min(per, n_users - u0)
+                    m = nu * ni
+                    pair_users = users[u0:u0 + nu].repeat_interleave(ni)
+                    pair_items = catalogue[i0:i0 + ni].repeat(nu)
+                    x = ops.dense_forward(
+                        ops.dense_operand((self.embeddings[0].weight.data, pair_users, None)), m,
+                        first.weight.data, first.bias.data, True, status=status, col_range=(0, d),
+                        addend=(share[i0:i0 + ni], ni))
+                    for layer in self.combined_layers[1:-1]:
+                        x = ops.dense_forward(ops.dense_operand((x, None, None)), m,
+                                              layer.weight.data, layer.bias.data, True,
+                                              status=status)
+                    out = ops.dense_forward(
+                        ops.dense_operand((x, None, None)), m, last.weight.data, last.bias.data,
+                        False, status=status,
+                        row_bias=(pair_users, self.biases[0].weight.data,
+                                  pair_items, self.biases[1].weight.data))
+                    if ni == n_items:
+                        scores[u0:u0 + nu] = out.view(nu, ni)
+                    else:
+                        scores[u0:u0 + nu, i0:i0 + ni] = out.view(nu, ni)
+        return scores
+
     def _layer_backward(self, layer, x_segs, out, dz, m, grads):
         """Gradients of one ``Linear (+ LeakyReLU)``: parameters into ``grads``; returns the operand
         ``dz_op`` (dY with the activation backward folded in) for the caller's data backward."""

@@ -45,6 +45,15 @@ def _get_user_item_pairs(user_ids, n_items: int, device):
 
 def get_preds(model, user_ids, n_items: int, device) -> torch.Tensor:
     """``metrics.py:77-107``: [n_users, n_items] scores through ``model(users, items)``."""
+    if isinstance(n_items, np.int64):
+        n_items = n_items.item()
+    grid = getattr(model, 'score_catalogue', None)
+    if grid is not None:
+        # a model that can score the users x catalogue grid without expanding it pair by pair
+        # (HybridPretrainedModel: the item side of its head once per item)
+        scores = grid(user_ids, n_items)
+        if scores is not None:
+            return scores
     user, item = _get_user_item_pairs(user_ids, n_items, device)
     with torch.no_grad():
         predicted_scores = model(user, item)

@@ -614,7 +614,8 @@ int collie_dense_forward(const collie_dense_operand* x, int64_t m, const float* 
                          int64_t y_ld, int32_t* status, collie_stream_t stream);
 
 /* collie_dense_forward with one more term before the activation: y = act(x W^T + b + addend[m mod
- * add_period, :]), addend [add_period, >= n_out] floats with row pitch add_ld, add_period >= 256.
+ * add_period, :]), addend [add_period, >= n_out] floats with row pitch add_ld, add_period >= 1 (the
+ * LDS-DMA kernels take add_period >= 256, shorter periods go to the register-staged ones).
  * For operands whose leading column segments only depend on m mod add_period -- calculate_loss feeds
  * users.repeat(K + 1) (base_pipeline.py:616-621), so the user embedding's share of the first combined
  * layer (hybrid_pretrained_matrix_factorization.py:430-446) is the same for the 1 + K rows of a

@@ -707,6 +707,60 @@ def test_hybrid_evaluate_save_load(dev, tmp_path):
     assert list(loaded.state_dict()) == list(model.state_dict())
 
 
+@pytest.mark.parametrize('layout', [
+    dict(D=16, ic=24, kw=dict(item_metadata_layers_dims=[32], combined_layers_dims=[32, 16, 8])),
+    dict(D=128, ic=256, kw=dict(item_metadata_layers_dims=[128])),          # BASELINE configs[4] head
+    dict(D=10, ic=7, kw=dict(combined_layers_dims=[6])),                    # raw metadata columns
+    dict(D=12, ic=5, kw=dict(item_metadata_layers_dims=[9, 4], combined_layers_dims=[24, 8])),
+])
+@pytest.mark.parametrize('chunk', [1 << 21, 1000, 97])
+def test_hybrid_score_catalogue_equals_pairwise_scores(dev, layout, chunk):
+    """get_preds' users x catalogue grid (metrics.py:77-107) with the item side of the first
+    combined layer computed once per item == model(users, items) on the expanded pairs, for one
+    pass, for user-wise splits (chunk 1000 >= N) and for item-range splits (chunk 97 < N)."""
+    from collie_amd.metrics import get_preds
+    U, N, K = 40, 333, 3
+    rng = np.random.default_rng(layout['D'])
+    inter, mf = _mf_model(dev, U, N, layout['D'], K, seed=3)
+    item_md = rng.normal(size=(N, layout['ic'])).astype(np.float32)
+    torch.manual_seed(5)
+    model, ref = _pair(dev, inter, mf, item_md, None, **layout['kw'])
+    model.eval()
+    user_ids = rng.permutation(U)[:11]
+    uu = torch.tensor(user_ids).repeat_interleave(N)
+    ii = torch.arange(N).repeat(len(user_ids))
+    with torch.no_grad():
+        pairwise = model(uu.to(dev), ii.to(dev)).view(len(user_ids), N).cpu().numpy()
+        want = ref(uu, ii).view(len(user_ids), N).numpy()
+    model._NO_GRAD_CHUNK = chunk
+    grid = model.score_catalogue(user_ids, N)
+    assert grid is not None and grid.shape == (len(user_ids), N)
+    scale = np.abs(want).max()
+    np.testing.assert_allclose(grid.cpu().numpy(), pairwise, rtol=1e-5, atol=2e-6 * scale)
+    np.testing.assert_allclose(grid.cpu().numpy(), want, rtol=1e-5, atol=2e-6 * scale)
+    assert torch.equal(get_preds(model, user_ids, N, dev), grid)
+    model.check_status()
+
+
+def test_hybrid_score_catalogue_declines_other_layouts(dev):
+    """User metadata or a one-layer head: no split, get_preds takes model(users, items)."""
+    from collie_amd.metrics import get_preds
+    U, N, K = 30, 45, 3
+    rng = np.random.default_rng(8)
+    inter, mf = _mf_model(dev, U, N, 8, K, seed=8)
+    item_md = rng.normal(size=(N, 6)).astype(np.float32)
+    user_md = rng.normal(size=(U, 4)).astype(np.float32)
+    for imd, umd, kw in [(item_md, user_md, dict(combined_layers_dims=[8])),
+                         (item_md, None, dict(combined_layers_dims=[]))]:
+        torch.manual_seed(1)
+        model, ref = _pair(dev, inter, mf, imd, umd, **kw)
+        model.eval()
+        assert model.score_catalogue(np.arange(5), N) is None
+        with torch.no_grad():
+            want = ref(torch.arange(5).repeat_interleave(N), torch.arange(N).repeat(5)).view(5, N)
+        close(get_preds(model, np.arange(5), N, dev).cpu().numpy(), want.numpy())
+
+
 def test_hybrid_forward_backward_vs_numpy_oracle(dev):
     """The product model against oracle/hybrid_oracle.py (numpy): scores, Linear gradients and the
     staged table gradients for an arbitrary d loss / d scores."""
