@@ -1560,6 +1560,47 @@ bool wgrad_dma_ok(const WgParams& p) {
   return true;
 }
 
+// y[j, :] = act((outer[j / period, :] + bias) + inner[j mod period, :]): the first combined layer on
+// the users x catalogue grid once both of its shares are known (collie_dense_outer_sum).  HBM-bound
+// (one y row written per pair; outer / inner rows come from the caches).  V floats per thread.
+constexpr int kOsColsX = 32, kOsRowsY = 8;
+template <int V>
+__global__ __launch_bounds__(kOsColsX* kOsRowsY) void dense_outer_sum_kernel(
+    const float* __restrict__ outer, int64_t outer_ld, const float* __restrict__ inner,
+    int64_t inner_ld, uint32_t period, const float* __restrict__ bias, int32_t n, int64_t m,
+    int leaky, float slope, float* __restrict__ y, int64_t y_ld) {
+  const int nv = n / V;
+  for (int64_t j = static_cast<int64_t>(blockIdx.x) * kOsRowsY + threadIdx.y; j < m;
+       j += static_cast<int64_t>(gridDim.x) * kOsRowsY) {
+    const int64_t o = j / period, i = j - o * period;
+    const float* po = outer + o * outer_ld;
+    const float* pi = inner + i * inner_ld;
+    float* py = y + j * y_ld;
+    for (int c = threadIdx.x; c < nv; c += kOsColsX) {
+      float a[V], b[V], q[V];
+      if (V == 4) {
+        *reinterpret_cast<float4*>(a) = *reinterpret_cast<const float4*>(po + 4 * c);
+        *reinterpret_cast<float4*>(q) = *reinterpret_cast<const float4*>(pi + 4 * c);
+        if (bias) *reinterpret_cast<float4*>(b) = *reinterpret_cast<const float4*>(bias + 4 * c);
+      } else {
+        a[0] = po[c];
+        q[0] = pi[c];
+        if (bias) b[0] = bias[c];
+      }
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        float v = a[e];
+        if (bias) v += b[e];
+        v += q[e];
+        if (leaky) v = v > 0.0f ? v : v * slope;
+        a[e] = v;
+      }
+      if (V == 4) *reinterpret_cast<float4*>(py + 4 * c) = *reinterpret_cast<float4*>(a);
+      else py[c] = a[0];
+    }
+  }
+}
+
 int64_t wgrad_chunks(int64_t m, int64_t* chunk_out, int64_t max_chunks = 512) {
   int64_t nchunks = (m + 255) / 256;
   // register-staged kernel: two resident workgroups per CU; LDS-DMA kernel: one (max_chunks 256) --
@@ -1669,6 +1710,31 @@ extern "C" int collie_dense_forward_add(const collie_dense_operand* x, int64_t m
   }
   launch_fwd(p, vec, stream);
   return check_launch("dense_fwd_kernel");
+}
+
+extern "C" int collie_dense_outer_sum(const float* outer, int64_t outer_ld, int64_t n_outer,
+                                      const float* inner, int64_t inner_ld, int64_t period,
+                                      const float* bias, int32_t n, int32_t leaky, float slope,
+                                      float* y, int64_t y_ld, collie_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  COLLIE_REQUIRE(outer && inner && y && n >= 1 && n_outer >= 1 && period >= 1 &&
+                     period < (int64_t{1} << 32),
+                 "dense_outer_sum: bad arguments");
+  COLLIE_REQUIRE(outer_ld >= n && inner_ld >= n && y_ld >= n, "dense_outer_sum: row pitch below n");
+  COLLIE_REQUIRE(n_outer <= (int64_t{1} << 39) / period, "dense_outer_sum: too many rows");
+  const int64_t m = n_outer * period;
+  const int64_t blocks = (m + kOsRowsY - 1) / kOsRowsY;
+  const dim3 grid(static_cast<unsigned>(blocks < 256 * 64 ? blocks : 256 * 64)), block(kOsColsX, kOsRowsY);
+  auto al16 = [](const void* q) { return reinterpret_cast<uintptr_t>(q) % 16 == 0; };
+  const bool vec = n % 4 == 0 && outer_ld % 4 == 0 && inner_ld % 4 == 0 && y_ld % 4 == 0 &&
+                   al16(outer) && al16(inner) && al16(y) && (!bias || al16(bias));
+  if (vec)
+    hipLaunchKernelGGL(dense_outer_sum_kernel<4>, grid, block, 0, stream, outer, outer_ld, inner,
+                       inner_ld, static_cast<uint32_t>(period), bias, n, m, leaky, slope, y, y_ld);
+  else
+    hipLaunchKernelGGL(dense_outer_sum_kernel<1>, grid, block, 0, stream, outer, outer_ld, inner,
+                       inner_ld, static_cast<uint32_t>(period), bias, n, m, leaky, slope, y, y_ld);
+  return check_launch("dense_outer_sum_kernel");
 }
 
 extern "C" size_t collie_dense_weight_grad_workspace_bytes(int64_t m, int32_t n_out, int32_t n_in) {

@@ -13,6 +13,7 @@ GEMM (``collie_dense_forward`` / ``collie_dense_weight_grad``) whose operand gat
 metadata rows on the fly (the ``torch.cat`` input is never materialised), and the optimizers are
 the ``collie_dense_optim_step`` / ``collie_dense_rows_update`` kernels.  There is no CPU fallback.
 """
+import contextlib
 import copy
 import os
 import warnings
@@ -481,14 +482,25 @@ class HybridPretrainedModel(MatrixFactorizationModel):
         saved['combined'] = outs
         return scores.reshape(-1), saved
 
+    @contextlib.contextmanager
+    def catalogue_scope(self):
+        """A stretch of ``score_catalogue`` calls during which no parameter changes (one
+        ``evaluate_in_batches`` call, ``metrics.py:367-386``): the catalogue's item share is computed
+        by the first call and kept until the scope closes."""
+        self.__dict__['_catalogue_share'] = {}
+        try:
+            yield self
+        finally:
+            self.__dict__['_catalogue_share'] = None
+
     def score_catalogue(self, user_ids, n_items: int) -> torch.Tensor:
         """Scores of every ``(user, item < n_items)`` pair, ``[len(user_ids), n_items]``: what
         ``get_preds`` (``metrics.py:77-107``) obtains from ``model(users.repeat_interleave(n),
         arange(n).repeat(U))``.  On that grid the item side of the first combined layer (item
         embedding + item metadata stack, ``hybrid_pretrained_matrix_factorization.py:401-464``) does
-        not depend on the user: it is computed once per ITEM and enters the layer's GEMM over the
-        user columns as a periodic addend, so a pair costs the user's 128 columns of the first layer
-        plus the tail layers instead of the whole head.  Returns None when the model's layout does
+        not depend on the user and the user embedding's share does not depend on the item: each is
+        computed once (per ITEM, per USER), a pair's first layer is the sum of its two rows plus
+        bias and activation (``collie_dense_outer_sum``), and only the tail layers run per pair.  Returns None when the model's layout does
         not allow the split (user metadata, a head of one layer): the caller then takes
         ``model(users, items)``."""
         if (self.user_metadata is not None or len(self.combined_layers) < 2 or n_items < 1
@@ -506,8 +518,15 @@ class HybridPretrainedModel(MatrixFactorizationModel):
         status = self._status_flag()
         with torch.no_grad():
             catalogue = torch.arange(n_items, device=dev)
-            share = torch.empty((n_items, first.weight.shape[0]), dtype=torch.float32, device=dev)
-            for i0 in range(0, n_items, step):
+            kept = self.__dict__.get('_catalogue_share')
+            share = kept.get(n_items) if kept is not None else None
+            have_share = share is not None
+            if not have_share:
+                share = torch.empty((n_items, first.weight.shape[0]), dtype=torch.float32,
+                                    device=dev)
+                if kept is not None:
+                    kept[n_items] = share
+            for i0 in range(0, 0 if have_share else n_items, step):
                 ids = catalogue[i0:i0 + step]
                 n = ids.shape[0]
                 segs = [(self.embeddings[1].weight.data, ids, None)]
@@ -517,6 +536,9 @@ class HybridPretrainedModel(MatrixFactorizationModel):
                 ops.dense_forward(ops.dense_operand(*segs), n, first.weight.data, None, False,
                                   status=status, col_range=(d, first.weight.shape[1]),
                                   out=share[i0:i0 + n])
+            user_share = ops.dense_forward(
+                ops.dense_operand((self.embeddings[0].weight.data, users, None)), n_users,
+                first.weight.data, None, False, status=status, col_range=(0, d))
             scores = torch.empty((n_users, n_items), dtype=torch.float32, device=dev)
             width = min(n_items, step)
             for i0 in range(0, n_items, width):
@@ -527,10 +549,8 @@ class HybridPretrainedModel(MatrixFactorizationModel):
                     m = nu * ni
                     pair_users = users[u0:u0 + nu].repeat_interleave(ni)
                     pair_items = catalogue[i0:i0 + ni].repeat(nu)
-                    x = ops.dense_forward(
-                        ops.dense_operand((self.embeddings[0].weight.data, pair_users, None)), m,
-                        first.weight.data, first.bias.data, True, status=status, col_range=(0, d),
-                        addend=(share[i0:i0 + ni], ni))
+                    x = ops.dense_outer_sum(user_share[u0:u0 + nu], share[i0:i0 + ni],
+                                            first.bias.data, True)
                     for layer in self.combined_layers[1:-1]:
                         x = ops.dense_forward(ops.dense_operand((x, None, None)), m,
                                               layer.weight.data, layer.bias.data, True,

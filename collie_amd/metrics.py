@@ -17,6 +17,7 @@ The callables below then reduce that dense matrix -- any catalogue size, any ``k
 arithmetic is involved there either.  ``k`` above the MFMA kernel's 16 register-resident
 candidates costs one more scoring pass per 16 entries on the fast route.
 """
+import contextlib
 import warnings
 from functools import partial
 from typing import Any, Callable, Iterable, List, Optional
@@ -249,12 +250,16 @@ def evaluate_in_batches(
     else:
         targets = test_interactions.mat.tocsr()
         accumulators = [0] * len(metric_list)
-        for i in range(int(np.ceil(len(test_users) / batch_size))):
-            user_range = test_users[i * batch_size:(i + 1) * batch_size]
-            preds = get_preds(model, user_range, n_items, device)
-            for j, metric in enumerate(metric_list):
-                score = metric(targets=targets, user_ids=user_range, preds=preds, k=k)
-                accumulators[j] += (score * len(user_range))
+        # nothing changes the model inside this loop: a model whose get_preds route has a
+        # per-catalogue part (HybridPretrainedModel.score_catalogue) keeps it between batches
+        scope = getattr(model, 'catalogue_scope', None)
+        with (scope() if scope is not None else contextlib.nullcontext()):
+            for i in range(int(np.ceil(len(test_users) / batch_size))):
+                user_range = test_users[i * batch_size:(i + 1) * batch_size]
+                preds = get_preds(model, user_range, n_items, device)
+                for j, metric in enumerate(metric_list):
+                    score = metric(targets=targets, user_ids=user_range, preds=preds, k=k)
+                    accumulators[j] += (score * len(user_range))
 
     all_scores = [acc_score / len(test_users) for acc_score in accumulators]
     if logger is not None:

@@ -472,6 +472,25 @@ def dense_forward(x_op, m, weight, bias, leaky, transposed=False, out=None, row_
     return out
 
 
+def dense_outer_sum(outer, inner, bias, leaky, out=None):
+    """``act((outer[j // period] + bias) + inner[j % period])`` for ``j < len(outer) * period``,
+    ``period = len(inner)`` (the first combined layer on the users x catalogue grid)."""
+    require_hip(outer, 'outer')
+    require_hip(inner, 'inner')
+    assert outer.dtype == inner.dtype == torch.float32 and outer.dim() == inner.dim() == 2
+    assert outer.stride(1) == 1 and inner.stride(1) == 1 and outer.shape[1] == inner.shape[1]
+    n_outer, n = outer.shape
+    period = inner.shape[0]
+    if out is None:
+        out = torch.empty(n_outer * period, n, dtype=torch.float32, device=outer.device)
+    assert out.shape == (n_outer * period, n) and out.stride(1) == 1 and out.dtype == torch.float32
+    check(load().collie_dense_outer_sum(
+        ptr(outer), outer.stride(0) if n_outer > 1 else n, n_outer, ptr(inner),
+        inner.stride(0) if period > 1 else n, period, ptr(bias), n, 1 if leaky else 0, LEAKY_SLOPE,
+        ptr(out), out.stride(0) if out.shape[0] > 1 else n, stream_ptr()), 'collie_dense_outer_sum')
+    return out
+
+
 def dense_weight_grad(dz_op, x_op, m, n_out, n_in, want_bias=True, workspace=None, status=None):
     """(dW [n_out, n_in], db [n_out] or None, workspace) of ``nn.Linear`` from the two operands."""
     dev = torch.device('cuda', torch.cuda.current_device())

@@ -630,6 +630,18 @@ int collie_dense_forward_add(const collie_dense_operand* x, int64_t m, const flo
                              int64_t add_period, float* y, int64_t y_ld, int32_t* status,
                              collie_stream_t stream);
 
+/* The first combined layer on get_preds' users x catalogue grid (metrics.py:77-107: row j of the
+ * expanded pairs is user j / period, item j mod period) once the layer's two shares are known:
+ * y[j, :] = act((outer[j / period, :] + bias) + inner[j mod period, :]), j < n_outer * period;
+ * outer [n_outer, n] = the user rows times their columns of W, inner [period, n] = the item side
+ * (both from collie_dense_forward with bias = NULL, leaky = 0).  Replaces the nn.Linear + leaky_relu of
+ * hybrid_pretrained_matrix_factorization.py:430-446 on that grid; same rounding order as
+ * collie_dense_forward_add's epilogue.  bias may be NULL. */
+int collie_dense_outer_sum(const float* outer, int64_t outer_ld, int64_t n_outer, const float* inner,
+                           int64_t inner_ld, int64_t period, const float* bias, int32_t n,
+                           int32_t leaky, float slope, float* y, int64_t y_ld,
+                           collie_stream_t stream);
+
 /* autograd of nn.Linear w.r.t. its parameters: dw[n, k] = sum_j dz[j, n] * x[j, k] ([n_out, n_in]
  * contiguous), db[n] = sum_j dz[j, n]; dz is usually the operand (dY, act_ref = Y).  Either output
  * may be NULL.  Deterministic (fixed chunks of rows, partials added in fixed order). */

@@ -707,6 +707,30 @@ def test_hybrid_evaluate_save_load(dev, tmp_path):
     assert list(loaded.state_dict()) == list(model.state_dict())
 
 
+@pytest.mark.parametrize('shape', [(5, 333, 128, True), (1, 1000, 64, True), (7, 1, 32, False),
+                                   (3, 50, 6, True), (4, 17, 10, False), (2, 70000, 16, True)])
+def test_dense_outer_sum_bit_exact(dev, shape):
+    """collie_dense_outer_sum: y[j] = leaky((outer[j // period] + bias) + inner[j % period]) -- three
+    fp32 operations per element, so the result is bit-equal to the same expression in torch; vector
+    and scalar column paths, strided inputs, no bias."""
+    from collie_amd import ops
+    n_outer, period, n, leaky = shape
+    rng = np.random.default_rng(n_outer * 1000 + period)
+    outer_full = torch.tensor(rng.normal(size=(n_outer, n + 4)).astype(np.float32), device=dev)
+    outer = outer_full[:, :n]                                         # row pitch n + 4
+    inner = torch.tensor(rng.normal(size=(period, n)).astype(np.float32), device=dev)
+    for bias in (torch.tensor(rng.normal(size=n).astype(np.float32), device=dev), None):
+        got = ops.dense_outer_sum(outer, inner, bias, leaky)
+        want = outer.repeat_interleave(period, 0)
+        if bias is not None:
+            want = want + bias
+        want = want + inner.repeat(n_outer, 1)
+        if leaky:
+            want = torch.where(want > 0, want, want * np.float32(ops.LEAKY_SLOPE))
+        assert got.shape == (n_outer * period, n)
+        assert torch.equal(got, want)
+
+
 @pytest.mark.parametrize('layout', [
     dict(D=16, ic=24, kw=dict(item_metadata_layers_dims=[32], combined_layers_dims=[32, 16, 8])),
     dict(D=128, ic=256, kw=dict(item_metadata_layers_dims=[128])),          # BASELINE configs[4] head
@@ -739,6 +763,15 @@ def test_hybrid_score_catalogue_equals_pairwise_scores(dev, layout, chunk):
     np.testing.assert_allclose(grid.cpu().numpy(), pairwise, rtol=1e-5, atol=2e-6 * scale)
     np.testing.assert_allclose(grid.cpu().numpy(), want, rtol=1e-5, atol=2e-6 * scale)
     assert torch.equal(get_preds(model, user_ids, N, dev), grid)
+    # inside a scope the item share is kept between calls; outside it is rebuilt (parameters may
+    # have changed in between)
+    with model.catalogue_scope():
+        assert torch.equal(model.score_catalogue(user_ids, N), grid)
+        assert torch.equal(model.score_catalogue(user_ids[:3], N), grid[:3])
+        assert len(model._catalogue_share) == 1
+    with torch.no_grad():
+        model.combined_layers[0].weight.mul_(0.5)
+    assert not torch.equal(model.score_catalogue(user_ids, N), grid)
     model.check_status()
 
 
