@@ -202,6 +202,11 @@ SIGNATURES = {
     'collie_dense_outer_sum': (ctypes.c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
                                               c_void_p, c_int32, c_int32, c_float, c_void_p, c_int64,
                                               c_void_p]),
+    'collie_dense_grid_tail': (ctypes.c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
+                                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                              c_void_p, c_void_p, c_float, c_void_p, c_int32,
+                                              c_void_p, c_int64, c_int64, c_void_p, c_int64,
+                                              c_void_p, c_int64, c_void_p, c_void_p]),
     'collie_dense_weight_grad_workspace_bytes': (c_size_t, [c_int64, c_int32, c_int32]),
     'collie_dense_weight_grad': (ctypes.c_int, [POINTER(DenseOperand), POINTER(DenseOperand),
                                                 c_int64, c_int32, c_int32, c_float, c_void_p,

@@ -1601,6 +1601,149 @@ __global__ __launch_bounds__(kOsColsX* kOsRowsY) void dense_outer_sum_kernel(
   }
 }
 
+// The tail of the reference's default head (combined layers 128 -> 64 -> 32 -> 1) on the users x
+// catalogue grid, one launch, no activation ever written to HBM: a wave takes 32 pairs of one user
+// (32 consecutive items), forms their first-layer rows from the two shares in registers, and runs
+// both remaining Linear layers TRANSPOSED -- Y^T = W X^T, so the pair index stays on the lanes
+// (MFMA B operand in, C columns out) from layer to layer and no LDS transpose is needed.  A lane
+// half h owns the k values the previous layer's C layout hands it (layer 2: k = 64 h + s; layer 3:
+// k = 32 t + (r & 3) + 8 (r >> 2) + 4 h); W2 / W3 are re-laid in LDS so that a lane's four
+// consecutive k are one conflict-free 16-byte read.  MFMA-bound: 160 MFMAs per 32 pairs.
+constexpr int kGtBlock = 512;
+struct GridTailParams {
+  const float* user_share;
+  int64_t us_ld, n_users;
+  const float* item_share;
+  int64_t is_ld, period;
+  const float *b1, *w2, *b2, *w3, *b3, *w4, *b4;
+  float slope;
+  const void* users;
+  int32_t users_dtype;
+  const float* user_bias;
+  int64_t num_users, item0;
+  const float* item_bias;
+  int64_t num_items;
+  float* y;
+  int64_t y_ld;
+  int32_t* status;
+};
+
+__global__ __launch_bounds__(kGtBlock) void dense_grid_tail_kernel(GridTailParams p) {
+  __shared__ __align__(16) float W2s[64 * 128];
+  __shared__ __align__(16) float W3s[32 * 64];
+  __shared__ float consts[64 + 32 + 32];  // b2, b3, w4
+  __shared__ __align__(16) float ubs[kGtBlock / 64][128];  // per wave: user_share[u] + b1 of its user
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 31, h = lane >> 5;
+  for (int idx = tid; idx < 2048; idx += kGtBlock) {  // [t][s4][h][n] <- W2[32 t + n][64 h + 4 s4 ..]
+    const int nn = idx & 31, hh = (idx >> 5) & 1, s4 = (idx >> 6) & 15, t = idx >> 10;
+    *reinterpret_cast<f32x4*>(&W2s[idx * 4]) =
+        *reinterpret_cast<const f32x4*>(&p.w2[(32 * t + nn) * 128 + 64 * hh + 4 * s4]);
+  }
+  for (int idx = tid; idx < 512; idx += kGtBlock) {  // [t][q][h][n] <- W3[n][32 t + 8 q + 4 h ..]
+    const int nn = idx & 31, hh = (idx >> 5) & 1, q = (idx >> 6) & 3, t = idx >> 8;
+    *reinterpret_cast<f32x4*>(&W3s[idx * 4]) =
+        *reinterpret_cast<const f32x4*>(&p.w3[nn * 64 + 32 * t + 8 * q + 4 * hh]);
+  }
+  if (tid < 64) consts[tid] = p.b2 ? p.b2[tid] : 0.0f;
+  else if (tid < 96) consts[tid] = p.b3 ? p.b3[tid - 64] : 0.0f;
+  else if (tid < 128) consts[tid] = p.w4[tid - 96];
+  __syncthreads();
+  const float b4 = p.b4 ? p.b4[0] : 0.0f;
+  const int64_t tiles_per_user = (p.period + 31) / 32;
+  const int64_t ntiles = p.n_users * tiles_per_user;
+  int64_t cur_u = -1;
+  for (int64_t tile = static_cast<int64_t>(blockIdx.x) * (kGtBlock / 64) + wave; tile < ntiles;
+       tile += static_cast<int64_t>(gridDim.x) * (kGtBlock / 64)) {
+    const int64_t u = tile / tiles_per_user;
+    const int64_t i = (tile - u * tiles_per_user) * 32 + n;
+    const bool live = i < p.period;
+    const float* q = p.item_share + (live ? i : p.period - 1) * p.is_ld + 64 * h;
+    if (u != cur_u) {  // wave-uniform; LDS operations of one wave execute in order
+      const float* pu = p.user_share + u * p.us_ld;
+      ubs[wave][2 * lane] = pu[2 * lane] + (p.b1 ? p.b1[2 * lane] : 0.0f);
+      ubs[wave][2 * lane + 1] = pu[2 * lane + 1] + (p.b1 ? p.b1[2 * lane + 1] : 0.0f);
+      cur_u = u;
+    }
+    // ---- layer 2: Y2^T [64 x 32 pairs] = W2 X1^T, two 32-row tiles; the first-layer row is formed
+    // four k at a time, right where the MFMAs consume it (no 64-register copy of it) -------------
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int k = (r & 3) + 8 * (r >> 2) + 4 * h;
+      acc0[r] = consts[k];
+      acc1[r] = consts[32 + k];
+    }
+    // all 16 item-share loads of the tile in flight at once; the LDS operands one step ahead; the
+    // scheduler is fenced per step (left alone it hoists every LDS read of the tile and spills)
+    f32x4 qreg[16];
+#pragma unroll
+    for (int s4 = 0; s4 < 16; ++s4) qreg[s4] = *reinterpret_cast<const f32x4*>(q + 4 * s4);
+    f32x4 un = *reinterpret_cast<const f32x4*>(&ubs[wave][64 * h]);
+    f32x4 a0n = *reinterpret_cast<const f32x4*>(&W2s[((0 * 2 + h) * 32 + n) * 4]);
+    f32x4 a1n = *reinterpret_cast<const f32x4*>(&W2s[(((16 + 0) * 2 + h) * 32 + n) * 4]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s4 = 0; s4 < 16; ++s4) {
+      const f32x4 uv = un, a0 = a0n, a1 = a1n;
+      if (s4 + 1 < 16) {
+        un = *reinterpret_cast<const f32x4*>(&ubs[wave][64 * h + 4 * (s4 + 1)]);
+        a0n = *reinterpret_cast<const f32x4*>(&W2s[(((s4 + 1) * 2 + h) * 32 + n) * 4]);
+        a1n = *reinterpret_cast<const f32x4*>(&W2s[(((16 + s4 + 1) * 2 + h) * 32 + n) * 4]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float x = uv[j] + qreg[s4][j];
+        x = x > 0.0f ? x : x * p.slope;
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], x, acc1, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      acc0[r] = acc0[r] > 0.0f ? acc0[r] : acc0[r] * p.slope;
+      acc1[r] = acc1[r] > 0.0f ? acc1[r] : acc1[r] * p.slope;
+    }
+    // ---- layer 3: Y3^T [32 x 32 pairs] = W3 Y2^T; two partial accumulators = two MFMA chains ------
+    f32x16 acc3a, acc3b;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      acc3a[r] = consts[64 + (r & 3) + 8 * (r >> 2) + 4 * h];
+      acc3b[r] = 0.0f;
+    }
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(&W3s[(((0 * 4 + qd) * 2 + h) * 32 + n) * 4]);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(&W3s[(((1 * 4 + qd) * 2 + h) * 32 + n) * 4]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc3a = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], acc0[4 * qd + j], acc3a, 0, 0, 0);
+        acc3b = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], acc1[4 * qd + j], acc3b, 0, 0, 0);
+      }
+    }
+    // ---- last Linear (32 -> 1) + the two bias tables -----------------------------------------------
+    float part = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v = acc3a[r] + acc3b[r];
+      v = v > 0.0f ? v : v * p.slope;
+      part = fmaf(v, consts[96 + (r & 3) + 8 * (r >> 2) + 4 * h], part);
+    }
+    const float other = __shfl_xor(part, 32);
+    float score = (h == 0 ? part + other : other + part) + b4;
+    if (p.user_bias) {
+      const int64_t uid = load_idx(p.users, p.users_dtype, u);
+      const int64_t it = p.item0 + i;
+      if (uid < 0 || uid >= p.num_users || (live && it >= p.num_items)) {
+        if (p.status) atomicOr(p.status, 1);
+      } else if (live) {
+        score = (score + p.user_bias[uid]) + p.item_bias[it];
+      }
+    }
+    if (live && h == 0) p.y[u * p.y_ld + i] = score;
+  }
+}
+
 int64_t wgrad_chunks(int64_t m, int64_t* chunk_out, int64_t max_chunks = 512) {
   int64_t nchunks = (m + 255) / 256;
   // register-staged kernel: two resident workgroups per CU; LDS-DMA kernel: one (max_chunks 256) --
@@ -1735,6 +1878,66 @@ extern "C" int collie_dense_outer_sum(const float* outer, int64_t outer_ld, int6
     hipLaunchKernelGGL(dense_outer_sum_kernel<1>, grid, block, 0, stream, outer, outer_ld, inner,
                        inner_ld, static_cast<uint32_t>(period), bias, n, m, leaky, slope, y, y_ld);
   return check_launch("dense_outer_sum_kernel");
+}
+
+extern "C" int collie_dense_grid_tail(const float* user_share, int64_t us_ld, int64_t n_users,
+                                      const float* item_share, int64_t is_ld, int64_t period,
+                                      const float* b1, const float* w2, const float* b2,
+                                      const float* w3, const float* b3, const float* w4,
+                                      const float* b4, float slope, const void* users,
+                                      int32_t users_dtype, const float* user_bias, int64_t num_users,
+                                      int64_t item0, const float* item_bias, int64_t num_items,
+                                      float* y, int64_t y_ld, int32_t* status,
+                                      collie_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  COLLIE_REQUIRE(user_share && item_share && w2 && w3 && w4 && y && n_users >= 1 && period >= 1 &&
+                     us_ld >= 128 && is_ld >= 128 && y_ld >= period,
+                 "dense_grid_tail: bad arguments");
+  auto al16 = [](const void* q) { return reinterpret_cast<uintptr_t>(q) % 16 == 0; };
+  COLLIE_REQUIRE(al16(user_share) && al16(item_share) && al16(w2) && al16(w3) && (!b1 || al16(b1)) &&
+                     us_ld % 4 == 0 && is_ld % 4 == 0,
+                 "dense_grid_tail: shares, W2, W3 and b1 must be 16-byte aligned with row pitches of "
+                 "whole 16-byte units");
+  const bool row_bias = user_bias != nullptr || item_bias != nullptr;
+  if (row_bias) {
+    COLLIE_REQUIRE(user_bias && item_bias && users && num_users >= 1 && item0 >= 0 &&
+                       (users_dtype == COLLIE_I32 || users_dtype == COLLIE_I64),
+                   "dense_grid_tail: the bias-table add needs user ids and both bias tables");
+    COLLIE_REQUIRE(item0 + period <= num_items, "dense_grid_tail: items %lld..%lld outside the item "
+                   "bias table (%lld rows)", static_cast<long long>(item0),
+                   static_cast<long long>(item0 + period), static_cast<long long>(num_items));
+  }
+  const int64_t tiles_per_user = (period + 31) / 32;
+  COLLIE_REQUIRE(n_users <= (int64_t{1} << 40) / tiles_per_user, "dense_grid_tail: too many pairs");
+  GridTailParams p;
+  p.user_share = user_share;
+  p.us_ld = us_ld;
+  p.n_users = n_users;
+  p.item_share = item_share;
+  p.is_ld = is_ld;
+  p.period = period;
+  p.b1 = b1;
+  p.w2 = w2;
+  p.b2 = b2;
+  p.w3 = w3;
+  p.b3 = b3;
+  p.w4 = w4;
+  p.b4 = b4;
+  p.slope = slope;
+  p.users = users;
+  p.users_dtype = users_dtype;
+  p.user_bias = row_bias ? user_bias : nullptr;
+  p.num_users = num_users;
+  p.item0 = item0;
+  p.item_bias = item_bias;
+  p.num_items = num_items;
+  p.y = y;
+  p.y_ld = y_ld;
+  p.status = status;
+  const int64_t blocks = (n_users * tiles_per_user + kGtBlock / 64 - 1) / (kGtBlock / 64);
+  hipLaunchKernelGGL(dense_grid_tail_kernel, dim3(static_cast<unsigned>(blocks < 512 ? blocks : 512)),
+                     dim3(kGtBlock), 0, stream, p);
+  return check_launch("dense_grid_tail_kernel");
 }
 
 extern "C" size_t collie_dense_weight_grad_workspace_bytes(int64_t m, int32_t n_out, int32_t n_in) {

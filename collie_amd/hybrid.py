@@ -116,6 +116,7 @@ class HybridPretrainedModel(MatrixFactorizationModel):
     _active_rows_hint = None    # see calculate_loss / _head_backward
     _user_period_hint = None    # see calculate_loss / _head_forward
     _USER_SHARE_ONCE = True     # tests switch it off to compare with the plain first layer
+    _FUSED_GRID_TAIL = True     # score_catalogue: default head's tail in one launch (tests compare)
     # losses of this library under which only the positive and ONE negative of a sample receive a
     # score gradient (adaptive: the arg-max negative, bpr.py:153-167 / hinge.py:157-171; WARP: the
     # first violation, warp.py:73-154)
@@ -540,6 +541,18 @@ class HybridPretrainedModel(MatrixFactorizationModel):
                 ops.dense_operand((self.embeddings[0].weight.data, users, None)), n_users,
                 first.weight.data, None, False, status=status, col_range=(0, d))
             scores = torch.empty((n_users, n_items), dtype=torch.float32, device=dev)
+            shapes = [tuple(layer.weight.shape) for layer in self.combined_layers]
+            if (self._FUSED_GRID_TAIL and shapes[0][0] == 128
+                    and shapes[1:] == [(64, 128), (32, 64), (1, 32)]):
+                # the reference's default head: the whole tail in one launch, nothing but the
+                # scores written
+                second, third = self.combined_layers[1], self.combined_layers[2]
+                ops.dense_grid_tail(user_share, share, first.bias.data, second.weight.data,
+                                    second.bias.data, third.weight.data, third.bias.data,
+                                    last.weight.data.reshape(-1), last.bias.data, users,
+                                    self.biases[0].weight.data.reshape(-1), 0,
+                                    self.biases[1].weight.data.reshape(-1), scores, status=status)
+                return scores
             width = min(n_items, step)
             for i0 in range(0, n_items, width):
                 ni = min(width, n_items - i0)

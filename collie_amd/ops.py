@@ -491,6 +491,30 @@ def dense_outer_sum(outer, inner, bias, leaky, out=None):
     return out
 
 
+def dense_grid_tail(user_share, item_share, b1, w2, b2, w3, b3, w4, b4, users, user_bias, item0,
+                    item_bias, out, status=None):
+    """Scores ``out[u, i]`` of the users x items grid through the default head's tail
+    (128 -> 64 -> 32 -> 1) from the first layer's two shares; see ``collie_dense_grid_tail``."""
+    for t in (user_share, item_share, w2, w3, w4, out):
+        require_hip(t, 'dense_grid_tail')
+        assert t.dtype == torch.float32
+    n_users, period = user_share.shape[0], item_share.shape[0]
+    assert user_share.shape[1] == item_share.shape[1] == 128
+    assert user_share.stride(1) == 1 and item_share.stride(1) == 1
+    assert w2.shape == (64, 128) and w3.shape == (32, 64) and w4.numel() == 32
+    assert w2.is_contiguous() and w3.is_contiguous() and w4.is_contiguous()
+    assert out.shape == (n_users, period) and out.stride(1) == 1
+    users = users.contiguous()
+    check(load().collie_dense_grid_tail(
+        ptr(user_share), user_share.stride(0) if n_users > 1 else 128, n_users, ptr(item_share),
+        item_share.stride(0) if period > 1 else 128, period, ptr(b1), ptr(w2), ptr(b2), ptr(w3),
+        ptr(b3), ptr(w4), ptr(b4), LEAKY_SLOPE, ptr(users), idx_dtype(users), ptr(user_bias),
+        user_bias.shape[0], item0, ptr(item_bias), item_bias.shape[0], ptr(out),
+        out.stride(0) if n_users > 1 else period, ptr(status), stream_ptr()),
+        'collie_dense_grid_tail')
+    return out
+
+
 def dense_weight_grad(dz_op, x_op, m, n_out, n_in, want_bias=True, workspace=None, status=None):
     """(dW [n_out, n_in], db [n_out] or None, workspace) of ``nn.Linear`` from the two operands."""
     dev = torch.device('cuda', torch.cuda.current_device())

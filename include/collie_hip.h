@@ -642,6 +642,21 @@ int collie_dense_outer_sum(const float* outer, int64_t outer_ld, int64_t n_outer
                            int32_t leaky, float slope, float* y, int64_t y_ld,
                            collie_stream_t stream);
 
+/* get_preds' users x catalogue grid through the reference's DEFAULT head (combined_layers_dims =
+ * [128, 64, 32], hybrid_pretrained_matrix_factorization.py:110) in one launch: for u < n_users,
+ * i < period: x1 = leaky((user_share[u] + b1) + item_share[i]) (as collie_dense_outer_sum),
+ * x2 = leaky(W2 x1 + b2) (W2 [64, 128]), x3 = leaky(W3 x2 + b3) (W3 [32, 64]),
+ * y[u * y_ld + i] = w4 . x3 + b4 + user_bias[users[u]] + item_bias[item0 + i] (:430-464, :394-398).
+ * No activation is written to memory.  users: the n_users ids (for the bias table only); user_bias /
+ * item_bias may both be NULL.  Same arithmetic as the layer-by-layer route up to summation order. */
+int collie_dense_grid_tail(const float* user_share, int64_t us_ld, int64_t n_users,
+                           const float* item_share, int64_t is_ld, int64_t period, const float* b1,
+                           const float* w2, const float* b2, const float* w3, const float* b3,
+                           const float* w4, const float* b4, float slope, const void* users,
+                           int32_t users_dtype, const float* user_bias, int64_t num_users,
+                           int64_t item0, const float* item_bias, int64_t num_items, float* y,
+                           int64_t y_ld, int32_t* status, collie_stream_t stream);
+
 /* autograd of nn.Linear w.r.t. its parameters: dw[n, k] = sum_j dz[j, n] * x[j, k] ([n_out, n_in]
  * contiguous), db[n] = sum_j dz[j, n]; dz is usually the operand (dY, act_ref = Y).  Either output
  * may be NULL.  Deterministic (fixed chunks of rows, partials added in fixed order). */

@@ -731,6 +731,36 @@ def test_dense_outer_sum_bit_exact(dev, shape):
         assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize('shape', [(3, 333), (1, 32), (5, 1), (2, 4099)])
+def test_dense_grid_tail_vs_float64(dev, shape):
+    """collie_dense_grid_tail (default head's tail on the users x items grid in one launch) against
+    the same network in float64; ragged item counts, a sub-range of the catalogue (item0 > 0, output
+    rows with a pitch), both bias tables."""
+    from collie_amd import ops
+    n_users, period = shape
+    rng = np.random.default_rng(period)
+    f = lambda *sh: rng.normal(size=sh).astype(np.float32)
+    us, it, b1 = f(n_users, 128), f(period, 128), f(128)
+    w2, b2, w3, b3, w4, b4 = f(64, 128) / 8, f(64), f(32, 64) / 6, f(32), f(32) / 4, f(1)
+    num_users, num_items, item0 = 50, period + 7, 5
+    ub, ib = f(num_users), f(num_items)
+    users = rng.integers(0, num_users, n_users)
+    leaky = lambda v: np.where(v > 0, v, 0.01 * v)
+    x1 = leaky(us.astype(np.float64)[:, None, :] + b1 + it.astype(np.float64)[None, :, :])
+    x2 = leaky(x1 @ w2.astype(np.float64).T + b2)
+    x3 = leaky(x2 @ w3.astype(np.float64).T + b3)
+    want = x3 @ w4.astype(np.float64) + b4[0] + ub[users][:, None] + ib[item0:item0 + period][None, :]
+    t = lambda a: torch.tensor(a, device=dev)
+    out_full = torch.full((n_users, period + 3), -7.0, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    ops.dense_grid_tail(t(us), t(it), t(b1), t(w2), t(b2), t(w3), t(b3), t(w4), t(b4), t(users), t(ub),
+                        item0, t(ib), out_full[:, :period], status=status)
+    assert int(status.item()) == 0
+    got = out_full.cpu().numpy()
+    assert (got[:, period:] == -7.0).all()
+    np.testing.assert_allclose(got[:, :period], want, rtol=2e-5, atol=2e-5 * np.abs(want).max())
+
+
 @pytest.mark.parametrize('layout', [
     dict(D=16, ic=24, kw=dict(item_metadata_layers_dims=[32], combined_layers_dims=[32, 16, 8])),
     dict(D=128, ic=256, kw=dict(item_metadata_layers_dims=[128])),          # BASELINE configs[4] head
@@ -763,6 +793,15 @@ def test_hybrid_score_catalogue_equals_pairwise_scores(dev, layout, chunk):
     np.testing.assert_allclose(grid.cpu().numpy(), pairwise, rtol=1e-5, atol=2e-6 * scale)
     np.testing.assert_allclose(grid.cpu().numpy(), want, rtol=1e-5, atol=2e-6 * scale)
     assert torch.equal(get_preds(model, user_ids, N, dev), grid)
+    if layout['D'] == 128:
+        # the default head takes the one-launch tail (collie_dense_grid_tail); layer by layer the
+        # same scores up to summation order
+        model._FUSED_GRID_TAIL = False
+        by_layer = model.score_catalogue(user_ids, N)
+        model._FUSED_GRID_TAIL = True
+        assert not torch.equal(by_layer, grid)          # i.e. the fused kernel did run above
+        np.testing.assert_allclose(grid.cpu().numpy(), by_layer.cpu().numpy(), rtol=1e-5,
+                                   atol=2e-6 * scale)
     # inside a scope the item share is kept between calls; outside it is rebuilt (parameters may
     # have changed in between)
     with model.catalogue_scope():
