@@ -1652,12 +1652,24 @@ __global__ __launch_bounds__(kGtBlock) void dense_grid_tail_kernel(GridTailParam
   const int64_t tiles_per_user = (p.period + 31) / 32;
   const int64_t ntiles = p.n_users * tiles_per_user;
   int64_t cur_u = -1;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * (kGtBlock / 64);
+  // this lane's 64 floats of the item share of a tile (rows past the range: the last valid row)
+  auto share_row = [&](int64_t tile) {
+    const int64_t i = (tile % tiles_per_user) * 32 + n;
+    return p.item_share + (i < p.period ? i : p.period - 1) * p.is_ld + 64 * h;
+  };
+  f32x4 qnext[16];  // the NEXT tile's rows are fetched while this tile's MFMAs run
+  {
+    const int64_t first = static_cast<int64_t>(blockIdx.x) * (kGtBlock / 64) + wave;
+    const float* q = share_row(first < ntiles ? first : 0);
+#pragma unroll
+    for (int s4 = 0; s4 < 16; ++s4) qnext[s4] = *reinterpret_cast<const f32x4*>(q + 4 * s4);
+  }
   for (int64_t tile = static_cast<int64_t>(blockIdx.x) * (kGtBlock / 64) + wave; tile < ntiles;
-       tile += static_cast<int64_t>(gridDim.x) * (kGtBlock / 64)) {
+       tile += stride) {
     const int64_t u = tile / tiles_per_user;
     const int64_t i = (tile - u * tiles_per_user) * 32 + n;
     const bool live = i < p.period;
-    const float* q = p.item_share + (live ? i : p.period - 1) * p.is_ld + 64 * h;
     if (u != cur_u) {  // wave-uniform; LDS operations of one wave execute in order
       const float* pu = p.user_share + u * p.us_ld;
       ubs[wave][2 * lane] = pu[2 * lane] + (p.b1 ? p.b1[2 * lane] : 0.0f);
@@ -1673,11 +1685,15 @@ __global__ __launch_bounds__(kGtBlock) void dense_grid_tail_kernel(GridTailParam
       acc0[r] = consts[k];
       acc1[r] = consts[32 + k];
     }
-    // all 16 item-share loads of the tile in flight at once; the LDS operands one step ahead; the
-    // scheduler is fenced per step (left alone it hoists every LDS read of the tile and spills)
+    // the LDS operands one step ahead; the scheduler is fenced per step (left alone it hoists every LDS read of the tile and spills)
     f32x4 qreg[16];
 #pragma unroll
-    for (int s4 = 0; s4 < 16; ++s4) qreg[s4] = *reinterpret_cast<const f32x4*>(q + 4 * s4);
+    for (int s4 = 0; s4 < 16; ++s4) qreg[s4] = qnext[s4];
+    {
+      const float* q = share_row(tile + stride < ntiles ? tile + stride : tile);
+#pragma unroll
+      for (int s4 = 0; s4 < 16; ++s4) qnext[s4] = *reinterpret_cast<const f32x4*>(q + 4 * s4);
+    }
     f32x4 un = *reinterpret_cast<const f32x4*>(&ubs[wave][64 * h]);
     f32x4 a0n = *reinterpret_cast<const f32x4*>(&W2s[((0 * 2 + h) * 32 + n) * 4]);
     f32x4 a1n = *reinterpret_cast<const f32x4*>(&W2s[(((16 + 0) * 2 + h) * 32 + n) * 4]);
