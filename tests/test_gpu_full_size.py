@@ -14,7 +14,9 @@ the oracle finishes in seconds):
   per-row fingerprints instead of table clones (a second copy of the tables does not fit).
 * configs[4] (HybridPretrainedModel head, 10 M x 1 M x 128, 256-d item metadata, B = 65,536):
   the step is bit-reproducible, frozen tables do not move, the loss is chunk-additive; unfrozen,
-  only looked-up embedding / bias rows move on the first Adam step.
+  only looked-up embedding / bias rows move on the first Adam step; get_preds over the whole
+  catalogue (grid route) equals model(users, items) on sampled pairs and the layer-by-layer route's
+  metrics.
 """
 import numpy as np
 import pytest
@@ -409,3 +411,43 @@ def test_configs4_hybrid_head_full_size_properties(dev, freeze):
     assert torch.equal(runs[0][0], runs[1][0])
     for n in runs[0][1]:
         assert torch.equal(runs[0][1][n], runs[1][1][n]), n
+
+
+def test_configs4_hybrid_catalogue_scoring_full_size(dev):
+    """get_preds / evaluate_in_batches of the hybrid head over the whole 1 M-item catalogue
+    (metrics.py:77-107, 367-386): the grid route (item share once per item, user share once per user,
+    the tail in one launch) against model(users, items) on sampled pairs incl. the catalogue's edges,
+    bit-reproducible, the same with and without the evaluate scope, and the metrics equal to the
+    layer-by-layer route's."""
+    from collie_amd.interactions import Interactions
+    from collie_amd.metrics import auc, evaluate_in_batches, get_preds, mapk, mrr
+    U, N = 10_000_000, 1_000_000
+    model, _ = _hybrid_c4(dev, True)
+    model.eval()
+    user_ids = np.array([0, U - 1, 1_234_567, 42, 5_000_000])
+    grid = get_preds(model, user_ids, N, dev)
+    assert grid.shape == (len(user_ids), N) and bool(torch.isfinite(grid).all())
+    rng = np.random.default_rng(0)
+    rows = rng.integers(0, len(user_ids), 200_000)
+    items = rng.integers(0, N, 200_000)
+    items[:64] = np.arange(64)                      # first tile
+    items[64:128] = N - 1 - np.arange(64)           # last tiles
+    with torch.no_grad():
+        pair = model(torch.tensor(user_ids[rows], device=dev), torch.tensor(items, device=dev))
+    got = grid[torch.tensor(rows, device=dev), torch.tensor(items, device=dev)]
+    scale = float(pair.abs().max())
+    np.testing.assert_allclose(got.cpu().numpy(), pair.cpu().numpy(), rtol=1e-5, atol=2e-6 * scale)
+    assert torch.equal(get_preds(model, user_ids, N, dev), grid)
+    with model.catalogue_scope():
+        assert torch.equal(get_preds(model, user_ids, N, dev), grid)
+        assert torch.equal(get_preds(model, user_ids[:2], N, dev), grid[:2])
+
+    test = Interactions(users=np.repeat(user_ids[:4] % 1000, 25), items=rng.integers(0, N, 100),
+                        num_users=U, num_items=N, allow_missing_ids=True,
+                        check_num_negative_samples_is_valid=False,
+                        max_number_of_samples_to_consider=0)
+    fused = evaluate_in_batches([mapk, mrr, auc], test, model, k=10, batch_size=3)
+    model._FUSED_GRID_TAIL = False
+    layered = evaluate_in_batches([mapk, mrr, auc], test, model, k=10, batch_size=3)
+    np.testing.assert_allclose(fused, layered, rtol=1e-4, atol=1e-7)
+    model.check_status()
