@@ -983,8 +983,9 @@ __global__ __launch_bounds__(kBlock, 4) void mf_train_fwd_lds(const LdsParams p)
           gi.y = g * uu.y;
           gi.z = g * uu.z;
           gi.w = g * uu.w;
-          *reinterpret_cast<float4*>(p.stage_u + b * D + cidx * 4) = gu;
-          *reinterpret_cast<float4*>(p.stage_i + b * D + cidx * 4) = gi;
+          typedef float nt4 __attribute__((ext_vector_type(4)));
+          __builtin_nontemporal_store(*reinterpret_cast<nt4*>(&gu), reinterpret_cast<nt4*>(p.stage_u + b * D + cidx * 4));
+          __builtin_nontemporal_store(*reinterpret_cast<nt4*>(&gi), reinterpret_cast<nt4*>(p.stage_i + b * D + cidx * 4));
         }
       }
     }
