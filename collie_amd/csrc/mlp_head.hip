@@ -1652,23 +1652,28 @@ __global__ __launch_bounds__(kGtBlock) void dense_grid_tail_kernel(GridTailParam
   const int64_t tiles_per_user = (p.period + 31) / 32;
   const int64_t ntiles = p.n_users * tiles_per_user;
   int64_t cur_u = -1;
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * (kGtBlock / 64);
+  // Tiles are numbered user-fastest (tile = item_tile * n_users + user): the waves that run at the
+  // same time work on the same few item tiles, so an item-share row comes from HBM once and from L2
+  // for the other users.  The stride is a multiple of n_users when there are at least that many
+  // waves, so that a wave keeps its user (and its LDS copy of the user's row) for the whole launch.
+  const int64_t nwaves = static_cast<int64_t>(gridDim.x) * (kGtBlock / 64);
+  const int64_t stride = p.n_users <= nwaves ? nwaves / p.n_users * p.n_users : nwaves;
+  const int64_t first = static_cast<int64_t>(blockIdx.x) * (kGtBlock / 64) + wave;
   // this lane's 64 floats of the item share of a tile (rows past the range: the last valid row)
   auto share_row = [&](int64_t tile) {
-    const int64_t i = (tile % tiles_per_user) * 32 + n;
+    const int64_t i = (tile / p.n_users) * 32 + n;
     return p.item_share + (i < p.period ? i : p.period - 1) * p.is_ld + 64 * h;
   };
   f32x4 qnext[16];  // the NEXT tile's rows are fetched while this tile's MFMAs run
   {
-    const int64_t first = static_cast<int64_t>(blockIdx.x) * (kGtBlock / 64) + wave;
     const float* q = share_row(first < ntiles ? first : 0);
 #pragma unroll
     for (int s4 = 0; s4 < 16; ++s4) qnext[s4] = *reinterpret_cast<const f32x4*>(q + 4 * s4);
   }
-  for (int64_t tile = static_cast<int64_t>(blockIdx.x) * (kGtBlock / 64) + wave; tile < ntiles;
-       tile += stride) {
-    const int64_t u = tile / tiles_per_user;
-    const int64_t i = (tile - u * tiles_per_user) * 32 + n;
+  for (int64_t tile = first < stride ? first : ntiles; tile < ntiles; tile += stride) {
+    const int64_t it = tile / p.n_users;
+    const int64_t u = tile - it * p.n_users;
+    const int64_t i = it * 32 + n;
     const bool live = i < p.period;
     if (u != cur_u) {  // wave-uniform; LDS operations of one wave execute in order
       const float* pu = p.user_share + u * p.us_ld;
@@ -1951,7 +1956,7 @@ extern "C" int collie_dense_grid_tail(const float* user_share, int64_t us_ld, in
   p.y_ld = y_ld;
   p.status = status;
   const int64_t blocks = (n_users * tiles_per_user + kGtBlock / 64 - 1) / (kGtBlock / 64);
-  hipLaunchKernelGGL(dense_grid_tail_kernel, dim3(static_cast<unsigned>(blocks < 512 ? blocks : 512)),
+  hipLaunchKernelGGL(dense_grid_tail_kernel, dim3(static_cast<unsigned>(blocks < 256 ? blocks : 256)),
                      dim3(kGtBlock), 0, stream, p);
   return check_launch("dense_grid_tail_kernel");
 }
