@@ -731,7 +731,7 @@ def test_dense_outer_sum_bit_exact(dev, shape):
         assert torch.equal(got, want)
 
 
-@pytest.mark.parametrize('shape', [(3, 333), (1, 32), (5, 1), (2, 4099)])
+@pytest.mark.parametrize('shape', [(3, 333), (1, 32), (5, 1), (2, 4099), (2500, 40), (70, 977)])
 def test_dense_grid_tail_vs_float64(dev, shape):
     """collie_dense_grid_tail (default head's tail on the users x items grid in one launch) against
     the same network in float64; ragged item counts, a sub-range of the catalogue (item0 > 0, output
