@@ -511,8 +511,13 @@ class HybridPretrainedModel(MatrixFactorizationModel):
         if self.item_metadata is not None and not self.item_metadata.is_cuda:
             self._move_any_external_data_to_device()
         dev = self.embeddings[0].weight.device
-        users = torch.as_tensor(np.asarray(user_ids), dtype=torch.int64, device=dev).contiguous()
+        if isinstance(user_ids, torch.Tensor):
+            users = user_ids.to(device=dev, dtype=torch.int64).contiguous()
+        else:
+            users = torch.as_tensor(np.asarray(user_ids), dtype=torch.int64, device=dev).contiguous()
         n_users = users.shape[0]
+        if n_users == 0:
+            return torch.empty((0, n_items), dtype=torch.float32, device=dev)
         first, last = self.combined_layers[0], self.combined_layers[-1]
         d = self.embeddings[0].weight.shape[1]
         step = self._NO_GRAD_CHUNK

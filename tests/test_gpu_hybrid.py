@@ -793,6 +793,8 @@ def test_hybrid_score_catalogue_equals_pairwise_scores(dev, layout, chunk):
     np.testing.assert_allclose(grid.cpu().numpy(), pairwise, rtol=1e-5, atol=2e-6 * scale)
     np.testing.assert_allclose(grid.cpu().numpy(), want, rtol=1e-5, atol=2e-6 * scale)
     assert torch.equal(get_preds(model, user_ids, N, dev), grid)
+    assert torch.equal(model.score_catalogue(torch.tensor(user_ids), N), grid)     # ids as a tensor
+    assert model.score_catalogue([], N).shape == (0, N)
     if layout['D'] == 128:
         # the default head takes the one-launch tail (collie_dense_grid_tail); layer by layer the
         # same scores up to summation order
