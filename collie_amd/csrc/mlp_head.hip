@@ -1664,13 +1664,17 @@ __global__ __launch_bounds__(kGtBlock) void dense_grid_tail_kernel(GridTailParam
     const int64_t i = (tile / p.n_users) * 32 + n;
     return p.item_share + (i < p.period ? i : p.period - 1) * p.is_ld + 64 * h;
   };
-  f32x4 qnext[16];  // the NEXT tile's rows are fetched while this tile's MFMAs run
+  // two register images of item-share rows: while a tile is computed from one, the NEXT tile's rows
+  // are fetched into the other (the loop is unrolled by two so that the images swap roles without
+  // register copies -- VALU and MFMA issue do not overlap on this chip, every VALU instruction counts)
+  f32x4 qa[16], qb[16];
   {
     const float* q = share_row(first < ntiles ? first : 0);
 #pragma unroll
-    for (int s4 = 0; s4 < 16; ++s4) qnext[s4] = *reinterpret_cast<const f32x4*>(q + 4 * s4);
+    for (int s4 = 0; s4 < 16; ++s4) qa[s4] = *reinterpret_cast<const f32x4*>(q + 4 * s4);
   }
-  for (int64_t tile = first < stride ? first : ntiles; tile < ntiles; tile += stride) {
+  auto leaky = [&](float v) { return fmaxf(v, v * p.slope); };  // slope <= 1 (host check)
+  auto do_tile = [&](int64_t tile, f32x4(&qreg)[16], f32x4(&qnext)[16]) {
     const int64_t it = tile / p.n_users;
     const int64_t u = tile - it * p.n_users;
     const int64_t i = it * 32 + n;
@@ -1690,10 +1694,8 @@ __global__ __launch_bounds__(kGtBlock) void dense_grid_tail_kernel(GridTailParam
       acc0[r] = consts[k];
       acc1[r] = consts[32 + k];
     }
-    // the LDS operands one step ahead; the scheduler is fenced per step (left alone it hoists every LDS read of the tile and spills)
-    f32x4 qreg[16];
-#pragma unroll
-    for (int s4 = 0; s4 < 16; ++s4) qreg[s4] = qnext[s4];
+    // the LDS operands one step ahead; the scheduler is fenced per step (left alone it hoists every
+    // LDS read of the tile and spills)
     {
       const float* q = share_row(tile + stride < ntiles ? tile + stride : tile);
 #pragma unroll
@@ -1713,8 +1715,7 @@ __global__ __launch_bounds__(kGtBlock) void dense_grid_tail_kernel(GridTailParam
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float x = uv[j] + qreg[s4][j];
-        x = x > 0.0f ? x : x * p.slope;
+        const float x = leaky(uv[j] + qreg[s4][j]);
         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], x, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], x, acc1, 0, 0, 0);
       }
@@ -1722,8 +1723,8 @@ __global__ __launch_bounds__(kGtBlock) void dense_grid_tail_kernel(GridTailParam
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      acc0[r] = acc0[r] > 0.0f ? acc0[r] : acc0[r] * p.slope;
-      acc1[r] = acc1[r] > 0.0f ? acc1[r] : acc1[r] * p.slope;
+      acc0[r] = leaky(acc0[r]);
+      acc1[r] = leaky(acc1[r]);
     }
     // ---- layer 3: Y3^T [32 x 32 pairs] = W3 Y2^T; two partial accumulators = two MFMA chains ------
     f32x16 acc3a, acc3b;
@@ -1746,8 +1747,7 @@ __global__ __launch_bounds__(kGtBlock) void dense_grid_tail_kernel(GridTailParam
     float part = 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      float v = acc3a[r] + acc3b[r];
-      v = v > 0.0f ? v : v * p.slope;
+      const float v = leaky(acc3a[r] + acc3b[r]);
       part = fmaf(v, consts[96 + (r & 3) + 8 * (r >> 2) + 4 * h], part);
     }
     const float other = __shfl_xor(part, 32);
@@ -1762,6 +1762,10 @@ __global__ __launch_bounds__(kGtBlock) void dense_grid_tail_kernel(GridTailParam
       }
     }
     if (live && h == 0) p.y[u * p.y_ld + i] = score;
+  };
+  for (int64_t tile = first < stride ? first : ntiles; tile < ntiles; tile += 2 * stride) {
+    do_tile(tile, qa, qb);
+    if (tile + stride < ntiles) do_tile(tile + stride, qb, qa);
   }
 }
 
@@ -1930,6 +1934,8 @@ extern "C" int collie_dense_grid_tail(const float* user_share, int64_t us_ld, in
   }
   const int64_t tiles_per_user = (period + 31) / 32;
   COLLIE_REQUIRE(n_users <= (int64_t{1} << 40) / tiles_per_user, "dense_grid_tail: too many pairs");
+  // the kernel evaluates leaky_relu as max(v, slope * v)
+  COLLIE_REQUIRE(slope <= 1.0f, "dense_grid_tail: negative slope %g above 1", static_cast<double>(slope));
   GridTailParams p;
   p.user_share = user_share;
   p.us_ld = us_ld;

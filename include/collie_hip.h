@@ -648,7 +648,8 @@ int collie_dense_outer_sum(const float* outer, int64_t outer_ld, int64_t n_outer
  * x2 = leaky(W2 x1 + b2) (W2 [64, 128]), x3 = leaky(W3 x2 + b3) (W3 [32, 64]),
  * y[u * y_ld + i] = w4 . x3 + b4 + user_bias[users[u]] + item_bias[item0 + i] (:430-464, :394-398).
  * No activation is written to memory.  users: the n_users ids (for the bias table only); user_bias /
- * item_bias may both be NULL.  Same arithmetic as the layer-by-layer route up to summation order. */
+ * item_bias may both be NULL; slope <= 1.  Same arithmetic as the layer-by-layer route up to
+ * summation order. */
 int collie_dense_grid_tail(const float* user_share, int64_t us_ld, int64_t n_users,
                            const float* item_share, int64_t is_ld, int64_t period, const float* b1,
                            const float* w2, const float* b2, const float* w3, const float* b3,
