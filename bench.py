@@ -283,6 +283,16 @@ def hybrid_leg(steps, warmup, batch=65536, cpu_seconds=0.0):
     return mod.run(argv)
 
 
+def hybrid_get_preds_leg():
+    """The hybrid head scoring a whole catalogue through get_preds (tools/hybrid_eval_bench.py)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        'hybrid_eval_bench', os.path.join(ROOT, 'tools', 'hybrid_eval_bench.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.run([])
+
+
 def main_sharded(args, world, rank, device):
     """N > 1: BASELINE configs[3] -- the 100M x 10M x 128 tables row-sharded over the ranks, one
     rank per GPU, RCCL all-to-all each way; the GLOBAL batch is fixed and split evenly over the
@@ -505,6 +515,9 @@ def main():
         leg = hybrid_leg(args.hybrid_steps, 3)
         result['hybrid'] = {k: leg[k] for k in ('metric', 'value', 'unit', 'ms_per_step',
                                                 'config', 'roofline')}
+        del leg
+        torch.cuda.empty_cache()
+        result['hybrid']['get_preds'] = hybrid_get_preds_leg()
     print(json.dumps(result))
 
 

@@ -17,13 +17,14 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def main():
+def run(argv=None):
+    """Runs the measurement and returns the result dict (bench.py embeds it under ``hybrid``)."""
     ap = argparse.ArgumentParser()
     ap.add_argument('--users', type=int, default=10_000_000)
     ap.add_argument('--items', type=int, default=1_000_000)
     ap.add_argument('--users-scored', type=int, default=16)
     ap.add_argument('--reps', type=int, default=3)
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     from collie_amd.hybrid import HybridPretrainedModel
     from collie_amd.metrics import _get_user_item_pairs, get_preds
     from collie_amd.model import MatrixFactorizationModel
@@ -68,7 +69,7 @@ def main():
     pairs = args.users_scored * N
     # flops per pair through the whole head: metadata layer + first combined layer + tail
     f_pair = 2 * MC * 128 + 2 * (2 * D + 128) * 128 + 2 * (128 * 64 + 64 * 32 + 32)
-    print(json.dumps({
+    return {
         'workload': f'HybridPretrainedModel (configs[4] shape) scores of {args.users_scored} users x '
                     f'{N} items through get_preds',
         'grid_ms': t_grid * 1e3, 'grid_in_evaluate_ms': t_scoped * 1e3,
@@ -77,7 +78,11 @@ def main():
         'grid_pairs_per_s': pairs / t_grid, 'grid_in_evaluate_pairs_per_s': pairs / t_scoped,
         'pairwise_pairs_per_s': pairs / t_pair,
         'pairwise_tflops': pairs * f_pair / t_pair / 1e12,
-        'max_rel_difference': err}))
+        'max_rel_difference': err}
+
+
+def main():
+    print(json.dumps(run()))
 
 
 if __name__ == '__main__':
