@@ -253,6 +253,14 @@ class CapturedTrainStep:
                torch.is_grad_enabled(), w[0].data_ptr(), w[1].data_ptr(), w[2].data_ptr(),
                w[3].data_ptr(), ws.step_id, 0 if ws.buf is None else ws.buf.data_ptr(),
                id(model.__dict__.get('_loss_cfg'))]
+        # the other hyper-parameters a callback or scheduler may change between two steps (momentum
+        # / beta schedules, weight decay): a change sends the step through the slow path, which
+        # reads every cfg again.  Kept in front of the (count, lr) pairs, whose positions
+        # ``_replay`` computes from the END of the list.
+        for o in owners:
+            if o is not None:
+                g = o[1]
+                sig.append((g.get('betas'), g.get('eps'), g.get('weight_decay'), g.get('lr_decay')))
         for o in owners:
             if o is not None:
                 sig.append(_count(o[0], o[2]))

@@ -1142,11 +1142,19 @@ extern "C" int collie_mf_train_update(const collie_mf_tables* t, const collie_mf
   KindPlan k;
   if (plan_kind(k, t, ws, table_mask, is_bias, dense, from_device, cfg, state1, state2, row_stamp))
     return -1;
-  if (small_rows_ok(t, b, dense) && small_descs_ok(is_bias ? nullptr : &k)) {
-    if (launch_small_rows(t, b, ws, is_bias ? nullptr : &k, is_bias ? &k : nullptr, step_id, dyn,
-                          grad_scale, stream))
-      return -2;
-    return sweep_kind(k, t, ws, step_id, dyn, dyn_base, stream);
+  if (small_rows_ok(t, b, dense)) {
+    if (small_descs_ok(is_bias ? nullptr : &k)) {
+      if (launch_small_rows(t, b, ws, is_bias ? nullptr : &k, is_bias ? &k : nullptr, step_id, dyn,
+                            grad_scale, stream))
+        return -2;
+      return sweep_kind(k, t, ws, step_id, dyn, dyn_base, stream);
+    }
+    // collie_mf_train_update_needs_segments answered "no" for this batch (it cannot see the state
+    // pointers), but a table / state / staging row is not 16-byte aligned, so the sorted path below
+    // runs: coalesce here instead of reading segments nobody built for this step
+    if (sort_and_segment(ws.sort, t->num_users + t->num_items, static_cast<uint32_t>(t->num_users),
+                         stream))
+      return -1;
   }
   UpdParams p;
   memset(&p, 0, sizeof(p));
@@ -1207,7 +1215,8 @@ extern "C" int collie_mf_train_update_all(const collie_mf_tables* t, const colli
     if (mask[1] && sweep_kind(kz, t, ws, step_id, dyn, 2, stream)) return -2;
     return 0;
   }
-  // general path: the two ordinary calls (they need collie_mf_train_build_segments first)
+  // general path: the two ordinary calls (they need collie_mf_train_build_segments first; for a
+  // small batch with unaligned rows collie_mf_train_update builds the segments itself)
   if (mask[0] && collie_mf_train_update(t, b, workspace, workspace_bytes, mask[0], 0, dense, step_id,
                                         cfg, state1, state2, row_stamp, grad_scale, stream_))
     return -2;

@@ -530,8 +530,6 @@ class HybridPretrainedModel(MatrixFactorizationModel):
             if not have_share:
                 share = torch.empty((n_items, first.weight.shape[0]), dtype=torch.float32,
                                     device=dev)
-                if kept is not None:
-                    kept[n_items] = share
             for i0 in range(0, 0 if have_share else n_items, step):
                 ids = catalogue[i0:i0 + step]
                 n = ids.shape[0]
@@ -542,6 +540,8 @@ class HybridPretrainedModel(MatrixFactorizationModel):
                 ops.dense_forward(ops.dense_operand(*segs), n, first.weight.data, None, False,
                                   status=status, col_range=(d, first.weight.shape[1]),
                                   out=share[i0:i0 + n])
+            if kept is not None and not have_share:
+                kept[n_items] = share       # only a completely filled share is ever reused
             user_share = ops.dense_forward(
                 ops.dense_operand((self.embeddings[0].weight.data, users, None)), n_users,
                 first.weight.data, None, False, status=status, col_range=(0, d))

@@ -666,6 +666,15 @@ def eval_topk_static(tables, user_ids, item_begin, item_end, k, y_range, scores,
     """``eval_topk`` into caller-provided ``scores`` / ``ids`` [n, k] without any allocation: the
     candidate lists live in the library's static device buffer (``collie_mf_eval_topk_static``;
     at most 1024 users per call, calls on one GPU must not overlap)."""
+    require_hip(user_ids, 'user_ids')
+    n = user_ids.shape[0]
+    if user_ids.dtype != torch.int64 or not user_ids.is_contiguous():
+        raise ValueError('user_ids must be a contiguous int64 tensor')
+    for name, t, dt in (('scores', scores, torch.float32), ('ids', ids, torch.int64)):
+        if (t.dtype != dt or tuple(t.shape) != (n, k) or not t.is_contiguous()
+                or t.device != user_ids.device):
+            raise ValueError(f'{name} must be a contiguous {dt} tensor of shape ({n}, {k}) on '
+                             f'{user_ids.device}')
     has_y, lo, hi = _y(y_range)
     check(load().collie_mf_eval_topk_static(
         byref(tables), ptr(user_ids), user_ids.shape[0], item_begin, item_end, id_stride, id_offset,

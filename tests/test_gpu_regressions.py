@@ -185,3 +185,58 @@ def test_detect_anomaly_on_the_fused_route(capsys):
     finite = torch.isfinite(m.user_embeddings.weight.detach().cpu()).all()
     assert bool(finite), 'a poisoned gradient was applied'
     del before
+
+
+def test_small_batch_with_unaligned_tables_builds_its_own_segments():
+    """B <= 4,096 with dim % 4 == 0 lets callers skip build_segments
+    (``collie_mf_train_update_needs_segments`` == 0), yet tables / optimizer state at a 4-byte offset
+    cannot take the sort-free kernel.  ``collie_mf_train_step`` / ``_update`` must then coalesce by
+    themselves instead of reading segments nobody built: same tables as the aligned run, and a
+    second step with other ids must not reuse the first step's segments."""
+    from collie_amd import _lib, ops
+    dev = torch.device('cuda:0')
+    U, N, D, B, K = 500, 300, 16, 200, 5
+    rng = np.random.default_rng(3)
+    init = {'ue': rng.normal(0, 0.5, (U, D)).astype(np.float32),
+            'ie': rng.normal(0, 0.5, (N, D)).astype(np.float32),
+            'ub': np.zeros((U, 1), np.float32), 'ib': rng.normal(0, 0.05, (N, 1)).astype(np.float32)}
+    batches = [(torch.tensor(rng.integers(0, U, B), dtype=torch.int32, device=dev),
+                torch.tensor(rng.integers(0, N, B), dtype=torch.int32, device=dev),
+                torch.tensor(rng.integers(0, N, (B, K)), device=dev)) for _ in range(3)]
+
+    def offset_view(shape, off):
+        flat = torch.zeros(int(np.prod(shape)) + 4, dtype=torch.float32, device=dev)
+        return flat[off:off + int(np.prod(shape))].view(*shape)
+
+    results = []
+    for off in (0, 1):                      # 0: 16-byte aligned rows; 1: every row 4 bytes off
+        t = {k: offset_view(v.shape, off) for k, v in init.items()}
+        for k, v in init.items():
+            t[k].copy_(torch.from_numpy(v))
+        m = {k: offset_view(init[k].shape, off) for k in ('ue', 'ie')}
+        v2 = {k: offset_view(init[k].shape, off) for k in ('ue', 'ie')}
+        assert (t['ue'].data_ptr() % 16 == 0) == (off == 0)
+        tables = _lib.Tables(t['ue'].data_ptr(), t['ie'].data_ptr(), t['ub'].data_ptr(),
+                             t['ib'].data_ptr(), U, N, D)
+        ws = ops.TrainWorkspace(dev)
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        for s, (users, pos, neg) in enumerate(batches):
+            batch = ops.make_batch(users, pos, neg)
+            assert not ops.train_update_needs_segments(tables, batch, False)
+            buf = ws.ensure(B, K, D, U, N)
+            step_id = ws.next_step()
+            loss = torch.empty(1, device=dev)
+            cfg = ops.make_loss_cfg('adaptive_bpr', N)
+            ops.train_forward(tables, batch, cfg, buf, True, step_id, loss, None, None, status)
+            adam = ops.optim_cfg('sparse_adam', s + 1, 1e-2)
+            sgd = ops.optim_cfg('sgd', s + 1, 1e-1)
+            # no train_build_segments: the library said it is not needed
+            ops.train_update_all(tables, batch, buf, 1, False, step_id,
+                                 [(adam, m['ue'], v2['ue'], None), (adam, m['ie'], v2['ie'], None),
+                                  (sgd, None, None, None), (sgd, None, None, None)])
+        torch.cuda.synchronize()
+        assert int(status.item()) == 0
+        results.append({k: x.cpu().numpy().copy() for k, x in t.items()})
+    for k in init:
+        np.testing.assert_allclose(results[1][k], results[0][k], rtol=1e-6, atol=1e-7, err_msg=k)
+        assert np.abs(results[0][k] - init[k]).max() > 0 or k == 'ub'
