@@ -352,15 +352,15 @@ def main_sharded(args, world, rank, device):
                                             'same tables and global batch on one GPU, fused route',
                 'final_loss': float(loss.item()),
                 'rows_exchanged_per_rank_per_step': model.last_exchange.get('rows_requested'),
-                'gradient_rows_sent_per_rank_per_step': model.last_gradient_rows,
+                'gradient_rows_sent_per_rank_per_step': model.last_exchange.get('gradient_rows_sent'),
                 'phase_ms_rank0': phases,
             },
             'roofline': None,
         }
-        fwd_ms = phases.get('forward_backward')
+        fwd_ms = phases.get('forward')
         if fwd_ms:
-            # rank 0's K1 launch on its compact tables (the phase between the row exchange and the
-            # gradient exchange: K1 + loss finalize + segment export), same algorithmic bytes per
+            # rank 0's K1 launch on its compact table (the phase between the row exchange and the
+            # gradient export: bias unpack + K1 + loss finalize), same algorithmic bytes per
             # positive as the single-GPU line
             alg = fwd_algorithmic_bytes(local_batch)
             achieved = alg / (fwd_ms * 1e-3) / 1e9

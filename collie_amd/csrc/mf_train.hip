@@ -240,7 +240,7 @@ __global__ __launch_bounds__(kBlock) void mf_train_fwd_kernel(const FwdParams p)
     const bool live = g != 0.0f;
     const int sel_item = __shfl(item, sel, kWave);
     const int pos_item_b = __shfl(item, 0, kWave);
-    if (lane <= K) p.ws.touch_item[item] = p.dyn ? p.dyn->tag : touch_tag(p.step_id);
+    if (lane <= K && p.ws.touch_item) p.ws.touch_item[item] = p.dyn ? p.dyn->tag : touch_tag(p.step_id);
     if (lane < 3) {  // lane 0: user entry, lane 1: positive item, lane 2: selected negative
       const int64_t slot = lane == 0 ? b : B + 2 * b + (lane - 1);
       const uint32_t key =
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(kBlock) void mf_train_fwd_fast(const FwdParams p) {
     }
 #pragma unroll
     for (int pass = 0; pass < NPASS; ++pass)
-      if (lig == 0 && pass * RPW + grp <= K)
+      if (lig == 0 && pass * RPW + grp <= K && p.ws.touch_item)
         p.ws.touch_item[item[pass]] = p.dyn ? p.dyn->tag : touch_tag(p.step_id);
     if (lane < 3) {  // lane 0: user entry, lane 1: positive item, lane 2: selected negative
       const int64_t slot = lane == 0 ? b : B + 2 * b + (lane - 1);
@@ -706,6 +706,8 @@ __global__ __launch_bounds__(kBlock, 4) void mf_train_fwd_lds(const LdsParams p)
   const int64_t B = p.batch;
   const uint32_t key_off = static_cast<uint32_t>(p.num_users);
   const int tag = p.dyn ? p.dyn->tag : touch_tag(p.step_id);
+  // no stamps for callers that find the looked-up rows themselves (COLLIE_NO_STAMPS)
+  const bool stamps = p.need_grad && p.touch_item != nullptr;
   bool row_lane[NP], neg_lane[NP];
   int64_t neg_lane_off[NP];
 #pragma unroll
@@ -805,7 +807,7 @@ __global__ __launch_bounds__(kBlock, 4) void mf_train_fwd_lds(const LdsParams p)
       f.ib[q] = p.item_bias[f.item[q]];
       // the item's stamp: most items of a large batch were already stamped by another sample of
       // this step; a stale read only costs a redundant store
-      if (p.need_grad) f.stamp[q] = p.touch_item[f.item[q]];
+      if (stamps) f.stamp[q] = p.touch_item[f.item[q]];
     }
     return f;
   };
@@ -964,7 +966,7 @@ __global__ __launch_bounds__(kBlock, 4) void mf_train_fwd_lds(const LdsParams p)
     const bool live = g != 0.0f;
 #pragma unroll
     for (int q = 0; q < NP; ++q)
-      if (lig == 0 && row_lane[q] && stamp[q] != tag) p.touch_item[item[q]] = static_cast<uint8_t>(tag);
+      if (stamps && lig == 0 && row_lane[q] && stamp[q] != tag) p.touch_item[item[q]] = static_cast<uint8_t>(tag);
     if (live) {  // lane l stages 16-byte chunks l, l + 64, ... of the two rows (dim 512: two)
 #pragma unroll
       for (int c0 = 0; c0 < CH * LPR; c0 += kWave) {
@@ -1209,6 +1211,7 @@ extern "C" int collie_mf_train_forward(const collie_mf_tables* t, const collie_m
     COLLIE_REQUIRE(b->num_neg > 1, "Cannot use WARP loss with a single negative sample!");
   // need_grad bit 1 (COLLIE_DEFER_LOSS): loss_out is written by collie_mf_train_advance_step
   const bool defer_loss = (need_grad & COLLIE_DEFER_LOSS) != 0;
+  const bool no_stamps = (need_grad & COLLIE_NO_STAMPS) != 0;
   need_grad &= 1;
   const bool from_device = step_id == COLLIE_STEP_DEVICE;
   COLLIE_REQUIRE(step_id >= 1 || from_device, "step_id must be >= 1 (got %d)", step_id);
@@ -1218,7 +1221,7 @@ extern "C" int collie_mf_train_forward(const collie_mf_tables* t, const collie_m
                  "workspace too small: need %zu bytes, got %zu", ws.bytes, workspace_bytes);
   // the 8-bit stamp tags start a new cycle: forget the previous cycle's stamps (train_ws.h)
   // (a replayed step: collie_mf_train_advance_step does it on the device)
-  if (need_grad && !from_device && step_id % kTouchCycle == 0)
+  if (need_grad && !from_device && !no_stamps && step_id % kTouchCycle == 0)
     COLLIE_CHECK_HIP(hipMemsetAsync(ws.touch_item, 0, static_cast<size_t>(t->num_items), stream));
 
   FwdParams p;
@@ -1226,6 +1229,7 @@ extern "C" int collie_mf_train_forward(const collie_mf_tables* t, const collie_m
   p.b = *b;
   p.loss = *loss;
   p.ws = ws;
+  if (no_stamps) p.ws.touch_item = nullptr;
   p.s_pos_out = s_pos_out;
   p.s_neg_out = s_neg_out;
   p.status = status;

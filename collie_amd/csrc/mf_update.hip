@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "rowsort.h"
+#include "shard_wire.h"
 
 namespace collie {
 namespace {
@@ -776,6 +777,271 @@ __global__ __launch_bounds__(kBlock) void coo_entries_kernel(const void* __restr
   ecodes[i] = code;
 }
 
+
+// ---- row-sharded step: the requester's gradient rows as the owners' blocks of the wire buffer --------
+// (shard_wire.h).  The batch was run on COMPACT tables (the rows the owners served), user and item
+// rows in one key space: an entry's code says which staging buffer its gradient row lives in.
+struct WireExport {
+  const uint32_t* keys;
+  const uint32_t* vals;
+  const uint32_t* seg_start;
+  const uint32_t* nseg;
+  const uint32_t* long_base;
+  const uint32_t* piece_start;
+  const uint32_t* piece_end;
+  float* partial;        // [max_pieces, D] piece sums, then [max_pieces] bias piece sums
+  int64_t max_pieces;
+  const float* stage_u;
+  const float* stage_i;
+  const float* gcoef;
+  const float* grad_scale;
+  const int64_t* send_rows;   // dense request index -> row of the owner's combined table
+  const GradLayout* lay;
+  float* wire;
+  int world;
+  int D;
+};
+
+// entries [B, 3B) of the forward kernel's list are item rows: key - split is their compact row
+__global__ __launch_bounds__(kBlock) void wire_rekey_kernel(uint32_t* __restrict__ ekeys,
+                                                            uint32_t* __restrict__ ecodes, int64_t B,
+                                                            uint32_t split) {
+  const int64_t e = B + static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (e >= 3 * B) return;
+  ekeys[e] -= split;
+  const uint32_t c = ecodes[e];
+  if (c != kCodeNone) ecodes[e] = c | kCodeItem;
+}
+
+// where each peer's gradient segments start, how many there are, and where its block of the wire
+// buffer starts: thread p finds the first sorted entry at or behind peer p's first compact row
+__global__ __launch_bounds__(64) void wire_layout_kernel(const uint32_t* __restrict__ keys,
+                                                         const uint32_t* __restrict__ seg_of,
+                                                         const uint32_t* __restrict__ nseg, int64_t m,
+                                                         const WireBlocks look, int dim,
+                                                         GradLayout* __restrict__ lay,
+                                                         int64_t* __restrict__ peer_counts) {
+  __shared__ int64_t gfirst[kMaxWorld + 1];
+  const int world = look.world;
+  if (static_cast<int>(threadIdx.x) <= world) {
+    const int p = threadIdx.x;
+    int64_t at = static_cast<int64_t>(nseg[0]);
+    if (p < world) {
+      const int64_t want = look.row0[p];
+      int64_t lo = 0, hi = m;
+      while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (static_cast<int64_t>(keys[mid]) < want) lo = mid + 1;
+        else hi = mid;
+      }
+      if (lo < m) at = static_cast<int64_t>(seg_of[lo]);
+    }
+    gfirst[p] = at;
+    lay->gfirst[p] = at;
+    lay->row0[p] = look.row0[p];
+    lay->dense0[p] = look.first[p];
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  int64_t w = 0;
+  for (int p = 0; p < world; ++p) {
+    const int64_t c = gfirst[p + 1] - gfirst[p];
+    lay->wire0[p] = w;
+    peer_counts[p] = c;
+    w += c + 2 * ((c + dim - 1) / dim);
+  }
+  lay->wire0[world] = w;
+  peer_counts[world] = w;
+}
+
+template <int VEC>
+__device__ __forceinline__ RVec<VEC> wire_entry(const WireExport& p, uint32_t c, int chunk,
+                                                float& sg) {
+  RVec<VEC> x;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) x.v[i] = 0.0f;
+  sg = 0.0f;
+  if (c != kCodeNone) {
+    sg = (c & kCodeNeg) ? -1.0f : 1.0f;
+    const float* stage = (c & kCodeItem) ? p.stage_i : p.stage_u;
+    x = rload<VEC>(stage + static_cast<int64_t>(c & kCodeSample) * p.D + chunk * VEC);
+  }
+  return x;
+}
+
+// d loss / d bias of an entry: items only (the user bias cancels in s+ - s-, see bias_rows_kernel)
+__device__ __forceinline__ float wire_entry_bias(const WireExport& p, uint32_t c) {
+  if (c == kCodeNone || !(c & kCodeItem)) return 0.0f;
+  const float gv = p.gcoef[c & kCodeSample];
+  return (c & kCodeNeg) ? -gv : gv;
+}
+
+template <int VEC, int LPR>
+__global__ __launch_bounds__(kBlock) void wire_piece_kernel(const WireExport p) {
+  constexpr int GPW = kWave / LPR;
+  const int lane = lane_id();
+  const int grp = lane / LPR;
+  const int lig = lane % LPR;
+  const uint32_t npieces = p.nseg[2];
+  const int D = p.D;
+  const int nchunks = (D + VEC - 1) / VEC;
+  const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+  for (int64_t pc0 = (static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + threadIdx.x / kWave) * GPW;
+       pc0 < npieces; pc0 += nwaves * GPW) {
+    const int64_t pc = pc0 + grp;
+    if (pc >= npieces) continue;
+    const uint32_t start = p.piece_start[pc], end = p.piece_end[pc];
+    for (int chunk = lig; chunk < nchunks; chunk += LPR) {
+      RVec<VEC> acc;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc.v[i] = 0.0f;
+      for (uint32_t e0 = start; e0 < end; e0 += 4) {
+        RVec<VEC> x[4];
+        float sg[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          x[q] = wire_entry<VEC>(p, e0 + q < end ? p.vals[e0 + q] : kCodeNone, chunk, sg[q]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (sg[q] != 0.0f) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc.v[i] += sg[q] * x[q].v[i];
+          }
+      }
+      rstore<VEC>(p.partial + pc * D + chunk * VEC, acc);
+    }
+    if (lig == 0) {
+      float b = 0.0f;
+      for (uint32_t e = start; e < end; ++e) b += wire_entry_bias(p, p.vals[e]);
+      p.partial[p.max_pieces * D + pc] = b;
+    }
+  }
+}
+
+template <int VEC, int LPR>
+__global__ __launch_bounds__(kBlock) void wire_rows_kernel(const WireExport p) {
+  constexpr int GPW = kWave / LPR;
+  const int lane = lane_id();
+  const int grp = lane / LPR;
+  const int lig = lane % LPR;
+  const uint32_t nseg = p.nseg[0];
+  const float scale = p.grad_scale ? *p.grad_scale : 1.0f;
+  const int D = p.D;
+  const int nchunks = (D + VEC - 1) / VEC;
+  const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+  for (int64_t seg0 = (static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + threadIdx.x / kWave) * GPW;
+       seg0 < nseg; seg0 += nwaves * GPW) {
+    const int64_t seg = seg0 + grp;
+    const bool active = seg < nseg;
+    uint32_t start = 0, end = 0, key = 0;
+    if (active) {
+      start = p.seg_start[seg];
+      end = p.seg_start[seg + 1];
+      key = p.keys[start];
+    }
+    const uint32_t lbase = active ? p.long_base[seg] : kNoPiece;
+    const uint32_t npc = lbase != kNoPiece ? (end - start + kPieceLen - 1) / kPieceLen : 0u;
+    if (lbase != kNoPiece) end = start;
+    // the peer that owns the row, and the row's place in that peer's block
+    int peer = 0;
+    while (peer + 1 < p.world && static_cast<int64_t>(key) >= p.lay->row0[peer + 1]) ++peer;
+    const int64_t cnt = p.lay->gfirst[peer + 1] - p.lay->gfirst[peer];
+    const int64_t jj = seg - p.lay->gfirst[peer];
+    const int64_t w0 = p.lay->wire0[peer];
+    const int64_t extra = (cnt + D - 1) / D;
+    float bacc = 0.0f;
+    for (int c0 = 0; c0 < nchunks; c0 += LPR) {
+      const int chunk = c0 + lig;
+      const bool on = active && chunk < nchunks;
+      RVec<VEC> acc;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc.v[i] = 0.0f;
+      uint32_t e0 = start;
+      while (__any(e0 < end)) {
+        const uint32_t code = (e0 + lig < end) ? p.vals[e0 + lig] : kCodeNone;
+        const int n_here = e0 < end ? static_cast<int>(min(end - e0, static_cast<uint32_t>(LPR))) : 0;
+        for (int j0 = 0; j0 < LPR; j0 += 4) {
+          if (!__any(j0 < n_here)) break;
+          RVec<VEC> x[4];
+          float sg[4];
+          uint32_t cc[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const uint32_t c = __shfl(code, (j0 + q) % LPR, LPR);
+            cc[q] = (j0 + q < LPR) ? c : kCodeNone;
+            x[q] = wire_entry<VEC>(p, on ? cc[q] : kCodeNone, chunk, sg[q]);
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if (sg[q] != 0.0f) {
+#pragma unroll
+              for (int i = 0; i < VEC; ++i) acc.v[i] += sg[q] * x[q].v[i];
+            }
+            if (c0 == 0 && lig == 0) bacc += wire_entry_bias(p, cc[q]);
+          }
+        }
+        e0 += LPR;
+      }
+      if (on) {
+        for (uint32_t i0 = 0; i0 < npc; i0 += 4) {
+          RVec<VEC> x[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) x[q].v[i] = 0.0f;
+            if (i0 + q < npc)
+              x[q] = rload<VEC>(p.partial + static_cast<int64_t>(lbase + i0 + q) * D + chunk * VEC);
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (i0 + q < npc) {
+#pragma unroll
+              for (int i = 0; i < VEC; ++i) acc.v[i] += x[q].v[i];
+            }
+        }
+        RVec<VEC> g;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) g.v[i] = acc.v[i] * scale;
+        rstore<VEC>(p.wire + (w0 + jj) * D + chunk * VEC, g);
+      }
+    }
+    if (active && lig == 0) {
+      for (uint32_t i = 0; i < npc; ++i) bacc += p.partial[p.max_pieces * D + lbase + i];
+      p.wire[(w0 + cnt) * D + jj] = bacc * scale;
+      const int64_t dense = p.lay->dense0[peer] + (static_cast<int64_t>(key) - p.lay->row0[peer]);
+      reinterpret_cast<int32_t*>(p.wire)[(w0 + cnt + extra) * D + jj] =
+          static_cast<int32_t>(p.send_rows[dense]);
+    }
+  }
+}
+
+// owner side: the received blocks as (row key, code = wire row of the gradient) entries, and the
+// bias gradients as an array indexed like the wire rows
+__global__ __launch_bounds__(kBlock) void wire_entries_kernel(const float* __restrict__ wire, int dim,
+                                                              const WireBlocks w, int64_t num_rows,
+                                                              uint32_t* __restrict__ ekeys,
+                                                              uint32_t* __restrict__ ecodes,
+                                                              float* __restrict__ gbias,
+                                                              int32_t* __restrict__ status) {
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (e >= w.first[w.world]) return;
+  const int p = block_of(w, e);
+  const int64_t jj = e - w.first[p];
+  const int64_t cnt = w.first[p + 1] - w.first[p];
+  const int64_t extra = (cnt + dim - 1) / dim;
+  const int64_t w0 = w.row0[p];
+  int64_t r = reinterpret_cast<const int32_t*>(wire)[(w0 + cnt + extra) * dim + jj];
+  uint32_t code = static_cast<uint32_t>(w0 + jj);
+  if (r < 0 || r >= num_rows) {
+    if (status) atomicOr(status, 1);
+    r = 0;
+    code = kCodeNone;
+  }
+  ekeys[e] = static_cast<uint32_t>(r);
+  ecodes[e] = code;
+  gbias[w0 + jj] = wire[(w0 + cnt) * dim + jj];
+}
+
 }  // namespace
 
 int validate_tables(const collie_mf_tables* t);
@@ -1536,6 +1802,254 @@ extern "C" int collie_sparse_rows_update_pair(float* table, float* bias_table, i
                                                 nullptr, vals, bias_vals, m, cfg, bias_cfg, state1,
                                                 state2, bias_state1, bias_state2, workspace,
                                                 workspace_bytes, status, stream);
+}
+
+// ---- row-sharded step ----------------------------------------------------------------------------------
+namespace collie {
+namespace {
+
+struct ExportWs {
+  uint32_t* seg_of;     // [3B]
+  GradLayout* lay;
+  size_t bytes;
+};
+
+ExportWs carve_export_ws(void* base, int64_t B) {
+  Carver c(base);
+  ExportWs w;
+  w.seg_of = c.take<uint32_t>(3 * B);
+  w.lay = c.take<GradLayout>(1);
+  w.bytes = align_up(c.off, 256);
+  return w;
+}
+
+template <int VEC>
+void launch_wire(int lpr, unsigned pgrid, unsigned grid, bool pieces, hipStream_t stream,
+                 const WireExport& p) {
+#define COLLIE_WIRE_CASE(L)                                                                         \
+  case L:                                                                                           \
+    if (pieces)                                                                                     \
+      hipLaunchKernelGGL((wire_piece_kernel<VEC, L>), dim3(pgrid), dim3(kBlock), 0, stream, p);     \
+    hipLaunchKernelGGL((wire_rows_kernel<VEC, L>), dim3(grid), dim3(kBlock), 0, stream, p);         \
+    break;
+  switch (lpr) {
+    COLLIE_WIRE_CASE(1)
+    COLLIE_WIRE_CASE(2)
+    COLLIE_WIRE_CASE(4)
+    COLLIE_WIRE_CASE(8)
+    COLLIE_WIRE_CASE(16)
+    COLLIE_WIRE_CASE(32)
+    default:
+      if (pieces)
+        hipLaunchKernelGGL((wire_piece_kernel<VEC, 64>), dim3(pgrid), dim3(kBlock), 0, stream, p);
+      hipLaunchKernelGGL((wire_rows_kernel<VEC, 64>), dim3(grid), dim3(kBlock), 0, stream, p);
+  }
+#undef COLLIE_WIRE_CASE
+}
+
+struct OwnerWs {
+  SortWs sort;
+  float* gbias;       // [wire rows]
+  size_t bytes;
+};
+
+OwnerWs carve_owner_ws(void* base, int64_t entries, int64_t wire_rows, int D) {
+  Carver c(base);
+  OwnerWs w;
+  carve_sort_ws(c, w.sort, entries, D);
+  w.gbias = c.take<float>(wire_rows);
+  w.bytes = align_up(c.off, 256);
+  return w;
+}
+
+}  // namespace
+}  // namespace collie
+
+extern "C" size_t collie_shard_export_workspace_bytes(int64_t batch) {
+  if (batch < 1) return 0;
+  return carve_export_ws(nullptr, batch).bytes;
+}
+
+extern "C" int collie_shard_export_grads(const collie_mf_tables* t, const collie_mf_batch* b,
+                                         void* train_workspace, size_t train_workspace_bytes,
+                                         int32_t world, const int64_t* lookup_counts,
+                                         const int64_t* send_rows, const float* grad_scale,
+                                         float* wire, int64_t wire_rows, int64_t* peer_counts,
+                                         void* workspace, size_t workspace_bytes,
+                                         collie_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (validate_tables(t) || validate_batch(b)) return -1;
+  COLLIE_REQUIRE(t->num_users == t->num_items && t->user_emb == t->item_emb,
+                 "export_grads: the tables must be the compact table under both names");
+  COLLIE_REQUIRE(send_rows && wire && peer_counts, "export_grads: NULL pointer");
+  const int64_t B = b->batch;
+  const int D = t->dim;
+  COLLIE_REQUIRE(B < (int64_t{1} << 29), "export_grads: batch too large");
+  WireBlocks look;
+  if (make_blocks(look, lookup_counts, world, D, 1)) return -1;
+  COLLIE_REQUIRE(look.row0[world] <= t->num_users,
+                 "export_grads: the lookup blocks (%lld rows) exceed the compact table (%lld rows)",
+                 static_cast<long long>(look.row0[world]), static_cast<long long>(t->num_users));
+  // at most 3B gradient rows; every peer's block has at most 2 (ceil(c / D)) more rows
+  const int64_t need_rows = 3 * B + 2 * ((3 * B + D - 1) / D + world);
+  COLLIE_REQUIRE(wire_rows >= need_rows, "export_grads: wire holds %lld rows, need %lld",
+                 static_cast<long long>(wire_rows), static_cast<long long>(need_rows));
+  TrainWs ws = carve_train_ws(train_workspace, B, b->num_neg, D, t->num_users, t->num_items);
+  COLLIE_REQUIRE(train_workspace != nullptr && train_workspace_bytes >= ws.bytes,
+                 "workspace too small: need %zu bytes, got %zu", ws.bytes, train_workspace_bytes);
+  ExportWs xw = carve_export_ws(workspace, B);
+  COLLIE_REQUIRE(workspace != nullptr && workspace_bytes >= xw.bytes,
+                 "export workspace too small: need %zu bytes, got %zu", xw.bytes, workspace_bytes);
+  auto al16 = [](const void* q) { return reinterpret_cast<uintptr_t>(q) % 16 == 0; };
+  const int64_t m = 3 * B;
+  const int64_t nkeys = t->num_users;
+  hipLaunchKernelGGL(wire_rekey_kernel, dim3(static_cast<unsigned>((2 * B + kBlock - 1) / kBlock)),
+                     dim3(kBlock), 0, stream, ws.sort.ekeys, ws.sort.ecodes, B,
+                     static_cast<uint32_t>(t->num_users));
+  if (check_launch("wire_rekey_kernel")) return -2;
+  if (sort_and_segment(ws.sort, nkeys, 0xffffffffu, stream, xw.seg_of)) return -1;
+  hipLaunchKernelGGL(wire_layout_kernel, dim3(1), dim3(64), 0, stream, sorted_keys(ws.sort, nkeys),
+                     xw.seg_of, ws.sort.nseg, m, look, D, xw.lay, peer_counts);
+  if (check_launch("wire_layout_kernel")) return -2;
+  WireExport p;
+  memset(&p, 0, sizeof(p));
+  p.keys = sorted_keys(ws.sort, nkeys);
+  p.vals = sorted_vals(ws.sort, nkeys);
+  p.seg_start = ws.sort.seg_start;
+  p.nseg = ws.sort.nseg;
+  p.long_base = ws.sort.long_base;
+  p.piece_start = ws.sort.piece_start;
+  p.piece_end = ws.sort.piece_end;
+  p.partial = ws.sort.partial;
+  p.max_pieces = ws.sort.max_pieces;
+  p.stage_u = ws.stage_u;
+  p.stage_i = ws.stage_i;
+  p.gcoef = ws.gcoef;
+  p.grad_scale = grad_scale;
+  p.send_rows = send_rows;
+  p.lay = xw.lay;
+  p.wire = wire;
+  p.world = world;
+  p.D = D;
+  const int vec = (D % 4 == 0 && al16(wire) && al16(ws.stage_u) && al16(ws.stage_i)) ? 4 : 1;
+  const int nchunks = (D + vec - 1) / vec;
+  int lpr = 1;
+  while (lpr < nchunks && lpr < kWave) lpr *= 2;
+  const int gpw = kWave / lpr;
+  int64_t blocks = (m + gpw * kWavesPerBlock - 1) / (gpw * kWavesPerBlock);
+  if (blocks > 4 * kUpdateBlocks) blocks = 4 * kUpdateBlocks;
+  int64_t pblocks = (max_pieces_for(m) + gpw * kWavesPerBlock - 1) / (gpw * kWavesPerBlock);
+  if (pblocks > 2048) pblocks = 2048;
+  const bool pieces = !small_coalesce(m);
+  if (vec == 4)
+    launch_wire<4>(lpr, static_cast<unsigned>(pblocks), static_cast<unsigned>(blocks), pieces, stream, p);
+  else
+    launch_wire<1>(lpr, static_cast<unsigned>(pblocks), static_cast<unsigned>(blocks), pieces, stream, p);
+  return check_launch("wire_rows_kernel");
+}
+
+extern "C" size_t collie_shard_owner_workspace_bytes(int64_t entries, int64_t wire_rows, int32_t dim) {
+  if (entries < 0 || wire_rows < 0 || dim < 1) return 0;
+  return carve_owner_ws(nullptr, entries < 1 ? 1 : entries, wire_rows < 1 ? 1 : wire_rows, dim).bytes;
+}
+
+extern "C" int collie_shard_owner_update(float* emb, float* bias, int64_t num_rows, int32_t dim,
+                                         int64_t item_base, const float* wire, int64_t wire_rows,
+                                         const int64_t* peer_counts, int32_t world,
+                                         const uint8_t* item_touch, int32_t* row_seg,
+                                         const collie_optim_cfg* cfg, const collie_optim_cfg* bias_cfg,
+                                         float* state1, float* state2, float* bias_state1,
+                                         float* bias_state2, void* workspace, size_t workspace_bytes,
+                                         int32_t* status, collie_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  COLLIE_REQUIRE(emb && bias && cfg && bias_cfg && item_touch && row_seg,
+                 "owner_update: NULL pointer");
+  COLLIE_REQUIRE(num_rows >= 1 && num_rows < (int64_t{1} << 31) && dim >= 1 && item_base >= 0 &&
+                     item_base <= num_rows,
+                 "owner_update: bad table shape");
+  COLLIE_REQUIRE(cfg->algo != COLLIE_OPT_ADAM && bias_cfg->algo != COLLIE_OPT_ADAM,
+                 "Adam does not support sparse gradients, please consider SparseAdam instead");
+  COLLIE_REQUIRE(cfg->step == bias_cfg->step, "owner_update: the two optimizers must be at the same step");
+  WireBlocks w;
+  if (make_blocks(w, peer_counts, world, dim, 2)) return -1;
+  const int64_t m = w.first[world];
+  COLLIE_REQUIRE(m < (int64_t{1} << 30), "owner_update: too many entries");
+  COLLIE_REQUIRE(m == 0 || (wire != nullptr && wire_rows >= w.row0[world]),
+                 "owner_update: wire holds %lld rows, need %lld", static_cast<long long>(wire_rows),
+                 static_cast<long long>(w.row0[world]));
+  OwnerWs ow = carve_owner_ws(workspace, m < 1 ? 1 : m, w.row0[world] < 1 ? 1 : w.row0[world], dim);
+  COLLIE_REQUIRE(workspace && workspace_bytes >= ow.bytes,
+                 "owner workspace too small: need %zu bytes, got %zu", ow.bytes, workspace_bytes);
+  const int step = cfg->step;
+  UpdParams p;
+  memset(&p, 0, sizeof(p));
+  p.D = dim;
+  p.step = step;
+  p.d[0].table = emb;
+  p.d[0].stage = wire;
+  p.d[0].s1 = cfg->algo == COLLIE_OPT_SGD ? nullptr : state1;
+  p.d[0].s2 = cfg->algo == COLLIE_OPT_SPARSE_ADAM ? state2 : nullptr;
+  p.d[0].seg_stamp = row_seg;
+  if (make_hyper(p.d[0].h, cfg, 0, true, p.d[0].s1, p.d[0].s2)) return -1;
+  UpdParams q;
+  memset(&q, 0, sizeof(q));
+  q.D = 1;
+  q.step = step;
+  q.d[0].table = bias;
+  q.d[0].stage = ow.gbias;
+  q.d[0].s1 = bias_cfg->algo == COLLIE_OPT_SGD ? nullptr : bias_state1;
+  q.d[0].s2 = bias_cfg->algo == COLLIE_OPT_SPARSE_ADAM ? bias_state2 : nullptr;
+  q.d[0].seg_stamp = row_seg;
+  if (make_hyper(q.d[0].h, bias_cfg, 0, true, q.d[0].s1, q.d[0].s2)) return -1;
+  if (m > 0) {
+    hipLaunchKernelGGL(wire_entries_kernel, dim3(static_cast<unsigned>((m + kBlock - 1) / kBlock)),
+                       dim3(kBlock), 0, stream, wire, dim, w, num_rows, ow.sort.ekeys,
+                       ow.sort.ecodes, ow.gbias, status);
+    if (check_launch("wire_entries_kernel")) return -2;
+    if (sort_and_segment(ow.sort, num_rows, 0xffffffffu, stream)) return -1;
+    fill_sorted(p, ow.sort, num_rows, 0xffffffffu);
+    fill_sorted(q, ow.sort, num_rows, 0xffffffffu);
+    if (launch_emb<false>(p, m, stream)) return -2;
+    if (!small_coalesce(m))
+      hipLaunchKernelGGL(piece_bias_kernel<false>, dim3(piece_bias_grid(m)), dim3(kBlock), 0, stream, q);
+    hipLaunchKernelGGL(bias_rows_kernel<false>, dim3(bias_grid(m)), dim3(kBlock), 0, stream, q);
+    if (check_launch("bias_rows_kernel")) return -2;
+  }
+  // looked-up item rows without a gradient entry: SparseAdam decays their moments (K5b)
+  const int64_t items = num_rows - item_base;
+  if (items == 0) return 0;
+  auto al16 = [](const void* x) { return reinterpret_cast<uintptr_t>(x) % 16 == 0; };
+  if (cfg->algo == COLLIE_OPT_SPARSE_ADAM) {
+    float* tb = emb + item_base * dim;
+    float* s1 = state1 + item_base * dim;
+    float* s2 = state2 + item_base * dim;
+    const int32_t* seg = row_seg + item_base;
+    if (dim % 4 == 0 && al16(tb) && al16(s1) && al16(s2)) {
+      const int nchunks = dim / 4;
+      const unsigned grid = sweep_grid(items * 4);
+      const int span = items * 4 <= 4096 * static_cast<int64_t>(kBlock) ? 16 : kWave;
+      if (nchunks <= 16)
+        hipLaunchKernelGGL(touched_rows_kernel<4>, dim3(grid), dim3(kBlock), 0, stream, tb, s1, s2,
+                           item_touch, seg, items, dim, step, p.d[0].h, nullptr, 0, span);
+      else if (nchunks <= 32)
+        hipLaunchKernelGGL(touched_rows_kernel<8>, dim3(grid), dim3(kBlock), 0, stream, tb, s1, s2,
+                           item_touch, seg, items, dim, step, p.d[0].h, nullptr, 0, span);
+      else
+        hipLaunchKernelGGL(touched_rows_kernel<16>, dim3(grid), dim3(kBlock), 0, stream, tb, s1, s2,
+                           item_touch, seg, items, dim, step, p.d[0].h, nullptr, 0, span);
+    } else {
+      hipLaunchKernelGGL(touched_sweep_kernel, dim3(sweep_grid(items * dim)), dim3(kBlock), 0, stream,
+                         tb, s1, s2, item_touch, seg, items, dim, step, p.d[0].h, nullptr, 0);
+    }
+    if (check_launch("touched_rows_kernel")) return -2;
+  }
+  if (bias_cfg->algo == COLLIE_OPT_SPARSE_ADAM) {
+    hipLaunchKernelGGL(touched_sweep_kernel, dim3(sweep_grid(items)), dim3(kBlock), 0, stream,
+                       bias + item_base, bias_state1 + item_base, bias_state2 + item_base, item_touch,
+                       row_seg + item_base, items, 1, step, q.d[0].h, nullptr, 0);
+    if (check_launch("touched_sweep_kernel")) return -2;
+  }
+  return 0;
 }
 
 // ---- dense-gradient variants (hybrid head) -----------------------------------

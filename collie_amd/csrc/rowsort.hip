@@ -235,7 +235,8 @@ __global__ __launch_bounds__(kBlock) void seg_write_kernel(const uint32_t* __res
                                                            int64_t m, uint32_t split,
                                                            const uint32_t* __restrict__ blk_heads,
                                                            uint32_t* __restrict__ seg_start,
-                                                           uint32_t* __restrict__ nseg) {
+                                                           uint32_t* __restrict__ nseg,
+                                                           uint32_t* __restrict__ seg_of) {
   constexpr int kWaves = kBlock / kWave;
   __shared__ uint32_t counts[kItems * kWaves];
   const int64_t base = static_cast<int64_t>(blockIdx.x) * kSortTile;
@@ -258,6 +259,14 @@ __global__ __launch_bounds__(kBlock) void seg_write_kernel(const uint32_t* __res
   }
   __syncthreads();
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  if (seg_of) {  // segment index of EVERY entry (heads at or before it, minus one)
+#pragma unroll
+    for (int i = 0; i < kItems; ++i) {
+      const int64_t idx = base + i * kBlock + threadIdx.x;
+      if (idx < m)
+        seg_of[idx] = counts[i * kWaves + w] + __popcll(ball[i] & (lt_mask | (1ull << lane))) - 1u;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < kItems; ++i) {
     if ((ball[i] >> lane) & 1ull) {
@@ -345,7 +354,8 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* wave_t
 __global__ __launch_bounds__(kSmallBlock) void small_sort_segment_kernel(
     const uint32_t* __restrict__ ekeys, const uint32_t* __restrict__ ecodes, int m, int nbits,
     uint32_t split, uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
-    uint32_t* __restrict__ seg_start, uint32_t* __restrict__ nseg, uint32_t* __restrict__ long_base) {
+    uint32_t* __restrict__ seg_start, uint32_t* __restrict__ nseg, uint32_t* __restrict__ long_base,
+    uint32_t* __restrict__ seg_of) {
   __shared__ uint32_t kbuf[2][kSmallMax];
   __shared__ uint32_t vbuf[2][kSmallMax];
   __shared__ uint32_t wcount[kSmallBlock];   // [wave][digit]: a wave's lanes hit distinct banks
@@ -422,6 +432,7 @@ __global__ __launch_bounds__(kSmallBlock) void small_sort_segment_kernel(
 #pragma unroll
   for (int j = 0; j < kSmallPer; ++j) {
     const int idx = tid * kSmallPer + j;
+    if (seg_of && idx < m) seg_of[idx] = hbefore + (head[j] ? 1u : 0u) - 1u;
     if (head[j]) {
       seg_start[hbefore] = idx;
       long_base[hbefore] = kNoPiece;
@@ -458,7 +469,8 @@ int run_pass(const SortWs& s, const uint32_t* kin, const uint32_t* vin, uint32_t
 
 }  // namespace
 
-int sort_and_segment(const SortWs& s, int64_t nkeys, uint32_t split, hipStream_t stream) {
+int sort_and_segment(const SortWs& s, int64_t nkeys, uint32_t split, hipStream_t stream,
+                     uint32_t* seg_of) {
   const RadixPlan plan = radix_plan(nkeys);
   COLLIE_REQUIRE(plan.passes <= 4, "key range too large for the radix plan");
   if (small_coalesce(s.m)) {
@@ -467,7 +479,7 @@ int sort_and_segment(const SortWs& s, int64_t nkeys, uint32_t split, hipStream_t
     const int out = (plan.passes - 1) & 1;  // where sorted_keys() / sorted_vals() look
     hipLaunchKernelGGL(small_sort_segment_kernel, dim3(1), dim3(kSmallBlock), 0, stream, s.ekeys,
                        s.ecodes, static_cast<int>(s.m), nbits, split, s.keys[out], s.vals[out],
-                       s.seg_start, s.nseg, s.long_base);
+                       s.seg_start, s.nseg, s.long_base, seg_of);
     return check_launch("small_sort_segment_kernel");
   }
   for (int pass = 0; pass < plan.passes; ++pass) {
@@ -489,7 +501,7 @@ int sort_and_segment(const SortWs& s, int64_t nkeys, uint32_t split, hipStream_t
   hipLaunchKernelGGL(seg_scan_kernel, dim3(1), dim3(kBlock), 0, stream, s.blk_heads, s.ntiles, s.m,
                      s.nseg, s.seg_start);
   hipLaunchKernelGGL(seg_write_kernel, grid, dim3(kBlock), 0, stream, sorted, s.m, split,
-                     s.blk_heads, s.seg_start, s.nseg);
+                     s.blk_heads, s.seg_start, s.nseg, seg_of);
   int64_t pblocks = (s.m + kBlock - 1) / kBlock;
   if (pblocks > 1024) pblocks = 1024;
   hipLaunchKernelGGL(piece_plan_kernel, dim3(static_cast<unsigned>(pblocks)), dim3(kBlock), 0,

@@ -1,13 +1,23 @@
 // Row-sharded training, requester side: which table rows does this rank's batch look up, who owns
 // them, and what is each sample's row number in the compact tables the owners will send back?
 //
-// The set of looked-up ids is built without sorting the (2+K)*B ids: every id marks a stamp table
-// (plain stores of the step id: all writers of a cell write the same value), and the compact
-// numbering is a prefix sum over that table.  The table is laid out ROUTE-major -- route = (owner,
-// kind), owner = id mod G, kind = user|item, position inside a route = id div G -- so the prefix
-// sum walks memory linearly and the resulting order (owner, kind, id ascending) is exactly the order
-// in which the rows are requested from / returned by the owners.
-#include "common.h"
+// Round 3: the cost of a plan is proportional to the LOOKUPS of the batch, not to the size of the
+// tables (the stamp-table planner of rounds 1-2 walked a cell per table row -- 110 M cells for the
+// 100 M x 10 M shape on every rank, whatever the number of ranks).  The (2 + K) B ids are turned
+// into route-major keys -- route = (owner, kind), owner = id mod G, kind = user | item, position
+// inside a route = id div G -- and coalesced by the stable radix sort the optimizers use
+// (rowsort.hip): a segment of equal keys is one distinct row, the segment index IS the compact row
+// number (owner, kind, id ascending: the order in which rows are requested from / returned by the
+// owners), and the entry -> segment map rewrites the batch in compact numbers.
+//
+// Wire layout (one all-to-all each way, embedding rows and their bias values in ONE buffer): every
+// exchange buffer is a matrix of dim-float rows; the block of one peer holds its c embedding rows
+// followed by ceil(c / dim) rows that carry the c bias values (gradient direction: then as many rows
+// again with the c owner-side row numbers as int32).  The requester uses the received lookup buffer
+// AS its compact embedding table, so compact row numbers skip the bias rows between two peers'
+// blocks: compact = segment index + (bias rows of the peers before the row's owner).
+#include "rowsort.h"
+#include "shard_wire.h"
 
 namespace collie {
 
@@ -16,66 +26,47 @@ int validate_batch(const collie_mf_batch* b);
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kPerThread = 8;
-constexpr int kTile = kBlock * kPerThread;  // table cells per workgroup
-constexpr int kMaxWorld = 16;   // GPUs of one node; keeps Routes well inside the kernarg limit
 
 struct Routes {
   int world;
   int64_t num_users, num_items;
-  int64_t cell_base[2 * kMaxWorld + 1];  // first table cell of a route (tile aligned)
-  int64_t tile_base[2 * kMaxWorld + 1];  // first tile of a route
-  int64_t len[2 * kMaxWorld];            // rows in the route
+  int64_t key_base[2 * kMaxWorld + 1];   // first key of a route (routes are dense in key space)
   int64_t row_base[2 * kMaxWorld];       // owner-side row offset of the route's kind (0 | U_loc(owner))
-};
-
-struct PlanWs {
-  int32_t* stamp;       // [cells]  step id of the last step that looked the row up
-  int32_t* slot;        // [cells]  compact row number of the row in that step
-  uint32_t* tile_count; // [tiles]
-  uint32_t* tile_base_; // [tiles]  exclusive prefix
-  size_t bytes;
 };
 
 void make_routes(Routes& r, int64_t U, int64_t N, int world) {
   r.world = world;
   r.num_users = U;
   r.num_items = N;
-  int64_t cell = 0, tile = 0;
+  int64_t key = 0;
   for (int o = 0; o < world; ++o) {
     const int64_t u_loc = (U - o + world - 1) / world;
     const int64_t n_loc = (N - o + world - 1) / world;
     for (int kind = 0; kind < 2; ++kind) {
       const int q = 2 * o + kind;
-      r.len[q] = kind ? n_loc : u_loc;
       r.row_base[q] = kind ? u_loc : 0;
-      r.cell_base[q] = cell;
-      r.tile_base[q] = tile;
-      const int64_t tiles = (r.len[q] + kTile - 1) / kTile;
-      tile += tiles;
-      cell += tiles * kTile;
+      r.key_base[q] = key;
+      key += kind ? n_loc : u_loc;
     }
   }
-  r.cell_base[2 * world] = cell;
-  r.tile_base[2 * world] = tile;
+  r.key_base[2 * world] = key;   // == U + N
 }
 
-PlanWs carve_plan_ws(void* base, const Routes& r) {
+struct PlanWs {
+  SortWs sort;
+  uint32_t* seg_of;        // [m] compact row of every sorted entry
+  int64_t* shift;          // [world] compact row = segment index + shift[owner]
+  size_t bytes;
+};
+
+PlanWs carve_plan_ws(void* base, int64_t m, int world) {
   Carver c(base);
   PlanWs w;
-  const size_t cells = static_cast<size_t>(r.cell_base[2 * r.world]);
-  const size_t tiles = static_cast<size_t>(r.tile_base[2 * r.world]);
-  w.stamp = c.take<int32_t>(cells);
-  w.slot = c.take<int32_t>(cells);
-  w.tile_count = c.take<uint32_t>(tiles);
-  w.tile_base_ = c.take<uint32_t>(tiles + 1);
+  carve_sort_ws(c, w.sort, m, 1);
+  w.seg_of = c.take<uint32_t>(m);
+  w.shift = c.take<int64_t>(world);
   w.bytes = align_up(c.off, 256);
   return w;
-}
-
-__device__ __forceinline__ int64_t cell_of(const Routes& r, int kind, int64_t id) {
-  const int64_t owner = id % r.world;
-  return r.cell_base[2 * owner + kind] + id / r.world;
 }
 
 // element e of the batch: [0,B) users, [B,2B) positives, [2B, 2B+BK) negatives (b major)
@@ -92,153 +83,109 @@ __device__ __forceinline__ int64_t batch_id(const collie_mf_batch& b, int64_t e,
   return load_idx(b.neg_items, b.neg_dtype, row * b.neg_stride_b + k * b.neg_stride_k);
 }
 
-__global__ __launch_bounds__(kBlock) void plan_mark_kernel(const collie_mf_batch b, const Routes r,
-                                                           int32_t* __restrict__ stamp, int step,
+__global__ __launch_bounds__(kBlock) void plan_keys_kernel(const collie_mf_batch b, const Routes r,
+                                                           uint32_t* __restrict__ ekeys,
+                                                           uint32_t* __restrict__ ecodes,
                                                            int64_t* __restrict__ bad_flag) {
   const int64_t total = b.batch * (2 + b.num_neg);
   for (int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; e < total;
        e += static_cast<int64_t>(gridDim.x) * kBlock) {
     int kind;
-    const int64_t id = batch_id(b, e, kind);
-    if (id < 0 || id >= (kind ? r.num_items : r.num_users)) {
-      *bad_flag = 1;
-      continue;
-    }
-    // read before write: after the first few thousand ids almost every cell is already stamped, and
-    // a (cached) load is far cheaper than a store to a line every CU is writing
-    int32_t* cell = stamp + cell_of(r, kind, id);
-    if (*cell != step) *cell = step;
-  }
-}
-
-__global__ __launch_bounds__(kBlock) void plan_count_kernel(const int32_t* __restrict__ stamp,
-                                                            int step,
-                                                            uint32_t* __restrict__ tile_count) {
-  __shared__ uint32_t wave_tot[kBlock / kWave];
-  const int64_t cell0 = static_cast<int64_t>(blockIdx.x) * kTile + threadIdx.x * kPerThread;
-  const int4 a = *reinterpret_cast<const int4*>(stamp + cell0);
-  const int4 c = *reinterpret_cast<const int4*>(stamp + cell0 + 4);
-  uint32_t n = (a.x == step) + (a.y == step) + (a.z == step) + (a.w == step) + (c.x == step) +
-               (c.y == step) + (c.z == step) + (c.w == step);
-  for (int o = kWave / 2; o > 0; o >>= 1) n += __shfl_xor(n, o, kWave);
-  if (lane_id() == 0) wave_tot[threadIdx.x / kWave] = n;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t t = 0;
-    for (int w = 0; w < kBlock / kWave; ++w) t += wave_tot[w];
-    tile_count[blockIdx.x] = t;
-  }
-}
-
-// one workgroup: exclusive prefix over the tiles, route counts and the total
-__global__ __launch_bounds__(1024) void plan_scan_kernel(const uint32_t* __restrict__ tile_count,
-                                                         uint32_t* __restrict__ tile_base,
-                                                         const Routes r,
-                                                         int64_t* __restrict__ route_counts) {
-  __shared__ uint32_t part[1024];
-  __shared__ uint32_t carry;
-  const int64_t tiles = r.tile_base[2 * r.world];
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  for (int64_t base = 0; base < tiles; base += 1024) {
-    const int64_t i = base + threadIdx.x;
-    const uint32_t v = i < tiles ? tile_count[i] : 0u;
-    part[threadIdx.x] = v;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {  // Hillis-Steele inclusive scan
-      const uint32_t add = threadIdx.x >= o ? part[threadIdx.x - o] : 0u;
-      __syncthreads();
-      part[threadIdx.x] += add;
-      __syncthreads();
-    }
-    if (i < tiles) tile_base[i] = carry + part[threadIdx.x] - v;
-    __syncthreads();
-    if (threadIdx.x == 1023) carry += part[1023];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) tile_base[tiles] = carry;
-  __syncthreads();
-  const int nroutes = 2 * r.world;
-  if (threadIdx.x < nroutes) {
-    const uint32_t lo = tile_base[r.tile_base[threadIdx.x]];
-    const uint32_t hi = tile_base[r.tile_base[threadIdx.x + 1]];
-    route_counts[threadIdx.x] = static_cast<int64_t>(hi - lo);
-  }
-  if (threadIdx.x == 0) route_counts[nroutes] = carry;
-}
-
-__global__ __launch_bounds__(kBlock) void plan_number_kernel(
-    const int32_t* __restrict__ stamp, int step, const uint32_t* __restrict__ tile_base,
-    const Routes r, int32_t* __restrict__ slot, int64_t* __restrict__ send_rows) {
-  __shared__ uint32_t wave_tot[kBlock / kWave];
-  const int64_t tile = blockIdx.x;
-  int route = 0;
-  while (route + 1 < 2 * r.world && tile >= r.tile_base[route + 1]) ++route;
-  const int64_t cell0 = tile * kTile + threadIdx.x * kPerThread;
-  const int64_t local0 = cell0 - r.cell_base[route];  // row inside the route
-  int32_t s[kPerThread];
-  *reinterpret_cast<int4*>(s) = *reinterpret_cast<const int4*>(stamp + cell0);
-  *reinterpret_cast<int4*>(s + 4) = *reinterpret_cast<const int4*>(stamp + cell0 + 4);
-  uint32_t mine = 0;
-#pragma unroll
-  for (int i = 0; i < kPerThread; ++i) mine += (s[i] == step);
-  // exclusive prefix of `mine` over the workgroup
-  uint32_t incl = mine;
-  const int lane = lane_id();
-  for (int o = 1; o < kWave; o <<= 1) {
-    const uint32_t up = __shfl_up(incl, o, kWave);
-    if (lane >= o) incl += up;
-  }
-  if (lane == kWave - 1) wave_tot[threadIdx.x / kWave] = incl;
-  __syncthreads();
-  uint32_t before = tile_base[tile];
-  for (int w = 0; w < static_cast<int>(threadIdx.x / kWave); ++w) before += wave_tot[w];
-  uint32_t pos = before + incl - mine;
-#pragma unroll
-  for (int i = 0; i < kPerThread; ++i) {
-    if (s[i] == step) {
-      slot[cell0 + i] = static_cast<int32_t>(pos);
-      send_rows[pos] = r.row_base[route] + local0 + i;
-      ++pos;
-    }
-  }
-}
-
-__global__ __launch_bounds__(kBlock) void plan_translate_kernel(
-    const collie_mf_batch b, const Routes r, const int32_t* __restrict__ slot,
-    int32_t* __restrict__ cu, int32_t* __restrict__ cp, int64_t* __restrict__ cn) {
-  const int64_t B = b.batch;
-  const int64_t total = B * (2 + b.num_neg);
-  for (int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; e < total;
-       e += static_cast<int64_t>(gridDim.x) * kBlock) {
-    int kind;
     int64_t id = batch_id(b, e, kind);
     const int64_t rows = kind ? r.num_items : r.num_users;
-    int32_t out = 0;
-    if (id >= 0 && id < rows) out = slot[cell_of(r, kind, id)];
-    if (e < B) cu[e] = out;
-    else if (e < 2 * B) cp[e - B] = out;
-    else cn[e - 2 * B] = out;
+    if (id < 0 || id >= rows) {   // reported; the entry then stands for the nearest valid row
+      *bad_flag = 1;
+      id = id < 0 ? 0 : rows - 1;
+    }
+    const int64_t owner = id % r.world;
+    ekeys[e] = static_cast<uint32_t>(r.key_base[2 * owner + kind] + id / r.world);
+    ecodes[e] = static_cast<uint32_t>(e);
   }
 }
 
-// owner side of the lookup exchange: out_emb[j, :] = emb[rows[j], :], out_bias[j] = bias[rows[j]].
-// One 16-lane group per requested row (16-byte pieces when the rows allow it).
+__device__ __forceinline__ int route_of(const Routes& r, uint32_t key) {
+  int q = 0;
+  while (q + 1 < 2 * r.world && static_cast<int64_t>(key) >= r.key_base[q + 1]) ++q;
+  return q;
+}
+
+// one thread per route boundary: where the route starts among the segments (lower bound of its
+// first key in the sorted keys); thread 0 then turns the boundaries into rows per route and into the
+// shift of every owner's compact numbers (the bias rows of the blocks before it, see above).
+__global__ __launch_bounds__(64) void plan_layout_kernel(const uint32_t* __restrict__ keys,
+                                                         const uint32_t* __restrict__ seg_of,
+                                                         const uint32_t* __restrict__ nseg, int64_t m,
+                                                         const Routes r, int dim,
+                                                         int64_t* __restrict__ route_counts,
+                                                         int64_t* __restrict__ shift) {
+  __shared__ int64_t first[2 * kMaxWorld + 1];
+  const int nroutes = 2 * r.world;
+  if (static_cast<int>(threadIdx.x) <= nroutes) {
+    const int64_t want = r.key_base[threadIdx.x];
+    int64_t lo = 0, hi = m;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (static_cast<int64_t>(keys[mid]) < want) lo = mid + 1;
+      else hi = mid;
+    }
+    first[threadIdx.x] = lo < m ? static_cast<int64_t>(seg_of[lo]) : static_cast<int64_t>(nseg[0]);
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  int64_t pad = 0;
+  for (int o = 0; o < r.world; ++o) {
+    shift[o] = pad;
+    const int64_t rows = first[2 * o + 2] - first[2 * o];
+    pad += (rows + dim - 1) / dim;
+  }
+  for (int q = 0; q < nroutes; ++q) route_counts[q] = first[q + 1] - first[q];
+  route_counts[nroutes] = static_cast<int64_t>(nseg[0]);
+}
+
+// one thread per sorted entry: the entry's element of the batch gets its compact row number; a
+// segment's first entry also writes the row to request.
+__global__ __launch_bounds__(kBlock) void plan_emit_kernel(
+    const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+    const uint32_t* __restrict__ seg_of, int64_t m, int64_t B, const Routes r,
+    const int64_t* __restrict__ shift, int32_t* __restrict__ cu, int32_t* __restrict__ cp,
+    int64_t* __restrict__ cn, int64_t* __restrict__ send_rows) {
+  const int64_t j = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (j >= m) return;
+  const uint32_t key = keys[j];
+  const uint32_t seg = seg_of[j];
+  const int64_t e = vals[j];
+  const int q = route_of(r, key);
+  const int64_t compact = static_cast<int64_t>(seg) + shift[q >> 1];
+  if (e < B) cu[e] = static_cast<int32_t>(compact);
+  else if (e < 2 * B) cp[e - B] = static_cast<int32_t>(compact);
+  else cn[e - 2 * B] = compact;
+  if (j == 0 || keys[j - 1] != key)
+    send_rows[seg] = r.row_base[q] + (static_cast<int64_t>(key) - r.key_base[q]);
+}
+
+// owner side of the lookup exchange: the rows the peers requested, written as the peers' blocks of the
+// lookup buffer (embedding rows, then the bias values).  One 16-lane group per requested row (16-byte
+// pieces when the rows allow it).  Item rows (rows at or behind item_base) are stamped "looked up in
+// this step": the owner-side update finds the looked-up rows that received no gradient through these
+// stamps (SparseAdam moves them too).
 template <int VEC>
 __global__ __launch_bounds__(kBlock) void serve_rows_kernel(
     const float* __restrict__ emb, const float* __restrict__ bias, int64_t num_rows, int dim,
-    const int64_t* __restrict__ rows, int64_t m, float* __restrict__ out_emb,
-    float* __restrict__ out_bias, int32_t* __restrict__ status) {
+    const int64_t* __restrict__ rows, const WireBlocks w, float* __restrict__ out,
+    uint8_t* __restrict__ touch, int64_t item_base, int tag, int32_t* __restrict__ status) {
   constexpr int LPR = 16;
   const int lig = threadIdx.x % LPR;
+  const int64_t m = w.first[w.world];
   const int64_t ngroups = static_cast<int64_t>(gridDim.x) * (kBlock / LPR);
   for (int64_t j = static_cast<int64_t>(blockIdx.x) * (kBlock / LPR) + threadIdx.x / LPR; j < m;
        j += ngroups) {
     const int64_t r = rows[j];
     const bool ok = r >= 0 && r < num_rows;
     if (!ok && lig == 0 && status) atomicOr(status, 1);
+    const int p = block_of(w, j);
+    const int64_t jj = j - w.first[p];
     const float* src = emb + (ok ? r : 0) * dim;
-    float* dst = out_emb + j * dim;
+    float* dst = out + (w.row0[p] + jj) * dim;
     if (VEC == 4) {
       for (int c = lig; c < dim / 4; c += LPR) {
         float4 v = {0.f, 0.f, 0.f, 0.f};
@@ -248,8 +195,26 @@ __global__ __launch_bounds__(kBlock) void serve_rows_kernel(
     } else {
       for (int c = lig; c < dim; c += LPR) dst[c] = ok ? src[c] : 0.0f;
     }
-    if (lig == 0) out_bias[j] = ok ? bias[r] : 0.0f;
+    if (lig == 0) {
+      out[(w.row0[p] + (w.first[p + 1] - w.first[p])) * dim + jj] = ok ? bias[r] : 0.0f;
+      if (touch && ok && r >= item_base) {
+        uint8_t* cell = touch + (r - item_base);
+        if (*cell != static_cast<uint8_t>(tag)) *cell = static_cast<uint8_t>(tag);
+      }
+    }
   }
+}
+
+// requester side: the bias values of the received lookup buffer as an array indexed like its rows
+// (compact row numbers), which is what the fused forward kernel reads.
+__global__ __launch_bounds__(kBlock) void unpack_bias_kernel(const float* __restrict__ buf, int dim,
+                                                             const WireBlocks w,
+                                                             float* __restrict__ bias_out) {
+  const int64_t j = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (j >= w.first[w.world]) return;
+  const int p = block_of(w, j);
+  const int64_t jj = j - w.first[p];
+  bias_out[w.row0[p] + jj] = buf[(w.row0[p] + (w.first[p + 1] - w.first[p])) * dim + jj];
 }
 
 }  // namespace
@@ -257,46 +222,83 @@ __global__ __launch_bounds__(kBlock) void serve_rows_kernel(
 
 using namespace collie;
 
+extern "C" int64_t collie_shard_wire_rows(const int64_t* counts, int32_t world, int32_t dim,
+                                          int32_t gradient) {
+  WireBlocks w;
+  if (dim < 1 || make_blocks(w, counts, world, dim, gradient ? 2 : 1)) return -1;
+  return w.row0[world];
+}
+
 extern "C" int collie_shard_serve_rows(const float* emb, const float* bias, int64_t num_rows,
-                                       int32_t dim, const int64_t* rows, int64_t m, float* out_emb,
-                                       float* out_bias, int32_t* status, collie_stream_t stream_) {
+                                       int32_t dim, const int64_t* rows, const int64_t* peer_counts,
+                                       int32_t world, float* out, int64_t out_rows,
+                                       uint8_t* item_touch, int64_t item_base, int32_t step_id,
+                                       int32_t* status, collie_stream_t stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   COLLIE_REQUIRE(emb && bias && num_rows >= 1 && dim >= 1, "serve_rows: bad table");
-  COLLIE_REQUIRE(m >= 0, "serve_rows: bad row count");
+  WireBlocks w;
+  if (make_blocks(w, peer_counts, world, dim, 1)) return -1;
+  int tag = 0;
+  if (item_touch) {
+    COLLIE_REQUIRE(item_base >= 0 && item_base <= num_rows && step_id >= 1,
+                   "serve_rows: bad item_base / step_id");
+    tag = touch_tag(step_id);
+    // the 8-bit tags start a new cycle: forget the previous cycle's stamps (train_ws.h)
+    if (step_id % kTouchCycle == 0 && num_rows > item_base)
+      COLLIE_CHECK_HIP(hipMemsetAsync(item_touch, 0, static_cast<size_t>(num_rows - item_base), stream));
+  }
+  const int64_t m = w.first[world];
   if (m == 0) return 0;
-  COLLIE_REQUIRE(rows && out_emb && out_bias, "serve_rows: NULL pointer");
+  COLLIE_REQUIRE(rows && out, "serve_rows: NULL pointer");
+  COLLIE_REQUIRE(out_rows >= w.row0[world], "serve_rows: out holds %lld rows, need %lld",
+                 static_cast<long long>(out_rows), static_cast<long long>(w.row0[world]));
   int64_t blocks = (m + kBlock / 16 - 1) / (kBlock / 16);
   if (blocks > 65536) blocks = 65536;
   auto al16 = [](const void* q) { return reinterpret_cast<uintptr_t>(q) % 16 == 0; };
-  if (dim % 4 == 0 && al16(emb) && al16(out_emb))
+  if (dim % 4 == 0 && al16(emb) && al16(out))
     hipLaunchKernelGGL(serve_rows_kernel<4>, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0,
-                       stream, emb, bias, num_rows, dim, rows, m, out_emb, out_bias, status);
+                       stream, emb, bias, num_rows, dim, rows, w, out, item_touch, item_base, tag,
+                       status);
   else
     hipLaunchKernelGGL(serve_rows_kernel<1>, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0,
-                       stream, emb, bias, num_rows, dim, rows, m, out_emb, out_bias, status);
+                       stream, emb, bias, num_rows, dim, rows, w, out, item_touch, item_base, tag,
+                       status);
   return check_launch("serve_rows_kernel");
 }
 
-extern "C" size_t collie_shard_plan_workspace_bytes(int64_t num_users, int64_t num_items,
-                                                    int32_t world) {
-  if (num_users < 1 || num_items < 1 || world < 1 || world > kMaxWorld) return 0;
-  Routes r;
-  make_routes(r, num_users, num_items, world);
-  return carve_plan_ws(nullptr, r).bytes;
+extern "C" int collie_shard_unpack_bias(const float* buf, int64_t buf_rows, int32_t dim,
+                                        const int64_t* peer_counts, int32_t world, float* bias_out,
+                                        collie_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  COLLIE_REQUIRE(dim >= 1, "unpack_bias: bad dim");
+  WireBlocks w;
+  if (make_blocks(w, peer_counts, world, dim, 1)) return -1;
+  const int64_t m = w.first[world];
+  if (m == 0) return 0;
+  COLLIE_REQUIRE(buf && bias_out, "unpack_bias: NULL pointer");
+  COLLIE_REQUIRE(buf_rows >= w.row0[world], "unpack_bias: buffer holds %lld rows, need %lld",
+                 static_cast<long long>(buf_rows), static_cast<long long>(w.row0[world]));
+  hipLaunchKernelGGL(unpack_bias_kernel, dim3(static_cast<unsigned>((m + kBlock - 1) / kBlock)),
+                     dim3(kBlock), 0, stream, buf, dim, w, bias_out);
+  return check_launch("unpack_bias_kernel");
+}
+
+extern "C" size_t collie_shard_plan_workspace_bytes(int64_t batch, int32_t num_neg, int32_t world) {
+  if (batch < 1 || num_neg < 1 || world < 1 || world > kMaxWorld) return 0;
+  return carve_plan_ws(nullptr, batch * (2 + static_cast<int64_t>(num_neg)), world).bytes;
 }
 
 extern "C" int collie_shard_plan(const collie_mf_batch* b, int64_t num_users, int64_t num_items,
-                                 int32_t world, int32_t step_id, void* workspace,
-                                 size_t workspace_bytes, int32_t* compact_users,
-                                 int32_t* compact_pos, int64_t* compact_neg, int64_t* send_rows,
-                                 int64_t send_capacity, int64_t* route_counts,
+                                 int32_t world, int32_t dim, void* workspace, size_t workspace_bytes,
+                                 int32_t* compact_users, int32_t* compact_pos, int64_t* compact_neg,
+                                 int64_t* send_rows, int64_t send_capacity, int64_t* route_counts,
                                  collie_stream_t stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   if (validate_batch(b)) return -1;
   COLLIE_REQUIRE(world >= 1 && world <= kMaxWorld, "shard_plan: world must be in [1, %d]", kMaxWorld);
+  COLLIE_REQUIRE(dim >= 1, "shard_plan: bad dim");
   COLLIE_REQUIRE(num_users >= 1 && num_items >= 1 && num_users + num_items < (int64_t{1} << 31),
                  "shard_plan: bad table sizes");
-  COLLIE_REQUIRE(step_id >= 1, "shard_plan: step_id must be >= 1");
   COLLIE_REQUIRE(compact_users && compact_pos && compact_neg && send_rows && route_counts,
                  "shard_plan: NULL output");
   const int64_t lookups = b->batch * (2 + b->num_neg);
@@ -305,27 +307,25 @@ extern "C" int collie_shard_plan(const collie_mf_batch* b, int64_t num_users, in
                  static_cast<long long>(send_capacity), static_cast<long long>(max_rows));
   Routes r;
   make_routes(r, num_users, num_items, world);
-  PlanWs ws = carve_plan_ws(workspace, r);
+  PlanWs ws = carve_plan_ws(workspace, lookups, world);
   COLLIE_REQUIRE(workspace && workspace_bytes >= ws.bytes,
                  "shard_plan: workspace too small: need %zu bytes, got %zu", ws.bytes,
                  workspace_bytes);
-  const int64_t tiles = r.tile_base[2 * world];
-  COLLIE_CHECK_HIP(hipMemsetAsync(route_counts, 0, sizeof(int64_t) * (2 * world + 2), stream));
+  const int nroutes = 2 * world;
+  COLLIE_CHECK_HIP(hipMemsetAsync(route_counts, 0, sizeof(int64_t) * (nroutes + 2), stream));
   int64_t grid = (lookups + kBlock - 1) / kBlock;
   if (grid > 8192) grid = 8192;
-  hipLaunchKernelGGL(plan_mark_kernel, dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0, stream,
-                     *b, r, ws.stamp, step_id, route_counts + 2 * world + 1);
-  if (check_launch("plan_mark_kernel")) return -2;
-  hipLaunchKernelGGL(plan_count_kernel, dim3(static_cast<unsigned>(tiles)), dim3(kBlock), 0, stream,
-                     ws.stamp, step_id, ws.tile_count);
-  if (check_launch("plan_count_kernel")) return -2;
-  hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(1024), 0, stream, ws.tile_count, ws.tile_base_,
-                     r, route_counts);
-  if (check_launch("plan_scan_kernel")) return -2;
-  hipLaunchKernelGGL(plan_number_kernel, dim3(static_cast<unsigned>(tiles)), dim3(kBlock), 0,
-                     stream, ws.stamp, step_id, ws.tile_base_, r, ws.slot, send_rows);
-  if (check_launch("plan_number_kernel")) return -2;
-  hipLaunchKernelGGL(plan_translate_kernel, dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0,
-                     stream, *b, r, ws.slot, compact_users, compact_pos, compact_neg);
-  return check_launch("plan_translate_kernel");
+  hipLaunchKernelGGL(plan_keys_kernel, dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0, stream,
+                     *b, r, ws.sort.ekeys, ws.sort.ecodes, route_counts + nroutes + 1);
+  if (check_launch("plan_keys_kernel")) return -2;
+  const int64_t nkeys = num_users + num_items;
+  if (sort_and_segment(ws.sort, nkeys, 0xffffffffu, stream, ws.seg_of)) return -1;
+  hipLaunchKernelGGL(plan_layout_kernel, dim3(1), dim3(64), 0, stream, sorted_keys(ws.sort, nkeys),
+                     ws.seg_of, ws.sort.nseg, lookups, r, dim, route_counts, ws.shift);
+  if (check_launch("plan_layout_kernel")) return -2;
+  hipLaunchKernelGGL(plan_emit_kernel, dim3(static_cast<unsigned>((lookups + kBlock - 1) / kBlock)),
+                     dim3(kBlock), 0, stream, sorted_keys(ws.sort, nkeys), sorted_vals(ws.sort, nkeys),
+                     ws.seg_of, lookups, b->batch, r, ws.shift, compact_users, compact_pos, compact_neg,
+                     send_rows);
+  return check_launch("plan_emit_kernel");
 }

@@ -11,6 +11,11 @@ namespace collie {
 constexpr uint32_t kCodeNone = 0x80000000u;  // entry contributes nothing (zero gradient)
 constexpr uint32_t kCodeNeg = 0x40000000u;   // contribution enters with a minus sign
 constexpr uint32_t kCodeMask = 0x3fffffffu;  // index of the staged row (sample index b)
+// Row-sharded gradient export only (mf_update.hip): user and item rows of the compact tables share
+// ONE key space there, so the kind of an entry travels in its code (set after the forward kernel;
+// the sample index then has 29 bits: (1 + K) * B < 2^30 and K >= 1 keep B below 2^29).
+constexpr uint32_t kCodeItem = 0x20000000u;
+constexpr uint32_t kCodeSample = 0x1fffffffu;
 
 constexpr int kSortTile = 2048;       // entries per workgroup per radix pass
 constexpr int kMaxRadixBits = 11;
@@ -104,7 +109,9 @@ inline void carve_sort_ws(Carver& c, SortWs& s, int64_t m, int D) {
   s.max_pieces = max_pieces_for(m);
   s.piece_start = c.take<uint32_t>(s.max_pieces);
   s.piece_end = c.take<uint32_t>(s.max_pieces);
-  s.partial = c.take<float>(static_cast<size_t>(s.max_pieces) * D);
+  // D floats per piece + one more: the row-sharded gradient export keeps a piece's bias sum at
+  // partial[max_pieces * D + piece]
+  s.partial = c.take<float>(static_cast<size_t>(s.max_pieces) * (D + 1));
 }
 
 // radix plan for keys in [0, nkeys)

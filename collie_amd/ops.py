@@ -190,6 +190,7 @@ def train_schedule_steps(tables, batch, ws_buf, first_step_id, n_steps, cfgs):
 
 
 DEFER_LOSS = 2             # COLLIE_DEFER_LOSS
+NO_STAMPS = 4              # COLLIE_NO_STAMPS
 SMALL_COALESCE_MAX = 4096  # csrc/train_ws.h kSmallMax: coalesces this small cut no pieces
 
 
@@ -574,26 +575,39 @@ def sample_batch(rows, cols, order, start, batch, indptr, indices, num_items, nu
     return (users, pos), neg
 
 
-# ---- row-sharded training: requester-side plan ---------------------------------------------------
-class ShardPlanner:
-    """Persistent stamp / slot tables of one sharded model + the per-step plan call."""
+# ---- row-sharded training (collie_shard_*) --------------------------------------------------------
+def _i64_array(values):
+    arr = (ctypes.c_int64 * len(values))(*[int(v) for v in values])
+    return arr
 
-    def __init__(self, num_users, num_items, world, device):
-        self.num_users, self.num_items, self.world = int(num_users), int(num_items), int(world)
-        need = int(load().collie_shard_plan_workspace_bytes(num_users, num_items, world))
-        if need == 0:
-            raise _lib.CollieHipError('collie_shard_plan_workspace_bytes: bad sizes')
-        self.buf = torch.zeros(need, dtype=torch.uint8, device=device)
-        self.step = 0
+
+def shard_wire_rows(counts, dim, gradient):
+    """Rows of an exchange buffer whose peer blocks hold ``counts[p]`` entries (shard_wire.h)."""
+    rows = int(load().collie_shard_wire_rows(_i64_array(counts), len(counts), dim,
+                                             1 if gradient else 0))
+    if rows < 0:
+        raise _lib.CollieHipError('collie_shard_wire_rows: bad arguments')
+    return rows
+
+
+class ShardPlanner:
+    """Sort scratch of the requester-side plan + the per-step plan call (``collie_shard_plan``)."""
+
+    def __init__(self, num_users, num_items, world, dim, device):
+        self.num_users, self.num_items = int(num_users), int(num_items)
+        self.world, self.dim = int(world), int(dim)
+        self.device = device
+        self.buf = None
 
     def plan(self, users, pos_items, neg_items):
         batch = make_batch(users, pos_items, neg_items)
         B, K = neg_items.shape
         dev = users.device
-        self.step += 1
-        if self.step >= 2 ** 31 - 1:
-            self.buf.zero_()
-            self.step = 1
+        need = int(load().collie_shard_plan_workspace_bytes(B, K, self.world))
+        if need == 0:
+            raise _lib.CollieHipError('collie_shard_plan_workspace_bytes: bad sizes')
+        if self.buf is None or self.buf.numel() < need:
+            self.buf = torch.empty(need, dtype=torch.uint8, device=self.device)
         cu = torch.empty(B, dtype=torch.int32, device=dev)
         cp = torch.empty(B, dtype=torch.int32, device=dev)
         cn = torch.empty(B, K, dtype=torch.int64, device=dev)
@@ -601,25 +615,72 @@ class ShardPlanner:
         send_rows = torch.empty(cap, dtype=torch.int64, device=dev)
         counts = torch.empty(2 * self.world + 2, dtype=torch.int64, device=dev)
         check(load().collie_shard_plan(
-            byref(batch), self.num_users, self.num_items, self.world, self.step, ptr(self.buf),
+            byref(batch), self.num_users, self.num_items, self.world, self.dim, ptr(self.buf),
             self.buf.numel(), ptr(cu), ptr(cp), ptr(cn), ptr(send_rows), cap, ptr(counts),
             stream_ptr()), 'collie_shard_plan')
         return cu, cp, cn, send_rows, counts
 
 
-def shard_serve_rows(emb, bias, rows, status=None):
-    """Owner side of the lookup exchange: (emb[rows], bias[rows]) (``collie_shard_serve_rows``)."""
+def shard_serve_rows(emb, bias, rows, peer_counts, item_touch, item_base, step_id, status=None):
+    """Owner side of the lookup exchange: the requested rows as the peers' blocks of the lookup
+    buffer ``[rows, dim]`` (``collie_shard_serve_rows``); stamps the served item rows."""
     require_hip(emb, 'table')
-    m = rows.shape[0]
-    out_e = torch.empty(m, emb.shape[1], dtype=torch.float32, device=emb.device)
-    out_b = torch.empty(m, dtype=torch.float32, device=emb.device)
-    if m:
-        rows = rows.contiguous()
-        assert rows.dtype == torch.int64
-        check(load().collie_shard_serve_rows(ptr(emb), ptr(bias), emb.shape[0], emb.shape[1],
-                                             ptr(rows), m, ptr(out_e), ptr(out_b), ptr(status),
-                                             stream_ptr()), 'collie_shard_serve_rows')
-    return out_e, out_b
+    dim = emb.shape[1]
+    out_rows = shard_wire_rows(peer_counts, dim, False)
+    out = torch.empty(out_rows, dim, dtype=torch.float32, device=emb.device)
+    rows = rows.contiguous()
+    assert rows.dtype == torch.int64 and rows.shape[0] == sum(peer_counts)
+    check(load().collie_shard_serve_rows(
+        ptr(emb), ptr(bias), emb.shape[0], dim, ptr(rows), _i64_array(peer_counts),
+        len(peer_counts), ptr(out), out_rows, ptr(item_touch), item_base, step_id, ptr(status),
+        stream_ptr()), 'collie_shard_serve_rows')
+    return out
+
+
+def shard_unpack_bias(buf, peer_counts):
+    """Bias values of a received lookup buffer, indexed like its rows."""
+    out = torch.empty(buf.shape[0], dtype=torch.float32, device=buf.device)
+    check(load().collie_shard_unpack_bias(
+        ptr(buf), buf.shape[0], buf.shape[1], _i64_array(peer_counts), len(peer_counts), ptr(out),
+        stream_ptr()), 'collie_shard_unpack_bias')
+    return out
+
+
+def shard_export_grads(tables, batch, train_ws_buf, lookup_counts, send_rows, grad_scale, workspace):
+    """``collie_shard_export_grads``: (wire [rows, dim], peer_counts [world + 1] device int64,
+    workspace)."""
+    B, D, world = batch.batch, tables.dim, len(lookup_counts)
+    dev = train_ws_buf.device
+    wire_rows = 3 * B + 2 * ((3 * B + D - 1) // D + world)
+    wire = torch.empty(wire_rows, D, dtype=torch.float32, device=dev)
+    counts = torch.empty(world + 1, dtype=torch.int64, device=dev)
+    need = int(load().collie_shard_export_workspace_bytes(B))
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+    check(load().collie_shard_export_grads(
+        byref(tables), byref(batch), ptr(train_ws_buf), train_ws_buf.numel(), world,
+        _i64_array(lookup_counts), ptr(send_rows), ptr(grad_scale), ptr(wire), wire_rows,
+        ptr(counts), ptr(workspace), workspace.numel(), stream_ptr()), 'collie_shard_export_grads')
+    return wire, counts, workspace
+
+
+def shard_owner_update(emb, bias, item_base, wire, peer_counts, item_touch, row_seg, cfg, bias_cfg,
+                       state, bias_state, status=None, workspace=None):
+    """``collie_shard_owner_update``; returns the (possibly grown) workspace."""
+    require_hip(emb, 'table')
+    dim = emb.shape[1]
+    entries = int(sum(peer_counts))
+    wire_rows = wire.shape[0] if wire is not None else 0
+    need = int(load().collie_shard_owner_workspace_bytes(entries, wire_rows, dim))
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=emb.device)
+    check(load().collie_shard_owner_update(
+        ptr(emb), ptr(bias), emb.shape[0], dim, item_base, ptr(wire), wire_rows,
+        _i64_array(peer_counts), len(peer_counts), ptr(item_touch), ptr(row_seg), byref(cfg),
+        byref(bias_cfg), ptr(state[0]), ptr(state[1]), ptr(bias_state[0]), ptr(bias_state[1]),
+        ptr(workspace), workspace.numel(), ptr(status), stream_ptr()),
+        'collie_shard_owner_update')
+    return workspace
 
 
 # ---- evaluation -----------------------------------------------------------------------------------

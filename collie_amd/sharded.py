@@ -12,19 +12,27 @@ item rows in ONE combined table ``emb [U_loc + N_loc, D]`` (user rows first) wit
 gather and the owner-side optimizer step is one ``collie_sparse_rows_update`` call.
 
 Training step on a rank (``train_step``), for its slice of the global batch:
-  1. unique user ids and unique item ids of the slice (positives and all K negatives), ordered by
-     (owner, kind, id): that order IS the compact row numbering of the step;
-     (``collie_shard_plan``: stamp table + prefix sum, no sort);
-  2. all-to-all of the per-peer counts, then of the requested row numbers;
-  3. owners gather the rows; all-to-all of embedding rows and bias values back.  The requester now
-     holds compact tables ``[n, D]`` / ``[n]`` in its compact numbering;
-  4. the fused forward kernel (``collie_mf_train_forward``) runs on the compact tables and compact
-     ids; the segment kernels reduce the staged rows into ``[n, D]`` / ``[n]`` gradient buffers
-     (``collie_mf_train_update`` with SGD, lr = -1, on zero-filled buffers: ``0 + 1 * g``), scaled by
-     ``B_local / B_global`` so that the sum over ranks is the gradient of the global-batch loss;
-  5. all-to-all of the gradient rows back to the owners along the same routes (every looked-up row
-     travels, zero-gradient rows included: SparseAdam decays their moments, SURVEY.md §8a A8);
-  6. owners coalesce what the requesters sent (rank order, deterministic) and update their rows.
+  1. distinct user rows and item rows of the slice (positives and all K negatives), ordered by
+     (owner, kind, id): that order IS the compact row numbering of the step
+     (``collie_shard_plan``: one stable radix sort of the (2 + K) B ids);
+  2. all-to-all of the per-peer counts (the step's first host read: ``plan_ahead`` hides it behind
+     the previous step), then of the requested row numbers;
+  3. owners write the requested rows as the peers' blocks of ONE lookup buffer -- embedding rows,
+     then the bias values packed into rows of the same width (``collie_shard_serve_rows``, which
+     also stamps the served item rows) -- and one all-to-all with row splits brings them back: the
+     received buffer IS the requester's compact embedding table (compact numbers skip the bias
+     rows between two owners' blocks);
+  4. the fused forward kernel (``collie_mf_train_forward``) runs on the compact table and compact
+     ids; ``collie_shard_export_grads`` coalesces its staged gradient rows (users, positives and the
+     one negative per sample the loss selected: at most 3 of the 2 + K rows a sample looks up) and
+     writes them, scaled by ``B_local / B_global``, straight into the owners' blocks of the gradient
+     buffer (rows, bias gradients, owner row numbers);
+  5. all-to-all of the per-owner gradient counts (second host read), then ONE all-to-all of the
+     gradient buffer;
+  6. owners coalesce what the requesters sent (stable sort by row: rank order, deterministic) and
+     update: rows with an entry get their summed gradient, and -- SparseAdam -- every item row
+     stamped in step 3 without an entry has its moments decayed (looked-up
+     rows are touched even with a zero gradient) (``collie_shard_owner_update``).
 There is no float atomic and every row has exactly one writer.  The loss returned is the
 global-batch loss: all-reduce of ``loss_local * B_local / B_global``.
 
@@ -34,8 +42,8 @@ ids, the scores of the positives it owns and the rank counters over its rows; an
 G x k candidates per user followed by ``collie_mf_eval_merge_topk``, and two sum all-reduces
 (positive scores: exact, every other rank contributes 0.0; integer counters) finish the metrics.
 
-The index plumbing (``torch.unique``, stable ``argsort``, ``index_select``) and the collectives
-are torch calls; all floating-point arithmetic is in the HIP library through ``HipEngine``.  The
+The collectives are torch calls; the planning, packing and all floating-point arithmetic are in
+the HIP library through ``HipEngine``.  The
 engine is a constructor argument only so that the world_size-2 ``gloo`` tests can drive the same
 exchange code on CPU tensors with the oracle as the arithmetic (tests/sharded_cpu_engine.py);
 the product never imports the oracle and ``HipEngine`` refuses CPU tensors.
@@ -101,75 +109,69 @@ class HipEngine:
             raise _lib.CollieHipError('HipEngine computes on a HIP device only (no CPU fallback)')
         _lib.load()
         self._train_ws = ops.TrainWorkspace(self.device)
-        self._rows_ws = None
+        self._export_ws = None
+        self._owner_ws = None
         self._eval_ws = ops.EvalWorkspace(self.device)
         self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
-        self._acc = ops.optim_cfg('sgd', 1, -1.0)
         self._planner = None
-        self.gradient_row_mask = None
+        self._touch = None          # owner-side stamps of one model (this engine serves one model)
+        self._row_seg = None
 
     # requester-side plan of one step (collie_shard_plan)
     def plan(self, model, users, pos_items, neg_items):
         if self._planner is None:
-            self._planner = ops.ShardPlanner(model.hparams['num_users'], model.hparams['num_items'],
-                                             model.comm.world, self.device)
+            hp = model.hparams
+            self._planner = ops.ShardPlanner(hp['num_users'], hp['num_items'], model.comm.world,
+                                             hp['embedding_dim'], self.device)
         return self._planner.plan(users, pos_items, neg_items)
 
-    # owner side of the lookup exchange: (emb[rows], bias[rows]) in one launch
-    def serve_rows(self, emb, bias, rows):
-        return ops.shard_serve_rows(emb, bias, rows, self._status)
+    def _owner_state(self, model):
+        if self._touch is None:
+            self._touch = torch.zeros(max(model.N_loc, 1), dtype=torch.uint8, device=self.device)
+            self._row_seg = torch.zeros(model.emb.shape[0], dtype=torch.int32, device=self.device)
+        return self._touch, self._row_seg
 
-    # compact tables + compact ids -> (loss[1], grad rows [n, D], grad bias [n]), both * scale
-    def train_grads(self, cemb, cbias, cu, cp, cn, kind, num_items, codes, weights, scale):
-        n, D = cemb.shape
+    # owner side of the lookup exchange: the peers' blocks of the lookup buffer in one launch
+    def serve(self, model, rows, peer_counts, step):
+        touch, _ = self._owner_state(model)
+        return ops.shard_serve_rows(model.emb, model.bias, rows, peer_counts, touch, model.U_loc,
+                                    step, self._status)
+
+    # received lookup buffer + compact ids -> (loss[1], gradient wire buffer, per-owner counts)
+    def forward_export(self, model, cw, lookup_counts, send_rows, cu, cp, cn, kind, num_items, codes,
+                       weights, scale):
+        R, D = cw.shape
         B, K = cn.shape
-        cb = cbias.view(n, 1)
-        tables = _lib.make_tables(cemb, cemb, cb, cb)       # one table, two id ranges
+        cbias = ops.shard_unpack_bias(cw, lookup_counts).view(R, 1)
+        tables = _lib.make_tables(cw, cw, cbias, cbias)     # one table, two id ranges
         batch = ops.make_batch(cu, cp, cn)
-        buf = self._train_ws.ensure(B, K, D, n, n)
+        buf = self._train_ws.ensure(B, K, D, R, R)
         step_id = self._train_ws.next_step()
         cfg = ops.make_loss_cfg(kind, num_items, codes, weights)
         loss = torch.empty(1, dtype=torch.float32, device=self.device)
-        ops.train_forward(tables, batch, cfg, buf, True, step_id, loss, None, None, self._status)
+        ops.train_forward(tables, batch, cfg, buf, 1 | ops.NO_STAMPS, step_id, loss, None, None,
+                          self._status)
         mark = getattr(self, 'phase_mark', None)
         if mark is not None:
-            mark('segment_reduce')      # everything before this mark is K1 (+ its loss finalize)
-        ops.train_build_segments(tables, batch, buf)
-        gemb = torch.zeros(n, D, dtype=torch.float32, device=self.device)
-        gbias = torch.zeros(n, dtype=torch.float32, device=self.device)
-        gb = gbias.view(n, 1)
-        gt = _lib.make_tables(gemb, gemb, gb, gb)
-        both = {_lib.SIDE_USER: (self._acc, None, None, None),
-                _lib.SIDE_ITEM: (self._acc, None, None, None)}
-        ops.train_update(gt, batch, buf, False, False, step_id, both, scale)
-        ops.train_update(gt, batch, buf, True, False, step_id, both, scale)
-        # rows that own gradient entries: what the compressed gradient exchange sends home
-        self.gradient_row_mask = torch.zeros(n, dtype=torch.uint8, device=self.device)
-        ops.train_gradient_rows(tables, batch, buf, self.gradient_row_mask, self.gradient_row_mask)
-        return loss, gemb, gbias
+            mark('gradient_export')     # everything before this mark is K1 (+ its loss finalize)
+        wire, counts, self._export_ws = ops.shard_export_grads(
+            tables, batch, buf, lookup_counts, send_rows, scale, self._export_ws)
+        return loss, wire, counts
 
-    # optimizer.step() of one combined shard table on an uncoalesced COO gradient
-    def rows_update(self, table, rows, vals, algo, step, lr, state, hyper):
-        cfg = ops.optim_cfg(algo, step, lr, hyper.get('beta1', 0.9), hyper.get('beta2', 0.999),
-                            hyper['eps'], 0.0, hyper.get('lr_decay', 0.0))
-        s1 = state.get('exp_avg', state.get('sum'))
-        s2 = state.get('exp_avg_sq')
-        self._rows_ws = ops.sparse_rows_update(table, rows, vals, cfg, s1, s2, self._status,
-                                               self._rows_ws)
-
-    def rows_update_pair(self, emb, bias, rows, gemb, gbias, algos, step, lrs, states, hypers,
-                         val_index=None):
-        """Embedding rows and their bias rows share the row list: one coalesce, two updates.
-        val_index: row of gemb / gbias that belongs to each entry of ``rows`` (-1: zero gradient)."""
-        if val_index is not None and gemb.shape[0] == 0:
-            gemb = torch.zeros(1, emb.shape[1], dtype=torch.float32, device=emb.device)
-            gbias = torch.zeros(1, dtype=torch.float32, device=emb.device)
-        cfgs = [ops.optim_cfg(a, step, lr, h.get('beta1', 0.9), h.get('beta2', 0.999), h['eps'], 0.0,
-                              h.get('lr_decay', 0.0)) for a, lr, h in zip(algos, lrs, hypers)]
-        st = [(s.get('exp_avg', s.get('sum')), s.get('exp_avg_sq')) for s in states]
-        self._rows_ws = ops.sparse_rows_update_pair(emb, bias, rows, gemb, gbias, cfgs[0], cfgs[1],
-                                                    st[0], st[1], self._status, self._rows_ws,
-                                                    val_index=val_index)
+    # optimizer.step() of the combined shard table on the gradient blocks the peers sent
+    def owner_update(self, model, wire, peer_counts, step):
+        hp = model.hparams
+        touch, row_seg = self._owner_state(model)
+        cfgs = []
+        for algo, lr in ((hp['optimizer'], hp['lr']), (hp['bias_optimizer'], hp['bias_lr'])):
+            h = model._HYPER[algo]
+            cfgs.append(ops.optim_cfg(algo, step, lr, h.get('beta1', 0.9), h.get('beta2', 0.999),
+                                      h['eps'], 0.0, h.get('lr_decay', 0.0)))
+        st = [(s_.get('exp_avg', s_.get('sum')), s_.get('exp_avg_sq'))
+              for s_ in (model.state['emb'], model.state['bias'])]
+        self._owner_ws = ops.shard_owner_update(model.emb, model.bias, model.U_loc, wire,
+                                                peer_counts, touch, row_seg, cfgs[0], cfgs[1],
+                                                st[0], st[1], self._status, self._owner_ws)
 
     # ---- catalog-sharded evaluation --------------------------------------------------------------
     def _eval_tables(self, utile, ubias, iemb, ibias):
@@ -247,11 +249,10 @@ class _Comm:
 
     def all_to_all(self, inp, in_splits, out_splits):
         """Rows of ``inp`` split by ``in_splits`` go to the peers; returns the rows received."""
+        if self.world == 1:         # nothing travels: the "received" buffer is the one sent
+            return inp
         shape = (int(sum(out_splits)),) + tuple(inp.shape[1:])
         out = torch.empty(shape, dtype=inp.dtype, device=inp.device)
-        if self.world == 1:
-            out.copy_(inp)
-            return out
         if self.staged and inp.is_cuda:
             host = torch.empty(shape, dtype=inp.dtype)
             dist.all_to_all_single(host, inp.cpu().contiguous(), list(out_splits), list(in_splits),
@@ -299,7 +300,14 @@ def shard_batch(batch, rank, world):
     return (users[lo:hi], pos[lo:hi]), neg[lo:hi]
 
 
-def plan_torch(users, pos_items, neg_items, U, N, G):
+def wire_rows(count, dim, gradient=False):
+    """Rows of one peer's block of an exchange buffer (csrc/shard_wire.h): ``count`` embedding (or
+    gradient) rows, ``ceil(count / dim)`` rows of bias values and, in the gradient direction, as
+    many rows again of owner row numbers."""
+    return count + (2 if gradient else 1) * ((count + dim - 1) // dim)
+
+
+def plan_torch(users, pos_items, neg_items, U, N, G, dim):
     """
     Step 1 of the module docstring with torch index ops (any device; what the gloo tests run).
     Same outputs, bit for bit, as ``collie_shard_plan`` (``HipEngine.plan``).
@@ -310,7 +318,12 @@ def plan_torch(users, pos_items, neg_items, U, N, G):
     ui, inv_i = torch.unique(torch.cat([pos_items.long(), neg_items.long().reshape(-1)]),
                              return_inverse=True)
     bad = (uu[0] < 0) | (uu[-1] >= U) | (ui[0] < 0) | (ui[-1] >= N)
+    # an id outside the tables stands for the nearest valid row (and is reported): merge it with
+    # that row if the batch also holds it
     uu, ui = uu.clamp(0, U - 1), ui.clamp(0, N - 1)
+    uu, inv_uu = torch.unique(uu, return_inverse=True)
+    ui, inv_ii = torch.unique(ui, return_inverse=True)
+    inv_u, inv_i = inv_uu[inv_u], inv_ii[inv_i]
     nu = uu.shape[0]
     n = nu + ui.shape[0]
     ids = torch.cat([uu, ui])
@@ -319,14 +332,19 @@ def plan_torch(users, pos_items, neg_items, U, N, G):
     owner = ids % G
     route = owner * 2 + kind                     # ids ascend inside a route
     order = torch.argsort(route, stable=True)
-    compact = torch.empty(n, dtype=torch.int64, device=dev)
-    compact[order] = torch.arange(n, dtype=torch.int64, device=dev)
+    seg = torch.empty(n, dtype=torch.int64, device=dev)
+    seg[order] = torch.arange(n, dtype=torch.int64, device=dev)
     u_loc = (U - owner + G - 1) // G             # the owner's user rows come first
     send_rows = (ids // G + kind * u_loc)[order]
     counts = torch.zeros(2 * G + 2, dtype=torch.int64, device=dev)
     counts[:2 * G] = torch.bincount(route, minlength=2 * G)
     counts[2 * G] = n
     counts[2 * G + 1] = bad.to(torch.int64)
+    # compact row = row of the lookup buffer: skip the bias rows of the owners before this one
+    per_owner = counts[:2 * G].reshape(G, 2).sum(1)
+    pad = (per_owner + dim - 1) // dim
+    shift = torch.cumsum(pad, 0) - pad
+    compact = seg + shift[owner]
     cu = compact[inv_u].to(torch.int32)
     ci = compact[nu + inv_i]
     return (cu, ci[:B].to(torch.int32), ci[B:].reshape(B, K).contiguous(), send_rows, counts)
@@ -398,10 +416,6 @@ class ShardedMatrixFactorizationModel:
         self._codes, self._weights = loss_mod.metadata_to_codes(
             metadata_for_loss, metadata_for_loss_weights, dev)
         self.last_exchange = {}
-        # send home only the gradient rows that are not zero (see _send_nonzero_gradients); with one
-        # rank nothing travels, so the dense hand-over stays
-        self.compress_gradients = self.comm.world > 1
-        self.last_gradient_rows = None
         self._ahead = None          # (batch tensors, plan, ready event) of plan_ahead()
         self._plan_stream = None
 
@@ -574,26 +588,26 @@ class ShardedMatrixFactorizationModel:
         else:
             cu, cp, cn, send_rows, counts = plan_torch(
                 users, pos_items, neg_items, self.hparams['num_users'],
-                self.hparams['num_items'], G)
+                self.hparams['num_items'], G, self.hparams['embedding_dim'])
         # one small all-to-all: [users, items, B_local, id range flag] per peer
         meta = torch.empty(G, 4, dtype=torch.int64, device=dev)
         meta[:, :2] = counts[:2 * G].reshape(G, 2)
         meta[:, 2] = B
         meta[:, 3] = counts[2 * G + 1]
         got = comm.all_to_all(meta, [1] * G, [1] * G)
-        # The split sizes of the row exchanges must be known to the host: the one read-back of the
-        # step.  With plan_ahead() it happens on a side stream while the previous step computes.
+        # The split sizes of the row exchanges must be known to the host: the first read-back of
+        # the step.  With plan_ahead() it happens on a side stream while the previous step computes.
         meta_h, got_h = torch.stack([meta, got]).cpu().tolist()
         if any(row[3] for row in got_h):
             raise IndexError('index out of range in self: a user or item id is outside the tables')
-        send_splits = [r[0] + r[1] for r in meta_h]
-        recv_splits = [r[0] + r[1] for r in got_h]
-        n = sum(send_splits)
+        send_counts = [r[0] + r[1] for r in meta_h]      # rows this rank requests from each peer
+        recv_counts = [r[0] + r[1] for r in got_h]       # rows each peer requests from this rank
+        n = sum(send_counts)
         B_global = sum(r[2] for r in got_h)
         # rows of the owner's combined table (user rows first, item rows behind them)
-        crow = comm.all_to_all(send_rows[:n], send_splits, recv_splits)
-        return dict(n=n, B=B, K=K, B_global=B_global, crow=crow, send_splits=send_splits,
-                    recv_splits=recv_splits, cu=cu, cp=cp, cn=cn)
+        crow = comm.all_to_all(send_rows[:n], send_counts, recv_counts)
+        return dict(n=n, B=B, K=K, B_global=B_global, crow=crow, send_counts=send_counts,
+                    recv_counts=recv_counts, cu=cu, cp=cp, cn=cn, send_rows=send_rows)
 
     def plan_ahead(self, batch) -> None:
         """
@@ -623,7 +637,7 @@ class ShardedMatrixFactorizationModel:
             p = self._plan(users, pos_items, neg_items)
             ready = torch.cuda.Event()
             ready.record(side)
-        for t in (p['crow'], p['cu'], p['cp'], p['cn']):
+        for t in (p['crow'], p['cu'], p['cp'], p['cn'], p['send_rows']):
             t.record_stream(main)       # allocated on the side stream, consumed on the main one
         self._ahead = ((users, pos_items, neg_items), p, ready)
 
@@ -651,109 +665,49 @@ class ShardedMatrixFactorizationModel:
         if neg_items.dim() == 1:
             neg_items = neg_items.reshape(-1, 1)
         comm, eng, dev = self.comm, self.engine, self.device
+        G = comm.world
         D = self.hparams['embedding_dim']
         mark = self._phase_mark
         mark('plan')
         p = self._take_plan(users, pos_items, neg_items)
-        n, crow = p['n'], p['crow']
-        # 3. owners serve the rows
+        step = self.steps + 1
+        # 3. owners serve the rows: one buffer, one all-to-all
         mark('lookup_exchange')
-        serve = getattr(eng, 'serve_rows', None)
-        if serve is not None:
-            served_e, served_b = serve(self.emb, self.bias, crow)
-        else:
-            served_e, served_b = self.emb.index_select(0, crow), self.bias.index_select(0, crow)
-        cemb = comm.all_to_all(served_e, p['recv_splits'], p['send_splits'])
-        cbias = comm.all_to_all(served_b, p['recv_splits'], p['send_splits'])
-        # 4. fused forward + segment reduce on the compact tables
-        mark('forward_backward')
+        served = eng.serve(self, p['crow'], p['recv_counts'], step)
+        cw = comm.all_to_all(served, [wire_rows(c, D) for c in p['recv_counts']],
+                             [wire_rows(c, D) for c in p['send_counts']])
+        # 4. fused forward on the compact table + gradient rows into the owners' blocks
+        mark('forward')
         codes = []
         for c in self._codes or []:          # category codes of the compact rows (items only)
-            cc = torch.zeros(n, dtype=torch.int32, device=dev)
+            cc = torch.zeros(cw.shape[0], dtype=torch.int32, device=dev)
             cc[p['cp'].long()] = c[pos_items.long()]
             cc[p['cn'].reshape(-1).long()] = c[neg_items.reshape(-1).long()]
             codes.append(cc)
         scale = torch.full((1,), p['B'] / p['B_global'], dtype=torch.float32, device=dev)
-        loss, gemb, gbias = eng.train_grads(cemb, cbias, p['cu'], p['cp'], p['cn'],
-                                            self._loss_kind, self.hparams['num_items'], codes,
-                                            self._weights, scale)
-        # 5. gradients home
+        loss, gwire, gcounts = eng.forward_export(
+            self, cw, p['send_counts'], p['send_rows'], p['cu'], p['cp'], p['cn'], self._loss_kind,
+            self.hparams['num_items'], codes, self._weights, scale)
+        # 5. gradients home: how many rows each owner gets depends on the forward pass (which
+        # negative each sample selected), so the counts are exchanged and read back first
         mark('gradient_exchange')
-        val_index = None
-        if self.compress_gradients:
-            grows, gb, val_index = self._send_nonzero_gradients(p, gemb, gbias, crow)
-        else:
-            grows = comm.all_to_all(gemb, p['send_splits'], p['recv_splits'])
-            gb = comm.all_to_all(gbias, p['send_splits'], p['recv_splits'])
-        # 6. owners update
-        mark('owner_update')
-        self.steps += 1
-        hp = self.hparams
-        pair = hasattr(eng, 'rows_update_pair') and D >= 2
-        if val_index is not None and not pair:
-            # engines without the indexed update: the received rows back in request order
-            full = torch.zeros(crow.shape[0], D, dtype=torch.float32, device=dev)
-            fullb = torch.zeros(crow.shape[0], dtype=torch.float32, device=dev)
-            at = torch.nonzero(val_index >= 0).reshape(-1)
-            full[at] = grows[val_index[at].long()]
-            fullb[at] = gb[val_index[at].long()]
-            grows, gb, val_index = full, fullb, None
-        if crow.shape[0] > 0 and pair:
-            eng.rows_update_pair(self.emb, self.bias, crow, grows, gb,
-                                 (hp['optimizer'], hp['bias_optimizer']), self.steps,
-                                 (hp['lr'], hp['bias_lr']), (self.state['emb'], self.state['bias']),
-                                 (self._HYPER[hp['optimizer']], self._HYPER[hp['bias_optimizer']]),
-                                 val_index=val_index)
-        elif crow.shape[0] > 0:
-            eng.rows_update(self.emb, crow, grows, hp['optimizer'], self.steps, hp['lr'],
-                            self.state['emb'], self._HYPER[hp['optimizer']])
-            eng.rows_update(self.bias, crow, gb, hp['bias_optimizer'], self.steps, hp['bias_lr'],
-                            self.state['bias'], self._HYPER[hp['bias_optimizer']])
-        total = comm.all_reduce(loss * scale)
-        mark(None)
-        self.last_exchange = dict(rows_requested=n, rows_served=int(crow.shape[0]),
-                                  bytes_each_way=n * (D + 1) * 4)
-        return total.reshape(())
-
-    def _send_nonzero_gradients(self, p, gemb, gbias, crow):
-        """
-        Step 5 with only the gradient rows that are not zero on the wire.  Every loss gives at most
-        one negative of a sample a gradient, so of the (2 + K) rows a sample looks up only three
-        can carry one: with K = 10 three quarters of the dense exchange would be zeros.  The owner
-        already knows which rows were looked up (the request lists of step 2: those are the rows
-        SparseAdam must touch), so a requester sends, per owner, the positions inside its request
-        list whose gradient is not zero, and those rows.  Costs one more count exchange and host
-        read-back per step.  Returns (rows [mv, D], bias values [mv], val_index [len(crow)] int32:
-        the received row of every served row, -1 = zero gradient).
-        """
-        comm, G, dev = self.comm, self.comm.world, gemb.device
-        n = gemb.shape[0]
-        mask = getattr(self.engine, 'gradient_row_mask', None)
-        if mask is not None:        # rows with gradient entries (a superset of the non-zero rows)
-            nz = mask.bool()
-        else:
-            nz = (gemb != 0).any(dim=1) | (gbias != 0)
-        bounds = torch.tensor([0] + list(_cumsum(p['send_splits'])), dtype=torch.int64, device=dev)
-        csum = torch.zeros(n + 1, dtype=torch.int64, device=dev)
-        torch.cumsum(nz, 0, out=csum[1:])
-        cnt_send = csum[bounds[1:]] - csum[bounds[:-1]]
+        cnt_send = gcounts[:G]
         cnt_recv = comm.all_to_all(cnt_send, [1] * G, [1] * G)
         send_c, recv_c = torch.stack([cnt_send, cnt_recv]).cpu().tolist()
-        idx = torch.nonzero(nz).reshape(-1)               # ascending = grouped by owner
-        owner = torch.bucketize(idx, bounds[1:], right=True)
-        pos = idx - bounds[owner]                         # position inside that owner's request list
-        rpos = comm.all_to_all(pos, send_c, recv_c)
-        grows = comm.all_to_all(gemb.index_select(0, idx), send_c, recv_c)
-        gb = comm.all_to_all(gbias.index_select(0, idx), send_c, recv_c)
-        # served row of every received gradient row: offset of the peer's request list + position
-        roff = torch.tensor([0] + list(_cumsum(p['recv_splits']))[:-1], dtype=torch.int64, device=dev)
-        peer = torch.repeat_interleave(torch.arange(G, device=dev),
-                                       torch.tensor(recv_c, dtype=torch.int64, device=dev))
-        served = roff[peer] + rpos
-        val_index = torch.full((crow.shape[0],), -1, dtype=torch.int32, device=dev)
-        val_index[served] = torch.arange(served.shape[0], dtype=torch.int32, device=dev)
-        self.last_gradient_rows = int(idx.shape[0])
-        return grows, gb, val_index
+        gsplit_send = [wire_rows(c, D, True) for c in send_c]
+        gsplit_recv = [wire_rows(c, D, True) for c in recv_c]
+        grecv = comm.all_to_all(gwire[:sum(gsplit_send)], gsplit_send, gsplit_recv)
+        # 6. owners update
+        mark('owner_update')
+        eng.owner_update(self, grecv, recv_c, step)
+        self.steps = step
+        total = comm.all_reduce(loss * scale)
+        mark(None)
+        self.last_exchange = dict(rows_requested=p['n'], rows_served=int(p['crow'].shape[0]),
+                                  gradient_rows_sent=int(sum(send_c)),
+                                  bytes_in=int(cw.shape[0]) * D * 4,
+                                  bytes_out=int(sum(gsplit_send)) * D * 4)
+        return total.reshape(())
 
     # ---- evaluation --------------------------------------------------------------------------------
     def _user_tile(self, uids):

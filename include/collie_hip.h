@@ -262,6 +262,12 @@ int collie_mf_train_step(const collie_mf_tables* t, const collie_mf_batch* b,
  * and loss_out (+ the non-finite bit of *status) is written by the collie_mf_train_advance_step that
  * ends the step: one launch less in a replayed step, where every launch costs more than the work. */
 #define COLLIE_DEFER_LOSS 2
+/* need_grad | COLLIE_NO_STAMPS: the forward does not stamp the looked-up items in the workspace.
+ * For callers that do not run the library's SparseAdam "looked up, zero gradient" pass on these
+ * tables: the row-sharded step computes on per-step compact tables and its OWNERS stamp the rows
+ * they serve (collie_shard_serve_rows).  collie_mf_train_update with SPARSE_ADAM on the item side
+ * must not follow such a forward. */
+#define COLLIE_NO_STAMPS 4
 /* Copies one batch (collie_mf_batch: any strides, int32 / int64 ids) into another of the same shape:
  * the batch of the step into the buffers a captured step was recorded on, in ONE launch.  The
  * loaders of the reference hand out fresh tensors per batch (collie/interactions/dataloaders.py). */
@@ -356,37 +362,111 @@ int collie_sparse_rows_update_pair_indexed(float* table, float* bias_table, int6
                                            collie_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
- * Row-sharded training, requester side (no counterpart in the reference, which has no multi-GPU
- * path for the tables: SURVEY.md 8e).  Replaces, for one rank's batch
- * ((users, pos_items), neg_items) (base_pipeline.py:603-613), the host-side de-duplication a
- * sharded nn.Embedding lookup would need: finds the distinct user / item rows the batch looks up,
- * numbers them in (owner = id mod world, kind = user|item, id) order -- the order in which they are
- * requested from and returned by the owners -- and rewrites the batch in those compact numbers.
+ * Row-sharded training (no counterpart in the reference, which has no multi-GPU path for the
+ * tables: SURVEY.md 8e).  One step on a rank, in call order:
+ *   collie_shard_plan          requester: distinct rows of the batch, compact numbering
+ *   collie_shard_serve_rows    owner: the requested rows as the peers' blocks of the lookup buffer
+ *   collie_shard_unpack_bias   requester: bias values of the received buffer, indexed like its rows
+ *   collie_mf_train_forward    requester: fused forward on the compact tables (COLLIE_NO_STAMPS)
+ *   collie_shard_export_grads  requester: coalesced gradient rows as the owners' blocks
+ *   collie_shard_owner_update  owner: coalesce over the requesters, SparseAdam / Adagrad / SGD
+ *
+ * Exchange buffers ("wire" buffers): matrices of dim-float rows.  The block of one peer holds its
+ * c embedding (or gradient) rows, then ceil(c / dim) rows that carry the c bias values and -- in
+ * the gradient direction -- as many rows again with the c owner-side row numbers (int32 bits): ONE
+ * all-to-all with row splits moves everything.  collie_shard_wire_rows(counts [world], world, dim,
+ * gradient) = rows of a buffer whose blocks hold counts[p] entries (-1: bad arguments).
+ *
+ * collie_shard_plan replaces, for one rank's batch ((users, pos_items), neg_items)
+ * (base_pipeline.py:603-613), the host-side de-duplication a sharded nn.Embedding lookup would
+ * need: finds the distinct user / item rows the batch looks up (stable radix sort of the (2 + K) B
+ * ids: the cost is proportional to the lookups, not to the tables), orders them by (owner = id mod
+ * world, kind = user|item, id) -- the order in which they are requested from and returned by the
+ * owners -- and rewrites the batch in compact row numbers = rows of the lookup buffer the owners will
+ * fill (so the numbers skip the bias rows between two owners' blocks).
  *   compact_users [B] int32, compact_pos [B] int32, compact_neg [B, K] int64 (row major):
  *                  compact row numbers, in the id dtypes the loaders use (so that the forward
  *                  kernel takes the same route as on one GPU)
  *   send_rows [n]: row to request, as a row of the owner's combined table (its user rows first,
- *                  then its item rows); send_capacity >= min((2+K)B, num_users+num_items)
+ *                  then its item rows), dense (no gaps); send_capacity >= min((2+K)B, users+items)
  *   route_counts [2*world + 2] int64: rows per (owner, kind) route; [2*world] = n;
- *                  [2*world + 1] = 1 if an id was outside the tables (such ids are skipped)
- * workspace: collie_shard_plan_workspace_bytes() bytes, zero-filled at creation, private to one
- * model; step_id >= 1 must increase by one per call.  world <= 16.
+ *                  [2*world + 1] = 1 if an id was outside the tables (it then stands for the
+ *                  nearest valid row; the caller raises)
+ * workspace: collie_shard_plan_workspace_bytes(batch, num_neg, world) bytes (need not be zeroed).
+ * world <= 16.
  * ------------------------------------------------------------------------------------------- */
-size_t collie_shard_plan_workspace_bytes(int64_t num_users, int64_t num_items, int32_t world);
+int64_t collie_shard_wire_rows(const int64_t* counts, int32_t world, int32_t dim, int32_t gradient);
+size_t collie_shard_plan_workspace_bytes(int64_t batch, int32_t num_neg, int32_t world);
 int collie_shard_plan(const collie_mf_batch* b, int64_t num_users, int64_t num_items,
-                      int32_t world, int32_t step_id, void* workspace, size_t workspace_bytes,
+                      int32_t world, int32_t dim, void* workspace, size_t workspace_bytes,
                       int32_t* compact_users, int32_t* compact_pos, int64_t* compact_neg,
                       int64_t* send_rows, int64_t send_capacity, int64_t* route_counts,
                       collie_stream_t stream);
 
-/* Row-sharded training, owner side of the lookup exchange (no counterpart in the reference): the
- * rows a peer requested out of this rank's combined table -- the nn.Embedding lookups of
- * matrix_factorization.py:143-150 executed where the rows live: out_emb [m, dim] = emb[rows, :],
- * out_bias [m] = bias[rows].  rows [m] int64 (rows of the combined table, as collie_shard_plan
- * numbers them); a row outside [0, num_rows) reads as zeros and sets bit 0 of *status. */
+/* Owner side of the lookup exchange: the rows the peers requested out of this rank's combined
+ * table -- the nn.Embedding lookups of matrix_factorization.py:143-150 executed where the rows
+ * live -- written as the peers' blocks of the lookup buffer `out` [out_rows, dim].  rows: int64,
+ * the peers' request lists back to back (peer_counts [world] entries each, host array; rows of the
+ * combined table as collie_shard_plan numbers them); a row outside [0, num_rows) reads as zeros
+ * and sets bit 0 of *status.
+ * item_touch (optional): uint8 [num_rows - item_base], zero-filled at creation, owned by the
+ * model: every served row >= item_base (the item rows of the combined table) is stamped "looked up
+ * in step_id" (one byte, cycle of 255 steps: cleared by this call when step_id % 255 == 0; call it
+ * once per step with step_id = the optimizers' step of that training step, also with no rows).
+ * collie_shard_owner_update finds the looked-up rows that received no gradient through these stamps. */
 int collie_shard_serve_rows(const float* emb, const float* bias, int64_t num_rows, int32_t dim,
-                            const int64_t* rows, int64_t m, float* out_emb, float* out_bias,
-                            int32_t* status, collie_stream_t stream);
+                            const int64_t* rows, const int64_t* peer_counts, int32_t world,
+                            float* out, int64_t out_rows, uint8_t* item_touch, int64_t item_base,
+                            int32_t step_id, int32_t* status, collie_stream_t stream);
+
+/* Requester: bias_out[r] = the bias value of row r of the received lookup buffer `buf`
+ * [buf_rows, dim] (peer_counts [world]: rows requested from each peer, host array); bias_out
+ * [buf_rows] is written at embedding rows only. */
+int collie_shard_unpack_bias(const float* buf, int64_t buf_rows, int32_t dim,
+                             const int64_t* peer_counts, int32_t world, float* bias_out,
+                             collie_stream_t stream);
+
+/* Requester, after collie_mf_train_forward(need_grad = 1 | COLLIE_NO_STAMPS) on the compact
+ * tables (t: user_emb == item_emb == the lookup buffer, user_bias == item_bias == the unpacked
+ * biases, num_users == num_items >= its rows; b: the batch in compact numbers; train_workspace:
+ * that forward's workspace): the backward pass of base_pipeline.py:613-634 as the sparse gradient
+ * nn.Embedding(sparse=True) would hold after coalesce() -- one row per distinct user, positive item
+ * and selected negative, duplicates summed in batch order, times *grad_scale (B_local / B_global;
+ * NULL = 1) -- written as the OWNERS' blocks of the gradient wire buffer (rows, bias gradients, and
+ * the rows of the owners' tables they belong to: send_rows of collie_shard_plan).
+ *   lookup_counts [world] (host): rows requested from each peer
+ *   wire [wire_rows, dim], wire_rows >= 3B + 2 (ceil(3B / dim) + world)
+ *   peer_counts [world + 1] int64 (DEVICE, out): gradient rows per owner; [world] = rows of `wire`
+ *                  in use.  The caller exchanges the counts and reads them back: the row splits of
+ *                  the gradient all-to-all are collie_shard_wire_rows of one count each.
+ * workspace: collie_shard_export_workspace_bytes(batch). */
+size_t collie_shard_export_workspace_bytes(int64_t batch);
+int collie_shard_export_grads(const collie_mf_tables* t, const collie_mf_batch* b,
+                              void* train_workspace, size_t train_workspace_bytes, int32_t world,
+                              const int64_t* lookup_counts, const int64_t* send_rows,
+                              const float* grad_scale, float* wire, int64_t wire_rows,
+                              int64_t* peer_counts, void* workspace, size_t workspace_bytes,
+                              collie_stream_t stream);
+
+/* Owner: optimizer.step() of the combined table and its bias table on the gradient blocks received
+ * from the peers (torch/optim/_functional.py:41-84 SparseAdam; adagrad.py:361-385; sgd): the
+ * blocks are coalesced in peer order (stable sort by row: the sum over the requesters is formed
+ * in rank order, bit-reproducible), every row with an entry is updated, and -- SparseAdam -- every
+ * item row that collie_shard_serve_rows stamped in this step but that received no entry has its
+ * moments decayed and its parameter moved (the "looked up, zero gradient" rows).
+ *   wire [wire_rows, dim]: the received buffer; peer_counts [world] (host): entries per peer
+ *   row_seg: int32 [num_rows], zero-filled at creation, owned by the model
+ *   cfg / bias_cfg: same step; state1 / state2 as collie_sparse_rows_update
+ * workspace: collie_shard_owner_workspace_bytes(entries, wire_rows, dim).  Call it every step, also
+ * with no entries. */
+size_t collie_shard_owner_workspace_bytes(int64_t entries, int64_t wire_rows, int32_t dim);
+int collie_shard_owner_update(float* emb, float* bias, int64_t num_rows, int32_t dim,
+                              int64_t item_base, const float* wire, int64_t wire_rows,
+                              const int64_t* peer_counts, int32_t world, const uint8_t* item_touch,
+                              int32_t* row_seg, const collie_optim_cfg* cfg,
+                              const collie_optim_cfg* bias_cfg, float* state1, float* state2,
+                              float* bias_state1, float* bias_state2, void* workspace,
+                              size_t workspace_bytes, int32_t* status, collie_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * A13-A17  get_preds + mapk / mrr / auc   collie/metrics.py:77-107,144-282

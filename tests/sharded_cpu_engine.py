@@ -1,7 +1,8 @@
 """
 TEST INFRASTRUCTURE: a stand-in for ``collie_amd.sharded.HipEngine`` whose arithmetic is the CPU
 oracle (``oracle/mf_oracle.py``), so that the world_size-2 ``gloo`` tests can drive the product's
-exchange code (unique / route / all-to-all / owner update / candidate merge) without a GPU.
+exchange code (plan / all-to-all of the packed buffers / candidate merge) without a GPU, in the
+product's buffer layout.
 Never imported by ``collie_amd``.
 """
 import numpy as np
@@ -20,30 +21,116 @@ class CpuOracleEngine:
     name = 'oracle'
 
     # ---- training -------------------------------------------------------------------------------
-    def train_grads(self, cemb, cbias, cu, cp, cn, kind, num_items, codes, weights, scale):
-        n, D = cemb.shape
-        tables = {'user_embeddings': _np(cemb), 'item_embeddings': _np(cemb),
-                  'user_biases': _np(cbias).reshape(n, 1), 'item_biases': _np(cbias).reshape(n, 1)}
+    # The exchange buffers have the product's layout (csrc/shard_wire.h): per peer, c rows, then
+    # ceil(c / D) rows of bias values, then (gradient direction) as many rows of int32 row numbers.
+    @staticmethod
+    def _blocks(counts, D, extra):
+        first, row0 = [0], [0]
+        for c in counts:
+            first.append(first[-1] + c)
+            row0.append(row0[-1] + c + extra * ((c + D - 1) // D))
+        return first, row0
+
+    def serve(self, model, rows, peer_counts, step):
+        emb, bias = _np(model.emb), _np(model.bias)
+        D = emb.shape[1]
+        first, row0 = self._blocks(peer_counts, D, 1)
+        out = np.zeros((row0[-1], D), F32)
+        flat = out.reshape(-1)
+        idx = _np(rows)
+        for p, c in enumerate(peer_counts):
+            r = idx[first[p]:first[p] + c]
+            out[row0[p]:row0[p] + c] = emb[r]
+            flat[(row0[p] + c) * D:(row0[p] + c) * D + c] = bias[r]
+        # looked-up item rows of this step (SparseAdam touches them even without a gradient)
+        self._touched = set(int(r) for r in idx if r >= model.U_loc)
+        return torch.from_numpy(out)
+
+    def forward_export(self, model, cw, lookup_counts, send_rows, cu, cp, cn, kind, num_items, codes,
+                       weights, scale):
+        buf = _np(cw)
+        R, D = buf.shape
+        first, row0 = self._blocks(lookup_counts, D, 1)
+        flat = buf.reshape(-1)
+        cbias = np.zeros(R, F32)
+        owner_of = np.zeros(R, np.int64)
+        dense_of = np.zeros(R, np.int64)
+        for p, c in enumerate(lookup_counts):
+            cbias[row0[p]:row0[p] + c] = flat[(row0[p] + c) * D:(row0[p] + c) * D + c]
+            owner_of[row0[p]:row0[p] + c] = p
+            dense_of[row0[p]:row0[p] + c] = np.arange(first[p], first[p] + c)
+        tables = {'user_embeddings': buf, 'item_embeddings': buf,
+                  'user_biases': cbias.reshape(R, 1), 'item_biases': cbias.reshape(R, 1)}
         metadata = {f'm{i}': _np(c) for i, c in enumerate(codes)} or None
         mweights = {f'm{i}': w for i, w in enumerate(weights)} or None
         out = O.calculate_loss(tables, _np(cu), _np(cp), _np(cn), kind, num_items=num_items,
                                metadata=metadata, metadata_weights=mweights)
         s = F32(scale.item())
-        gemb = np.zeros((n, D), F32)
+        gemb = np.zeros((R, D), F32)
         for name in ('user_embeddings', 'item_embeddings'):
             rows, vals = out['grads'][name]
             gemb[rows] += vals * s
-        gbias = np.zeros(n, F32)
+        gbias = np.zeros(R, F32)
         rows, vals = out['grads']['item_biases']        # d loss / d user_bias is identically 0
         gbias[rows] = vals[:, 0] * s
-        return (torch.tensor([out['loss']], dtype=torch.float32), torch.from_numpy(gemb),
-                torch.from_numpy(gbias))
+        # rows that travel: users, positives and every row with a non-zero gradient (the product
+        # sends users, positives and the selected negatives); the other looked-up rows reach the
+        # owner's update through the stamps of serve()
+        send = np.zeros(R, bool)
+        send[_np(cu)] = True
+        send[_np(cp)] = True
+        send |= (gemb != 0).any(axis=1) | (gbias != 0)
+        srows = _np(send_rows)
+        G = len(lookup_counts)
+        sel = [np.nonzero(send & (owner_of == p) & (np.arange(R) >= row0[p]) &
+                          (np.arange(R) < row0[p] + lookup_counts[p]))[0] for p in range(G)]
+        counts = [len(x) for x in sel]
+        _, w0 = self._blocks(counts, D, 2)
+        wire = np.zeros((w0[-1], D), F32)
+        wflat = wire.reshape(-1)
+        wint = wflat.view(np.int32)
+        for p, rows_p in enumerate(sel):
+            c = counts[p]
+            extra = (c + D - 1) // D
+            wire[w0[p]:w0[p] + c] = gemb[rows_p]
+            wflat[(w0[p] + c) * D:(w0[p] + c) * D + c] = gbias[rows_p]
+            wint[(w0[p] + c + extra) * D:(w0[p] + c + extra) * D + c] = srows[dense_of[rows_p]]
+        return (torch.tensor([out['loss']], dtype=torch.float32), torch.from_numpy(wire),
+                torch.tensor(counts + [w0[-1]], dtype=torch.int64))
 
-    def rows_update(self, table, rows, vals, algo, step, lr, state, hyper):
-        p = _np(table)
+    def owner_update(self, model, wire, peer_counts, step):
+        hp = model.hparams
+        emb, bias = _np(model.emb), _np(model.bias)
+        D = emb.shape[1]
+        buf = _np(wire) if wire is not None and wire.shape[0] else np.zeros((0, D), F32)
+        flat = buf.reshape(-1)
+        fint = flat.view(np.int32)
+        _, w0 = self._blocks(peer_counts, D, 2)
+        rows, gemb, gbias = [], [], []
+        for p, c in enumerate(peer_counts):              # peer order = requester rank order
+            extra = (c + D - 1) // D
+            rows.append(fint[(w0[p] + c + extra) * D:(w0[p] + c + extra) * D + c].astype(np.int64))
+            gemb.append(buf[w0[p]:w0[p] + c])
+            gbias.append(flat[(w0[p] + c) * D:(w0[p] + c) * D + c])
+        rows = np.concatenate(rows) if rows else np.zeros(0, np.int64)
+        gemb = np.concatenate(gemb) if gemb else np.zeros((0, D), F32)
+        gbias = np.concatenate(gbias) if gbias else np.zeros(0, F32)
+        have = set(rows.tolist())
+        extra_rows = np.array(sorted(r for r in self._touched if r not in have), np.int64)
+        rows = np.concatenate([rows, extra_rows])
+        gemb = np.concatenate([gemb, np.zeros((len(extra_rows), D), F32)])
+        gbias = np.concatenate([gbias, np.zeros(len(extra_rows), F32)])
+        if rows.shape[0] == 0:
+            return
+        for table, vals, algo, lr, state in (
+                (emb, gemb, hp['optimizer'], hp['lr'], model.state['emb']),
+                (bias, gbias, hp['bias_optimizer'], hp['bias_lr'], model.state['bias'])):
+            self._rows_update(table, rows, vals, algo, step, lr, state)
+
+    @staticmethod
+    def _rows_update(p, idx, vals, algo, step, lr, state):
         p2 = p.reshape(p.shape[0], -1)
-        idx = _np(rows)
-        v = _np(vals).reshape(idx.shape[0], -1).astype(F32)
+        v = vals.reshape(idx.shape[0], -1).astype(F32)
         urows, inv = np.unique(idx, return_inverse=True)
         g = np.zeros((urows.shape[0], v.shape[1]), F32)
         for e in range(idx.shape[0]):                    # entry order: requester rank order

@@ -99,13 +99,16 @@ def check_training(rank, world, loss, optimizer, bias_optimizer, K, metadata=Non
 
 def check_init(rank, world):
     U, N, D = 37, 29, 16
-    m = ShardedMatrixFactorizationModel(U, N, 3, embedding_dim=D, device='cpu',
-                                        engine=CpuOracleEngine(), seed=5)
+    m = ShardedMatrixFactorizationModel(U, N, 3, embedding_dim=D, device=DEV, engine=engine(),
+                                        seed=5)
     sd = m.state_dict()
-    want_u = counter_normal(torch.arange(U), D, 5, 0, 1.0 / (2.5 * D))     # on the CPU
-    want_i = counter_normal(torch.arange(N), D, 5, 1, 1.0 / (2.5 * D))
-    assert torch.equal(sd['user_embeddings.weight'].cpu(), want_u)  # independent of G and device
-    assert torch.equal(sd['item_embeddings.weight'].cpu(), want_i)
+    want_u = counter_normal(torch.arange(U, device=DEV), D, 5, 0, 1.0 / (2.5 * D))
+    want_i = counter_normal(torch.arange(N, device=DEV), D, 5, 1, 1.0 / (2.5 * D))
+    assert torch.equal(sd['user_embeddings.weight'], want_u)        # independent of G
+    assert torch.equal(sd['item_embeddings.weight'], want_i)
+    # ... and of the device up to the last bits of the float64 log / cos behind it
+    cpu_u = counter_normal(torch.arange(U), D, 5, 0, 1.0 / (2.5 * D))
+    np.testing.assert_allclose(want_u.cpu().numpy(), cpu_u.numpy(), rtol=1e-6, atol=1e-9)
     assert float(sd['user_biases.weight'].abs().max()) == 0.0
     # streamed gather to rank 0's host (tiny chunks: several rounds, ragged last chunk) and the
     # reference-format file written from it
@@ -137,8 +140,8 @@ def check_eval(rank, world):
     t0['item_biases'][5] = t0['item_biases'][6]
     t0['item_embeddings'][11] = t0['item_embeddings'][20]
     t0['item_biases'][11] = t0['item_biases'][20]
-    model = ShardedMatrixFactorizationModel(U, N, 3, embedding_dim=D, device='cpu',
-                                            engine=CpuOracleEngine(), init=False)
+    model = ShardedMatrixFactorizationModel(U, N, 3, embedding_dim=D, device=DEV, engine=engine(),
+                                            init=False)
     model.load_full_state_dict({f'{k_}.weight': dev(v.copy()) for k_, v in t0.items()})
     rng = np.random.default_rng(11)
     rows, cols = [], []
@@ -160,8 +163,8 @@ def check_eval(rank, world):
 
 
 def check_errors(rank, world):
-    model = ShardedMatrixFactorizationModel(10, 10, 2, embedding_dim=4, device='cpu',
-                                            engine=CpuOracleEngine())
+    model = ShardedMatrixFactorizationModel(10, 10, 2, embedding_dim=4, device=DEV,
+                                            engine=engine())
     users = torch.tensor([1, 2, 3, 4], dtype=torch.int32, device=DEV)
     pos = torch.tensor([1, 2, 3, 10 if rank == 1 else 4], dtype=torch.int32,
                        device=DEV)                                   # bad on rank 1 only
@@ -173,8 +176,7 @@ def check_errors(rank, world):
     else:
         raise AssertionError('out-of-range id was not reported')
     try:
-        ShardedMatrixFactorizationModel(10, 10, 2, optimizer='adam', device='cpu',
-                                        engine=CpuOracleEngine())
+        ShardedMatrixFactorizationModel(10, 10, 2, optimizer='adam', device=DEV, engine=engine())
     except ValueError:
         pass
     else:

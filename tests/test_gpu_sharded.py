@@ -36,12 +36,10 @@ def _step(model, opts, batch):
     return loss
 
 
-@pytest.mark.parametrize('compress', [False, True])
 @pytest.mark.parametrize('loss,optimizer,K,D', [('bpr', 'sparse_adam', 10, 64),
                                                 ('warp', 'adagrad', 5, 32),
                                                 ('hinge', 'sgd', 1, 10)])
-def test_world_1_sharded_step_matches_single_gpu_model(loss, optimizer, K, D, compress):
-    """compress: only the non-zero gradient rows go home (what world > 1 does by default)."""
+def test_world_1_sharded_step_matches_single_gpu_model(loss, optimizer, K, D):
     from collie_amd.model import MatrixFactorizationModel
     from collie_amd.sharded import ShardedMatrixFactorizationModel
     dev = torch.device('cuda:0')
@@ -55,7 +53,6 @@ def test_world_1_sharded_step_matches_single_gpu_model(loss, optimizer, K, D, co
         single.item_embeddings.weight.mul_(10.0)
         single.item_biases.weight.normal_(0, 0.01)
     sharded = ShardedMatrixFactorizationModel.from_model(single, K, device=dev)
-    sharded.compress_gradients = compress
     opts = single.configure_optimizers()
     rng = np.random.default_rng(4)
     for it in range(3):
@@ -66,9 +63,10 @@ def test_world_1_sharded_step_matches_single_gpu_model(loss, optimizer, K, D, co
         l2 = sharded.train_step(((users, pos), neg))
         np.testing.assert_allclose(l2.item(), l1.item(), rtol=1e-6)
     single.check_status()
-    if compress:        # at most user + positive + one negative per sample carry a gradient
-        assert 0 < sharded.last_gradient_rows <= 3 * B
-        assert sharded.last_gradient_rows < sharded.last_exchange['rows_requested'] or K == 1
+    # at most user + positive + one negative per sample carry a gradient: only those go home
+    sent = sharded.last_exchange['gradient_rows_sent']
+    assert 0 < sent <= 3 * B
+    assert sent < sharded.last_exchange['rows_requested'] or K == 1
     sd = sharded.state_dict()
     for name in NAMES:
         want = getattr(single, name).weight.detach().cpu().numpy()
@@ -127,17 +125,17 @@ def test_hip_shard_plan_equals_torch_plan(G, neg_dtype):
     from collie_amd import ops
     from collie_amd.sharded import plan_torch
     dev = torch.device('cuda:0')
-    U, N, B, K = 9001, 5003, 3000, 7
+    U, N, B, K, D = 9001, 5003, 3000, 7, 24
     rng = np.random.default_rng(G)
-    planner = ops.ShardPlanner(U, N, G, dev)
-    for it in range(3):                                   # the stamp tables are reused
+    planner = ops.ShardPlanner(U, N, G, D, dev)
+    for it in range(3):                                   # the sort scratch is reused
         users = torch.tensor(rng.zipf(1.2, B) % U, dtype=torch.int32, device=dev)
         pos = torch.tensor(rng.integers(0, N, B), dtype=torch.int64, device=dev)
         neg = torch.tensor(rng.integers(0, N, (B, K)), device=dev).to(neg_dtype)
         if it == 2:
             neg = neg.t().contiguous().t()                # strided negatives
         cu, cp, cn, rows, counts = planner.plan(users, pos, neg)
-        tu, tp, tn, trows, tcounts = plan_torch(users, pos, neg, U, N, G)
+        tu, tp, tn, trows, tcounts = plan_torch(users, pos, neg, U, N, G, D)
         assert torch.equal(counts, tcounts)
         n = int(counts[2 * G])
         assert torch.equal(rows[:n], trows)

@@ -14,11 +14,10 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 if len(sys.argv) > 3:
     bench.set_shape(sys.argv[3])            # c2 (default) | c4
-compress = len(sys.argv) > 4 and sys.argv[4] == 'compress'
+out_json = sys.argv[4] if len(sys.argv) > 4 and sys.argv[4].endswith('.json') else None
 dev = torch.device('cuda:0')
 m = ShardedMatrixFactorizationModel(bench.NUM_USERS, bench.NUM_ITEMS, bench.NUM_NEG,
                                     embedding_dim=bench.DIM, loss='bpr', device=dev)
-m.compress_gradients = compress      # what world > 1 does by default
 batches = bench.synthetic_batches(8, B, dev, 'uniform', 1)
 for i in range(5):
     m.train_step(batches[i % 8])
@@ -27,7 +26,7 @@ t0 = time.perf_counter()
 for i in range(steps):
     m.train_step(batches[i % 8])
 torch.cuda.synchronize()
-dt = (time.perf_counter() - t0) / steps
+dt = dt0 = (time.perf_counter() - t0) / steps
 print(f'B={B}: {dt * 1e3:.3f} ms/step, {B * 11 / dt / 1e9:.3f} G interactions/s, '
       f'rows/step {m.last_exchange}')
 torch.cuda.synchronize()
@@ -42,8 +41,15 @@ print(f'B={B} with plan_ahead: {dt * 1e3:.3f} ms/step, {B * 11 / dt / 1e9:.3f} G
 m.profile_phases(True)
 for i in range(10):
     m.train_step(batches[i % 8])
-print('phase ms:', {k: round(v, 3) for k, v in m.phase_times().items()})
+phases = {k: round(v, 3) for k, v in m.phase_times().items()}
+print('phase ms:', phases)
 m.profile_phases(False)
+if out_json:
+    import json
+    with open(out_json, 'w') as f:
+        json.dump({'shape': sys.argv[3] if len(sys.argv) > 3 else 'c2', 'world': 1, 'batch': B,
+                   'ms_per_step': round(dt0 * 1e3, 3), 'ms_per_step_plan_ahead': round(dt * 1e3, 3),
+                   'phase_ms': phases, 'exchange': m.last_exchange}, f, indent=1)
 if os.environ.get('PROFILE'):
     from torch.profiler import ProfilerActivity, profile
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:

@@ -19,7 +19,6 @@ torch.cuda.set_device(dev)
 dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
 m = ShardedMatrixFactorizationModel(bench.NUM_USERS, bench.NUM_ITEMS, bench.NUM_NEG,
                                     embedding_dim=bench.DIM, loss='bpr', device=dev, seed=0)
-m.compress_gradients = True      # what world > 1 does: exercise those collectives too
 batches = bench.synthetic_batches(4, 65536, dev, 'uniform', 1)
 for i in range(6):
     loss = m.train_step(batches[i % 4])
