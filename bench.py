@@ -330,6 +330,7 @@ def main_sharded(args, world, rank, device):
         model.train_step(batches[i % n_distinct])
     phases = model.phase_times()
     model.profile_phases(False)
+    rccl = rccl_selftest(device, world, backend)
     t = torch.tensor([elapsed], device=device, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -356,6 +357,7 @@ def main_sharded(args, world, rank, device):
                 'phase_ms_rank0': phases,
             },
             'roofline': None,
+            'rccl': rccl,
         }
         fwd_ms = phases.get('forward')
         if fwd_ms:
@@ -436,6 +438,63 @@ def train_leg(shape, args, device, steps, warmup):
     return out
 
 
+def launch_ranks(n):
+    """``python bench.py --gpus N`` run plainly: start the N ranks as a CHILD process
+    (torch.distributed.run, rendezvous on 127.0.0.1), relay rank 0's JSON line and exit with the
+    child's code.  This parent never touches the GPU (no torch.cuda call before or after)."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)]
+    cmd += sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    child = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in child.stdout.splitlines() if ln.startswith('{') and '"metric"' in ln]
+    for ln in child.stdout.splitlines():
+        if ln not in lines:
+            print(ln, file=sys.stderr)
+    if lines:
+        print(lines[-1])
+    sys.stdout.flush()
+    raise SystemExit(child.returncode if child.returncode or lines else 1)
+
+
+def rccl_selftest(device, world, backend):
+    """What the collectives of this run cost, measured on the process group the step uses: the
+    latency of a small all-to-all (the count exchanges) and the rate of a large one (the row
+    exchanges), so the N > 1 line shows that the backend saw `world` ranks and what it delivered."""
+    import torch.distributed as dist
+    staged = backend == 'gloo'
+    dev = 'cpu' if staged else device
+
+    def a2a(n_floats, iters):
+        src = torch.ones(world * n_floats, dtype=torch.float32, device=dev)
+        dst = torch.empty_like(src)
+        for _ in range(3):
+            dist.all_to_all_single(dst, src)
+        if not staged:
+            torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            dist.all_to_all_single(dst, src)
+        if not staged:
+            torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / iters
+
+    small = a2a(8, 50)
+    big_floats = (32 << 20) // 4                      # 32 MiB to every peer
+    big = a2a(big_floats, 5)
+    return {'backend': dist.get_backend(), 'world_size': dist.get_world_size(),
+            'all_to_all_us_small': small * 1e6,
+            'all_to_all_GBps_large': (world - 1) * big_floats * 4 / big / 1e9,
+            'note': 'per rank: 64-byte messages (latency) / 32 MiB per peer, bytes sent to the '
+                    'other ranks per second'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -451,10 +510,10 @@ def main():
                          'c5 = configs[4], the hybrid MLP head (tools/hybrid_bench.py)')
     ap.add_argument('--sharded-shape', choices=['c2', 'c4'], default='c4',
                     help="tables of the N > 1 run (default: configs[3], north_star's scaling config)")
-    ap.add_argument('--plan-ahead', action='store_true',
-                    help='N > 1: plan step t + 1 on a side stream while step t computes '
-                         '(ShardedMatrixFactorizationModel.plan_ahead; at G = 1 it measured 2-14 %% '
-                         'slower, see DESIGN.md 6)')
+    ap.add_argument('--no-plan-ahead', dest='plan_ahead', action='store_false',
+                    help='N > 1: do NOT plan step t + 1 on a side stream while step t computes '
+                         '(ShardedMatrixFactorizationModel.plan_ahead hides the first host read of '
+                         'a step behind the previous one; on by default, see DESIGN.md 6)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--eval-users', type=int, default=65536,
                     help='users in the eval leg (0 = skip it)')
@@ -477,8 +536,7 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus > 1 and world == 1:
-        raise SystemExit('for --gpus N > 1 launch with: python -m torch.distributed.run '
-                         '--nnodes=1 --nproc-per-node N bench.py --gpus N ...')
+        return launch_ranks(args.gpus)
     local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)

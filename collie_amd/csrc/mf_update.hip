@@ -918,9 +918,17 @@ __global__ __launch_bounds__(kBlock) void wire_piece_kernel(const WireExport p) 
   }
 }
 
+// LPR lanes own one segment, every lane CPL chunks of VEC floats of its row (chunks lig, lig + LPR,
+// ...): 64 / LPR segments per wave with up to 4 x CPL loads in flight per lane -- nearly every
+// segment is a single entry, so the kernel lives on independent rows in flight, not on long sums.
 template <int VEC, int LPR>
 __global__ __launch_bounds__(kBlock) void wire_rows_kernel(const WireExport p) {
   constexpr int GPW = kWave / LPR;
+  constexpr int CPL = 4;
+  __shared__ GradLayout lay;
+  for (int i = threadIdx.x; i < static_cast<int>(sizeof(GradLayout) / sizeof(int64_t)); i += kBlock)
+    reinterpret_cast<int64_t*>(&lay)[i] = reinterpret_cast<const int64_t*>(p.lay)[i];
+  __syncthreads();
   const int lane = lane_id();
   const int grp = lane / LPR;
   const int lig = lane % LPR;
@@ -934,83 +942,80 @@ __global__ __launch_bounds__(kBlock) void wire_rows_kernel(const WireExport p) {
     const int64_t seg = seg0 + grp;
     const bool active = seg < nseg;
     uint32_t start = 0, end = 0, key = 0;
+    uint32_t lbase = kNoPiece;
     if (active) {
       start = p.seg_start[seg];
       end = p.seg_start[seg + 1];
+      lbase = p.long_base[seg];
       key = p.keys[start];
     }
-    const uint32_t lbase = active ? p.long_base[seg] : kNoPiece;
     const uint32_t npc = lbase != kNoPiece ? (end - start + kPieceLen - 1) / kPieceLen : 0u;
     if (lbase != kNoPiece) end = start;
     // the peer that owns the row, and the row's place in that peer's block
     int peer = 0;
-    while (peer + 1 < p.world && static_cast<int64_t>(key) >= p.lay->row0[peer + 1]) ++peer;
-    const int64_t cnt = p.lay->gfirst[peer + 1] - p.lay->gfirst[peer];
-    const int64_t jj = seg - p.lay->gfirst[peer];
-    const int64_t w0 = p.lay->wire0[peer];
+    while (peer + 1 < p.world && static_cast<int64_t>(key) >= lay.row0[peer + 1]) ++peer;
+    const int64_t cnt = lay.gfirst[peer + 1] - lay.gfirst[peer];
+    const int64_t jj = seg - lay.gfirst[peer];
+    const int64_t w0 = lay.wire0[peer];
     const int64_t extra = (cnt + D - 1) / D;
+    int64_t owner_row = 0;
+    if (active && lig == 0)
+      owner_row = p.send_rows[lay.dense0[peer] + (static_cast<int64_t>(key) - lay.row0[peer])];
     float bacc = 0.0f;
-    for (int c0 = 0; c0 < nchunks; c0 += LPR) {
-      const int chunk = c0 + lig;
-      const bool on = active && chunk < nchunks;
-      RVec<VEC> acc;
+    for (int c0 = 0; c0 < nchunks; c0 += LPR * CPL) {
+      RVec<VEC> acc[CPL];
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) acc.v[i] = 0.0f;
+      for (int u = 0; u < CPL; ++u)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[u].v[i] = 0.0f;
       uint32_t e0 = start;
       while (__any(e0 < end)) {
-        const uint32_t code = (e0 + lig < end) ? p.vals[e0 + lig] : kCodeNone;
-        const int n_here = e0 < end ? static_cast<int>(min(end - e0, static_cast<uint32_t>(LPR))) : 0;
-        for (int j0 = 0; j0 < LPR; j0 += 4) {
-          if (!__any(j0 < n_here)) break;
-          RVec<VEC> x[4];
-          float sg[4];
-          uint32_t cc[4];
+        // four entries at a time, added in order
+        uint32_t cc[4];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const uint32_t c = __shfl(code, (j0 + q) % LPR, LPR);
-            cc[q] = (j0 + q < LPR) ? c : kCodeNone;
-            x[q] = wire_entry<VEC>(p, on ? cc[q] : kCodeNone, chunk, sg[q]);
+        for (int q = 0; q < 4; ++q) cc[q] = e0 + q < end ? p.vals[e0 + q] : kCodeNone;
+        RVec<VEC> x[4][CPL];
+        float sg[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+          for (int u = 0; u < CPL; ++u) {
+            const int chunk = c0 + u * LPR + lig;
+            x[q][u] = wire_entry<VEC>(p, chunk < nchunks ? cc[q] : kCodeNone, chunk, sg[q]);
           }
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            if (sg[q] != 0.0f) {
-#pragma unroll
-              for (int i = 0; i < VEC; ++i) acc.v[i] += sg[q] * x[q].v[i];
-            }
-            if (c0 == 0 && lig == 0) bacc += wire_entry_bias(p, cc[q]);
-          }
+          sg[q] = cc[q] == kCodeNone ? 0.0f : ((cc[q] & kCodeNeg) ? -1.0f : 1.0f);
         }
-        e0 += LPR;
-      }
-      if (on) {
-        for (uint32_t i0 = 0; i0 < npc; i0 += 4) {
-          RVec<VEC> x[4];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < 4; ++q) {
+          if (sg[q] != 0.0f) {
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) x[q].v[i] = 0.0f;
-            if (i0 + q < npc)
-              x[q] = rload<VEC>(p.partial + static_cast<int64_t>(lbase + i0 + q) * D + chunk * VEC);
+            for (int u = 0; u < CPL; ++u)
+#pragma unroll
+              for (int i = 0; i < VEC; ++i) acc[u].v[i] += sg[q] * x[q][u].v[i];
           }
+          if (c0 == 0 && lig == 0) bacc += wire_entry_bias(p, cc[q]);
+        }
+        e0 += 4;
+      }
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
-            if (i0 + q < npc) {
+      for (int u = 0; u < CPL; ++u) {
+        const int chunk = c0 + u * LPR + lig;
+        if (!active || chunk >= nchunks) continue;
+        for (uint32_t i = 0; i < npc; ++i) {     // a long segment: its piece sums, in piece order
+          const RVec<VEC> x = rload<VEC>(p.partial + static_cast<int64_t>(lbase + i) * D + chunk * VEC);
 #pragma unroll
-              for (int i = 0; i < VEC; ++i) acc.v[i] += x[q].v[i];
-            }
+          for (int k = 0; k < VEC; ++k) acc[u].v[k] += x.v[k];
         }
         RVec<VEC> g;
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) g.v[i] = acc.v[i] * scale;
+        for (int k = 0; k < VEC; ++k) g.v[k] = acc[u].v[k] * scale;
         rstore<VEC>(p.wire + (w0 + jj) * D + chunk * VEC, g);
       }
     }
     if (active && lig == 0) {
       for (uint32_t i = 0; i < npc; ++i) bacc += p.partial[p.max_pieces * D + lbase + i];
       p.wire[(w0 + cnt) * D + jj] = bacc * scale;
-      const int64_t dense = p.lay->dense0[peer] + (static_cast<int64_t>(key) - p.lay->row0[peer]);
-      reinterpret_cast<int32_t*>(p.wire)[(w0 + cnt + extra) * D + jj] =
-          static_cast<int32_t>(p.send_rows[dense]);
+      reinterpret_cast<int32_t*>(p.wire)[(w0 + cnt + extra) * D + jj] = static_cast<int32_t>(owner_row);
     }
   }
 }
@@ -1933,8 +1938,9 @@ extern "C" int collie_shard_export_grads(const collie_mf_tables* t, const collie
   p.D = D;
   const int vec = (D % 4 == 0 && al16(wire) && al16(ws.stage_u) && al16(ws.stage_i)) ? 4 : 1;
   const int nchunks = (D + vec - 1) / vec;
+  // the row kernel gives every lane 4 chunks of its row, the piece kernel one chunk per pass
   int lpr = 1;
-  while (lpr < nchunks && lpr < kWave) lpr *= 2;
+  while (lpr * 4 < nchunks && lpr < kWave) lpr *= 2;
   const int gpw = kWave / lpr;
   int64_t blocks = (m + gpw * kWavesPerBlock - 1) / (gpw * kWavesPerBlock);
   if (blocks > 4 * kUpdateBlocks) blocks = 4 * kUpdateBlocks;

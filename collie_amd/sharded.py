@@ -49,6 +49,7 @@ exchange code on CPU tensors with the oracle as the arithmetic (tests/sharded_cp
 the product never imports the oracle and ``HipEngine`` refuses CPU tensors.
 """
 import math
+import os
 from typing import Iterable, Optional
 
 import numpy as np
@@ -246,10 +247,16 @@ class _Comm:
             self.staged = dist.get_backend(group) == 'gloo'
         else:
             self.world, self.rank = 1, 0
+        # one rank: nothing travels, the "received" buffer is the one sent.  COLLIE_SHARDED_COLLECTIVES=1
+        # keeps the collective calls anyway (tools/sharded_nccl_selftest.py: argument dtypes,
+        # contiguity and split lists of every call against RCCL on one GPU)
+        self.local = self.world == 1 and not (
+            dist.is_available() and dist.is_initialized()
+            and os.environ.get('COLLIE_SHARDED_COLLECTIVES') == '1')
 
     def all_to_all(self, inp, in_splits, out_splits):
         """Rows of ``inp`` split by ``in_splits`` go to the peers; returns the rows received."""
-        if self.world == 1:         # nothing travels: the "received" buffer is the one sent
+        if self.local:
             return inp
         shape = (int(sum(out_splits)),) + tuple(inp.shape[1:])
         out = torch.empty(shape, dtype=inp.dtype, device=inp.device)
@@ -263,7 +270,7 @@ class _Comm:
         return out
 
     def all_reduce(self, t):
-        if self.world > 1:
+        if not self.local:
             if self.staged and t.is_cuda:
                 host = t.cpu()
                 dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
@@ -275,7 +282,7 @@ class _Comm:
     def gather_to_host(self, t, dst=0):
         """Every rank's ``t`` (same shape) as a list of HOST tensors on rank ``dst``; None on the
         other ranks.  Only ``dst`` ever holds more than its own piece."""
-        if self.world == 1:
+        if self.local:
             return [t.cpu()]
         src = t.cpu() if (self.staged and t.is_cuda) else t.contiguous()
         out = [torch.empty_like(src) for _ in range(self.world)] if self.rank == dst else None
@@ -283,7 +290,7 @@ class _Comm:
         return [o.cpu() for o in out] if out is not None else None
 
     def all_gather(self, t):
-        if self.world == 1:
+        if self.local:
             return [t]
         src = t.cpu() if (self.staged and t.is_cuda) else t.contiguous()
         out = [torch.empty_like(src) for _ in range(self.world)]

@@ -12,6 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 from collie_amd.sharded import ShardedMatrixFactorizationModel  # noqa: E402
 
+os.environ['COLLIE_SHARDED_COLLECTIVES'] = '1'     # one rank, but every collective call is made
 os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
 os.environ.setdefault('MASTER_PORT', '29533')
 dev = torch.device('cuda:0')
