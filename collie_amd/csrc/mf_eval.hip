@@ -667,10 +667,10 @@ __global__ __launch_bounds__(kBlockDma) void eval_gemm_dma_kernel(const EvalPara
   }
 }
 
-// one wave per user: k rounds of "best remaining candidate" over nslots * kCap candidates
+// one wave per user: k rounds of "best remaining candidate" over the user's n candidates
 __global__ __launch_bounds__(kBlock) void merge_topk_kernel(const float* __restrict__ cand_scores,
                                                             const int32_t* __restrict__ cand_ids,
-                                                            int64_t n_users, int nslots, int k,
+                                                            int64_t n_users, int n, int k,
                                                             int has_y, float y_lo, float y_hi,
                                                             float* __restrict__ out_scores,
                                                             int64_t* __restrict__ out_ids,
@@ -680,7 +680,6 @@ __global__ __launch_bounds__(kBlock) void merge_topk_kernel(const float* __restr
   const int lane = lane_id();
   const int64_t user = static_cast<int64_t>(blockIdx.x) * kWaves + threadIdx.x / kWave;
   if (user >= n_users) return;
-  const int n = nslots * kCap;
   const float* cs = cand_scores + user * n;
   const int32_t* ci = cand_ids + user * n;
   float last_s = INFINITY;
@@ -1015,7 +1014,7 @@ int topk_rounds(EvalParams& p, int gemm_done_rounds, int32_t k, int32_t has_y_ra
     const bool more = r + 1 < rounds;
     hipLaunchKernelGGL(merge_topk_kernel,
                        dim3(static_cast<unsigned>((p.n_users + kWaves - 1) / kWaves)), dim3(kBlock),
-                       0, stream, ws.cand_scores, ws.cand_ids, p.n_users, p.nchunks * 2, kr,
+                       0, stream, ws.cand_scores, ws.cand_ids, p.n_users, p.nchunks * 2 * kCap, kr,
                        has_y_range, y_lo, y_hi, topk_scores, topk_ids, k, r * kCap,
                        more ? ws.cut_s : nullptr, more ? ws.cut_i : nullptr);
     if (check_launch("merge_topk_kernel")) return -1;
@@ -1131,14 +1130,17 @@ extern "C" int collie_mf_eval_topk_static(const collie_mf_tables* t, const int64
 }
 
 extern "C" int collie_mf_eval_merge_topk(const float* cand_scores, const int32_t* cand_ids,
-                                         int64_t n_users, int32_t nslots, int32_t k,
-                                         float* topk_scores, int64_t* topk_ids,
+                                         int64_t n_users, int32_t nslots, int32_t slot_len,
+                                         int32_t k, float* topk_scores, int64_t* topk_ids,
                                          collie_stream_t stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   COLLIE_REQUIRE(cand_scores && cand_ids && topk_scores && topk_ids, "merge_topk: NULL pointer");
-  COLLIE_REQUIRE(n_users >= 1 && nslots >= 1 && k >= 1 && k <= kCap, "merge_topk: bad sizes");
+  COLLIE_REQUIRE(n_users >= 1 && nslots >= 1 && slot_len >= 1 && k >= 1 &&
+                     static_cast<int64_t>(nslots) * slot_len < (int64_t{1} << 30) &&
+                     k <= static_cast<int64_t>(nslots) * slot_len,
+                 "merge_topk: bad sizes");
   hipLaunchKernelGGL(merge_topk_kernel, dim3(static_cast<unsigned>((n_users + kWaves - 1) / kWaves)),
-                     dim3(kBlock), 0, stream, cand_scores, cand_ids, n_users, nslots, k, 0, 0.0f,
+                     dim3(kBlock), 0, stream, cand_scores, cand_ids, n_users, nslots * slot_len, k, 0, 0.0f,
                      0.0f, topk_scores, topk_ids, k, 0, static_cast<float*>(nullptr),
                      static_cast<int32_t*>(nullptr));
   return check_launch("merge_topk_kernel");

@@ -853,12 +853,13 @@ def preds_rank_counts(preds, indptr, lo, hi, best_s, best_id, counts):
 
 
 def eval_merge_topk(cand_scores, cand_ids, k):
-    n, nslots, cap = cand_scores.shape
-    assert cap == eval_topk_capacity() and cand_ids.dtype == torch.int32
+    n, nslots, slot_len = cand_scores.shape
+    assert cand_ids.dtype == torch.int32 and cand_ids.shape == cand_scores.shape
     dev = cand_scores.device
     scores = torch.empty(n, k, dtype=torch.float32, device=dev)
     ids = torch.empty(n, k, dtype=torch.int64, device=dev)
     check(load().collie_mf_eval_merge_topk(ptr(cand_scores.contiguous()),
-                                           ptr(cand_ids.contiguous()), n, nslots, k, ptr(scores),
+                                           ptr(cand_ids.contiguous()), n, nslots, slot_len, k,
+                                           ptr(scores),
                                            ptr(ids), stream_ptr()), 'collie_mf_eval_merge_topk')
     return scores, ids

@@ -744,9 +744,10 @@ class ShardedMatrixFactorizationModel:
         utile, ubias = self._user_tile(uids)
         iemb, ibias = self.item_embeddings, self.item_biases
         topk_ids = pos = counts = shard_top = None
+        lk = min(k, iemb.shape[0])      # a shard smaller than k contributes all of its items
         if callable(indptr):    # lazy CSR rows: MAP@k alone needs them only after the scoring pass
             if want_ap and not (want_rr or want_auc):
-                shard_top = eng.shard_topk(utile, ubias, iemb, ibias, G, rank, k)
+                shard_top = eng.shard_topk(utile, ubias, iemb, ibias, G, rank, lk)
             indptr, indices = indptr()
         if want_rr or want_auc:
             pos = eng.shard_pos_scores(utile, ubias, iemb, ibias, G, rank, indptr, indices)
@@ -754,20 +755,22 @@ class ShardedMatrixFactorizationModel:
             thr = eng.thresholds(utile, ubias, iemb, ibias, indptr, indices, pos, y)
             fused = getattr(eng, 'shard_topk_rank_counts', None)
             if want_ap and fused is not None:   # one pass over the shard for both
-                shard_top, counts = fused(utile, ubias, iemb, ibias, G, rank, k, indptr, thr)
+                shard_top, counts = fused(utile, ubias, iemb, ibias, G, rank, lk, indptr, thr)
             else:
                 counts = eng.shard_rank_counts(utile, ubias, iemb, ibias, G, rank, indptr, thr)
             comm.all_reduce(counts)
         if want_ap:
-            cap = ops.eval_topk_capacity() if eng.name == 'hip' else 16
+            # every shard's own top-k, all gathered: G lists of k candidates per user, merged by
+            # (score desc, id asc); any k <= num_items (metrics.py:170-175)
             s, i = shard_top if shard_top is not None else eng.shard_topk(
-                utile, ubias, iemb, ibias, G, rank, k)
-            parts_s, parts_i = comm.all_gather(s), comm.all_gather(i.to(torch.int32))
-            cs = torch.full((n, G, cap), float('-inf'), dtype=torch.float32, device=self.device)
-            ci = torch.full((n, G, cap), _I31, dtype=torch.int32, device=self.device)
-            for r in range(G):
-                cs[:, r, :k] = parts_s[r]
-                ci[:, r, :k] = parts_i[r]
+                utile, ubias, iemb, ibias, G, rank, lk)
+            i = i.to(torch.int32)
+            if lk < k:
+                s = torch.nn.functional.pad(s, (0, k - lk), value=float('-inf'))
+                i = torch.nn.functional.pad(i, (0, k - lk), value=_I31)
+            parts_s, parts_i = comm.all_gather(s.contiguous()), comm.all_gather(i.contiguous())
+            cs = torch.stack(parts_s, 1).contiguous()
+            ci = torch.stack(parts_i, 1).contiguous()
             topk_ids = eng.merge_topk(cs, ci, k)
         return eng.metrics(topk_ids, k, n, N, indptr, indices, pos, counts, y, want)
 
@@ -791,11 +794,6 @@ class ShardedMatrixFactorizationModel:
             raise ValueError('test interactions and model disagree on the number of items')
         if k > n_items:
             raise ValueError(f'Ensure ``k`` ({k}) is less than the number of items ({n_items}):')
-        # the smallest shard over ALL ranks (shards differ by one row): every rank raises or none
-        # does, so no rank is left waiting in a collective
-        min_shard = n_items // self.comm.world
-        if want[0] and (k > 16 or k > min_shard):
-            raise ValueError(f'k={k} must not exceed 16 or the smallest item shard ({min_shard})')
         test_users = M._unique_users(test_interactions)
         csr = []
 

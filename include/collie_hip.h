@@ -512,11 +512,12 @@ int collie_mf_eval_topk_static(const collie_mf_tables* t, const int64_t* user_id
                                collie_stream_t stream);
 
 /* Catalog-sharded evaluation: merge per-shard top-k candidate lists (cand_* [n_users, nslots,
- * collie_mf_eval_topk_capacity()], unused entries = (-inf, INT32_MAX)) into the global top-k.
- * No counterpart in the reference (it has no sharded evaluation). */
+ * slot_len]: every shard's own top-k in slot_len >= its length entries, unused entries = (-inf,
+ * INT32_MAX)) into the global top-k, any k <= nslots * slot_len (metrics.py:170-175 allows any
+ * k <= num_items).  No counterpart in the reference (it has no sharded evaluation). */
 int collie_mf_eval_merge_topk(const float* cand_scores, const int32_t* cand_ids, int64_t n_users,
-                              int32_t nslots, int32_t k, float* topk_scores, int64_t* topk_ids,
-                              collie_stream_t stream);
+                              int32_t nslots, int32_t slot_len, int32_t k, float* topk_scores,
+                              int64_t* topk_ids, collie_stream_t stream);
 
 /* Scores of the positives, computed with the same fmaf chain as the MFMA tiles so that they are
  * bit-identical to the catalog scores of the same pairs:

@@ -160,6 +160,20 @@ def check_eval(rank, world):
         np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-9)
     one = model.evaluate_in_batches([M.mapk], inter, k=k)
     np.testing.assert_allclose(one, O.evaluate_in_batches([O.mapk], mat, t0, k=k), rtol=1e-12)
+    # any k <= num_items (metrics.py:170-175): beyond the 16 candidates one scoring round keeps,
+    # beyond a whole shard (47 items over 2 ranks = 24 + 23), and the whole catalogue
+    for big_k in (20, 30, N):
+        got = model.evaluate_in_batches([M.mapk, M.mrr, M.auc], inter, k=big_k, batch_size=20)
+        want = O.evaluate_in_batches([O.mapk, O.mrr, O.auc], mat, t0, k=big_k, batch_size=20)
+        np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-9)
+        one = model.evaluate_in_batches([M.mapk], inter, k=big_k)
+        np.testing.assert_allclose(one, O.evaluate_in_batches([O.mapk], mat, t0, k=big_k), rtol=1e-12)
+    try:
+        model.evaluate_in_batches([M.mapk], inter, k=N + 1)
+    except ValueError:
+        pass
+    else:
+        raise AssertionError('k > num_items must be refused')
 
 
 def check_errors(rank, world):

@@ -185,6 +185,85 @@ def test_configs2_catalogue_topk_shard_merge_and_rescoring(dev):
     assert int(clear.sum()) > n_eval // 2
     assert torch.equal(ids[clear], top_k1.indices[clear][:, :k])
 
+    # (3) the MRR / AUC rank-count epilogues and the fused pass at this catalogue size: users with
+    # 1, 15, 16 and 40 positives among them (the per-user LDS search tree holds 15), every other
+    # user with three of its own top-10 items planted as positives (so that AP and RR are not ~0)
+    import scipy.sparse as sp
+    from collie_amd.metrics import _csr_slice
+    rng = np.random.default_rng(9)
+    n_pos = rng.integers(1, 13, n_eval)
+    n_pos[:8] = (1, 15, 16, 40, 1, 15, 16, 40)
+    ids_h = ids.cpu().numpy()
+    slots_h = slots.cpu().numpy()
+    rows, cols = [], []
+    for u in range(n_eval):
+        c = set(rng.choice(N, int(n_pos[u]), replace=False).tolist())
+        if u % 2 == 0:
+            c.update(int(x) for x in ids_h[u, [0, 3, 7]])
+        rows += [slots_h[u]] * len(c)
+        cols += sorted(c)
+    csr = sp.coo_matrix((np.ones(len(rows)), (rows, cols)), shape=(U, N)).tocsr()
+    indptr, indices = _csr_slice(csr, slots_h, dev)
+    pos, lo, hi, best_s, best_id = ops.eval_pos_scores(t, slots, indptr, indices, None, True)
+    counts = torch.zeros(n_eval, 3, dtype=torch.int64, device=dev)
+    s2, i2 = ops.eval_topk_rank_counts(t, slots, indptr, lo, hi, best_s, best_id, 0, N, k, None,
+                                       counts, ws)
+    assert torch.equal(i2, ids) and torch.equal(s2, scores)      # fused pass == top-k pass
+    only = torch.zeros(n_eval, 3, dtype=torch.int64, device=dev)
+    ops.eval_rank_counts(t, slots, indptr, lo, hi, best_s, best_id, 0, N, only)
+    assert torch.equal(only, counts)                              # ... == rank-count pass
+    ap, rr, au = ops.eval_metrics(ids, k, n_eval, N, indptr, indices, pos, counts, None,
+                                  True, True, True)
+    # the positives' scores are the catalogue scores (same chain), to the rounding of part (2)
+    ip = indptr.cpu().numpy()
+    ix = indices.cpu().numpy()
+    urow = torch.repeat_interleave(torch.arange(n_eval, device=dev), indptr[1:] - indptr[:-1])
+    assert float((full[urow, indices] - pos[:indices.shape[0]]).abs().max()) <= 1e-5 * scale
+    # counters against plain torch on `full`: an item within the rounding band of a threshold may
+    # fall on either side, everything else must be counted exactly
+    band = 1e-5 * scale
+    item_ids = torch.arange(N, device=dev)
+    want_rr = np.zeros(n_eval)
+    want_auc = np.zeros(n_eval)
+    for u in range(n_eval):
+        a, b = ip[u], ip[u + 1]
+        row = full[u]
+        p_s = pos[a:b]
+        p_i = indices[a:b]
+        order = np.lexsort((p_i.cpu().numpy(), -p_s.cpu().numpy().astype(np.float64)))
+        bs, bi = p_s[order[0]], p_i[order[0]]
+        c0 = int(counts[u, 0])
+        assert int((row > bs + band).sum()) <= c0 <= int((row >= bs - band).sum()), u
+        lt_lo = int((row[None, :] < (p_s[:, None] - band)).sum())
+        le_hi = int((row[None, :] <= (p_s[:, None] + band)).sum())
+        assert lt_lo <= int(counts[u, 1]) <= int(counts[u, 2]) <= le_hi, u
+        # torch-side formulas (metrics.py:224-240, 266-282) on torch's own scores
+        first = int(((row > row[bi]) | ((row == row[bi]) & (item_ids < bi))).sum())
+        want_rr[u] = 1.0 / (1.0 + first)
+        sig = torch.sigmoid(row)
+        psig = sig[p_i]
+        is_pos = torch.zeros(N, dtype=torch.bool, device=dev)
+        is_pos[p_i] = True
+        neg = sig[~is_pos]
+        lt = (neg[None, :] < psig[:, None]).sum().item()
+        eq = (neg[None, :] == psig[:, None]).sum().item()
+        want_auc[u] = (lt + 0.5 * eq) / (float(b - a) * neg.shape[0])
+    np.testing.assert_allclose(rr.cpu().numpy(), want_rr, rtol=0, atol=1e-5)
+    np.testing.assert_allclose(au.cpu().numpy(), want_auc, rtol=0, atol=1e-5)
+    assert float(rr[::2].min()) == 1.0          # planted: the user's top item is a positive
+    # AP@k (metrics.py:178-198) from the top-k ids verified above, in float64
+    want_ap = np.zeros(n_eval)
+    for u in range(n_eval):
+        truth = set(ix[ip[u]:ip[u + 1]].tolist())
+        hits, acc = 0, 0.0
+        for j in range(k):
+            if int(ids_h[u, j]) in truth:
+                hits += 1
+                acc += hits / (j + 1.0)
+        want_ap[u] = acc / min(k, len(truth))
+    np.testing.assert_allclose(ap.cpu().numpy(), want_ap, rtol=1e-12)
+    assert float(ap[::2].min()) > 0.0
+
 
 # ---- configs[3]: 100 M x 10 M x 128 on one GPU ---------------------------------------------------
 def _fingerprint(w, probe):
