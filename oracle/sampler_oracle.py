@@ -13,11 +13,16 @@ last negative (:412-419, :425).
 
 The random STREAM is necessarily different from the reference's (CPython ``random`` / numpy's
 global generator are host generators): draws come from the counter-based Philox4x32-10 generator
-(Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11; the Random123 known-answer
-vectors are checked in tests/test_sampler_cpu.py), counter = (global sample position, draw number),
-key = seed, so a batch does not depend on how the work is split.  Parity of the stream itself is
-therefore "parity unpinned" against the reference; what is pinned is (a) this file against the
-Random123 vectors, (b) the device kernel against this file bit for bit, (c) the invariants the
+(Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11), counter = (global sample
+position, draw number), key = seed, so a batch does not depend on how the work is split.
+
+Pinned: (a) the generator against the Random123 known-answer vectors; (b) the sampling RULES against
+the reference's own ``Interactions.__getitem__`` / ``_negative_sample`` run in the build container
+with its three RNG calls (``random.choice``, ``random.choices``, ``np.random.randint``) reading this
+stream -- ``tests/golden/ref_sampler.npz``, written by ``tests/golden/make_golden_ref_sampler.py``:
+exact mode with and without an exhausted budget, K = 1 / 4 / 10, tiny catalogues, approximate mode
+scalar and batched -- bit for bit (tests/test_sampler_cpu.py); (c) the device kernel against that
+fixture and against this file bit for bit (tests/test_gpu_sampler.py); (d) the invariants the
 reference's own tests assert (tests/test_interactions.py:356-457).
 """
 import numpy as np

@@ -3,11 +3,15 @@ GPU tests of the device-side batch assembly + negative sampler (``collie_sample_
 the C ABI: bit-exact against oracle/sampler_oracle.py on seeded inputs, the reference's sampling
 invariants at a larger size, and the loader / trainer built on it.
 """
+import os
+import sys
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
 import torch
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
@@ -54,6 +58,30 @@ def test_device_sampler_is_bit_exact_vs_oracle(dev, exact, shuffle, max_tries, K
         np.testing.assert_array_equal(u.cpu().numpy(), want[0])
         np.testing.assert_array_equal(p.cpu().numpy(), want[1])
         np.testing.assert_array_equal(n.cpu().numpy(), want[2])
+
+
+def test_device_sampler_equals_the_references_negative_sample(dev):
+    """``collie_sample_batch`` against tests/golden/ref_sampler.npz: the reference's own
+    ``Interactions.__getitem__`` / ``_negative_sample`` (datasets.py:378-445) reading the Philox
+    stream (exact mode with and without an exhausted budget, K = 1 / 4 / 10, tiny catalogues,
+    approximate mode scalar and batched), bit for bit, whole and in ragged pieces."""
+    from collie_amd import ops
+    from test_sampler_cpu import ref_sampler_cases
+    for c in ref_sampler_cases():
+        exact = c['max_tries'] > 0
+        n = len(c['rows'])
+        indptr = c['csr'].indptr.astype(np.int64) if exact else None
+        indices = c['csr'].indices.astype(np.int32) if exact else None
+        d_rows, d_cols, d_order, d_indptr, d_indices = to_dev(dev, c['rows'], c['cols'], c['order'],
+                                                              indptr, indices)
+        for start, batch in ((0, n), (0, n // 3), (n // 3, n - n // 3)):
+            (u, p), neg = ops.sample_batch(d_rows, d_cols, d_order, start, batch, d_indptr,
+                                           d_indices, c['N'], c['K'], c['max_tries'], c['seed'],
+                                           c['base'])
+            sl = slice(start, start + batch)
+            np.testing.assert_array_equal(u.cpu().numpy(), c['want'][0][sl], err_msg=c['tag'])
+            np.testing.assert_array_equal(p.cpu().numpy(), c['want'][1][sl], err_msg=c['tag'])
+            np.testing.assert_array_equal(neg.cpu().numpy(), c['want'][2][sl], err_msg=c['tag'])
 
 
 def test_exact_sampling_invariants_at_scale(dev):

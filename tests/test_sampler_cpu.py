@@ -94,3 +94,44 @@ def test_host_loader_rejects_positives_and_within_row_repeats():
     pos = set(zip(it.mat.row.tolist(), it.mat.col.tolist()))
     assert all(len(set(r.tolist())) == len(r) for r in neg)
     assert not any((uu, n) in pos for uu, r in zip(u.tolist(), neg.tolist()) for n in r)
+
+
+# ---- the sampling RULES pinned to the reference's own _negative_sample -----------------------------
+GOLDEN = __import__('os').path.join(__import__('os').path.dirname(__file__), 'golden',
+                                    'ref_sampler.npz')
+
+
+def ref_sampler_cases():
+    """tests/golden/ref_sampler.npz: outputs of the reference's ``Interactions.__getitem__``
+    (datasets.py:378-445) with its three RNG calls reading the Philox stream
+    (tests/golden/make_golden_ref_sampler.py)."""
+    z = np.load(GOLDEN)
+    for tag in sorted({k.split('|')[0] for k in z.files}):
+        U, N, K, max_tries, seed, base, shuffled = (int(v) for v in z[f'{tag}|params'])
+        rows, cols = z[f'{tag}|rows'], z[f'{tag}|cols']
+        csr = sp.coo_matrix((np.ones(len(rows)), (rows, cols)), shape=(U, N)).tocsr()
+        csr.sort_indices()
+        yield dict(tag=tag, U=U, N=N, K=K, max_tries=max_tries, seed=seed, base=base,
+                   rows=rows, cols=cols, order=z[f'{tag}|order'] if shuffled else None, csr=csr,
+                   want=(z[f'{tag}|users'], z[f'{tag}|pos'], z[f'{tag}|neg']))
+
+
+def test_oracle_equals_the_references_negative_sample_bit_for_bit():
+    seen_budget_hit = False
+    for c in ref_sampler_cases():
+        exact = c['max_tries'] > 0
+        got = S.sample_batch(c['rows'], c['cols'], c['order'], 0, len(c['rows']),
+                             c['csr'].indptr if exact else None,
+                             c['csr'].indices if exact else None, c['N'], c['K'], c['max_tries'],
+                             seed=c['seed'], position_base=c['base'])
+        for g, w, name in zip(got, c['want'], ('users', 'pos', 'neg')):
+            np.testing.assert_array_equal(g, w, err_msg=f"{c['tag']} {name}")
+            assert g.dtype == w.dtype, (c['tag'], name)
+        if exact:       # does the fixture exercise the exhausted-budget fill (datasets.py:412-419)?
+            neg = c['want'][2]
+            for t in range(len(neg)):
+                mine = set(c['csr'].indices[c['csr'].indptr[c['want'][0][t]]:
+                                            c['csr'].indptr[c['want'][0][t] + 1]])
+                if len(set(neg[t])) < c['K'] or set(neg[t]) & mine:
+                    seen_budget_hit = True
+    assert seen_budget_hit
