@@ -238,5 +238,6 @@ def test_small_batch_with_unaligned_tables_builds_its_own_segments():
         assert int(status.item()) == 0
         results.append({k: x.cpu().numpy().copy() for k, x in t.items()})
     for k in init:
-        np.testing.assert_allclose(results[1][k], results[0][k], rtol=1e-6, atol=1e-7, err_msg=k)
+        # (unaligned rows take the generic forward kernel: another summation order of the dot products)
+        np.testing.assert_allclose(results[1][k], results[0][k], rtol=1e-5, atol=1e-6, err_msg=k)
         assert np.abs(results[0][k] - init[k]).max() > 0 or k == 'ub'
