@@ -140,7 +140,7 @@ SIGNATURES = {
                                                               c_void_p, c_void_p]),
     'collie_shard_wire_rows': (c_int64, [c_void_p, c_int32, c_int32, c_int32]),
     'collie_shard_plan_workspace_bytes': (c_size_t, [c_int64, c_int32, c_int32]),
-    'collie_shard_plan': (ctypes.c_int, [POINTER(Batch), c_int64, c_int64, c_int32, c_int32,
+    'collie_shard_plan': (ctypes.c_int, [POINTER(Batch), c_int64, c_int64, c_int32, c_int32, c_int32,
                                          c_void_p, c_size_t, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_int64, c_void_p, c_void_p]),
     'collie_shard_serve_rows': (ctypes.c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p,
@@ -150,7 +150,7 @@ SIGNATURES = {
                                                 c_void_p, c_void_p]),
     'collie_shard_export_workspace_bytes': (c_size_t, [c_int64]),
     'collie_shard_export_grads': (ctypes.c_int, [POINTER(Tables), POINTER(Batch), c_void_p,
-                                                 c_size_t, c_int32, c_void_p, c_void_p, c_void_p,
+                                                 c_size_t, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                                  c_void_p, c_int64, c_void_p, c_void_p, c_size_t,
                                                  c_void_p]),
     'collie_shard_owner_workspace_bytes': (c_size_t, [c_int64, c_int64, c_int32]),

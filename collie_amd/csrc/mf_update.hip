@@ -798,6 +798,8 @@ struct WireExport {
   const int64_t* send_rows;   // dense request index -> row of the owner's combined table
   const GradLayout* lay;
   float* wire;
+  uint32_t key_sub;   // users local: keys of item rows are num_users + compact row, user segments stay
+  int all_items;      // users local: every exported entry is an item entry (codes carry no kind)
   int world;
   int D;
 };
@@ -819,6 +821,7 @@ __global__ __launch_bounds__(64) void wire_layout_kernel(const uint32_t* __restr
                                                          const uint32_t* __restrict__ seg_of,
                                                          const uint32_t* __restrict__ nseg, int64_t m,
                                                          const WireBlocks look, int dim,
+                                                         uint32_t key_sub,
                                                          GradLayout* __restrict__ lay,
                                                          int64_t* __restrict__ peer_counts) {
   __shared__ int64_t gfirst[kMaxWorld + 1];
@@ -827,7 +830,7 @@ __global__ __launch_bounds__(64) void wire_layout_kernel(const uint32_t* __restr
     const int p = threadIdx.x;
     int64_t at = static_cast<int64_t>(nseg[0]);
     if (p < world) {
-      const int64_t want = look.row0[p];
+      const int64_t want = look.row0[p] + static_cast<int64_t>(key_sub);
       int64_t lo = 0, hi = m;
       while (lo < hi) {
         const int64_t mid = (lo + hi) >> 1;
@@ -863,7 +866,7 @@ __device__ __forceinline__ RVec<VEC> wire_entry(const WireExport& p, uint32_t c,
   sg = 0.0f;
   if (c != kCodeNone) {
     sg = (c & kCodeNeg) ? -1.0f : 1.0f;
-    const float* stage = (c & kCodeItem) ? p.stage_i : p.stage_u;
+    const float* stage = (p.all_items || (c & kCodeItem)) ? p.stage_i : p.stage_u;
     x = rload<VEC>(stage + static_cast<int64_t>(c & kCodeSample) * p.D + chunk * VEC);
   }
   return x;
@@ -871,7 +874,7 @@ __device__ __forceinline__ RVec<VEC> wire_entry(const WireExport& p, uint32_t c,
 
 // d loss / d bias of an entry: items only (the user bias cancels in s+ - s-, see bias_rows_kernel)
 __device__ __forceinline__ float wire_entry_bias(const WireExport& p, uint32_t c) {
-  if (c == kCodeNone || !(c & kCodeItem)) return 0.0f;
+  if (c == kCodeNone || !(p.all_items || (c & kCodeItem))) return 0.0f;
   const float gv = p.gcoef[c & kCodeSample];
   return (c & kCodeNeg) ? -gv : gv;
 }
@@ -891,6 +894,7 @@ __global__ __launch_bounds__(kBlock) void wire_piece_kernel(const WireExport p) 
     const int64_t pc = pc0 + grp;
     if (pc >= npieces) continue;
     const uint32_t start = p.piece_start[pc], end = p.piece_end[pc];
+    if (p.keys[start] < p.key_sub) continue;     // a user row (users local): updated in place
     for (int chunk = lig; chunk < nchunks; chunk += LPR) {
       RVec<VEC> acc;
 #pragma unroll
@@ -937,7 +941,9 @@ __global__ __launch_bounds__(kBlock) void wire_rows_kernel(const WireExport p) {
   const int D = p.D;
   const int nchunks = (D + VEC - 1) / VEC;
   const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
-  for (int64_t seg0 = (static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + threadIdx.x / kWave) * GPW;
+  // (users local: the segments before gfirst[0] are user rows, which are not exported)
+  for (int64_t seg0 = lay.gfirst[0] +
+                      (static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + threadIdx.x / kWave) * GPW;
        seg0 < nseg; seg0 += nwaves * GPW) {
     const int64_t seg = seg0 + grp;
     const bool active = seg < nseg;
@@ -947,7 +953,7 @@ __global__ __launch_bounds__(kBlock) void wire_rows_kernel(const WireExport p) {
       start = p.seg_start[seg];
       end = p.seg_start[seg + 1];
       lbase = p.long_base[seg];
-      key = p.keys[start];
+      key = p.keys[start] - p.key_sub;
     }
     const uint32_t npc = lbase != kNoPiece ? (end - start + kPieceLen - 1) / kPieceLen : 0u;
     if (lbase != kNoPiece) end = start;
@@ -1877,24 +1883,25 @@ extern "C" size_t collie_shard_export_workspace_bytes(int64_t batch) {
 
 extern "C" int collie_shard_export_grads(const collie_mf_tables* t, const collie_mf_batch* b,
                                          void* train_workspace, size_t train_workspace_bytes,
-                                         int32_t world, const int64_t* lookup_counts,
-                                         const int64_t* send_rows, const float* grad_scale,
-                                         float* wire, int64_t wire_rows, int64_t* peer_counts,
-                                         void* workspace, size_t workspace_bytes,
-                                         collie_stream_t stream_) {
+                                         int32_t world, int32_t users_local,
+                                         const int64_t* lookup_counts, const int64_t* send_rows,
+                                         const float* grad_scale, float* wire, int64_t wire_rows,
+                                         int64_t* peer_counts, void* workspace,
+                                         size_t workspace_bytes, collie_stream_t stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   if (validate_tables(t) || validate_batch(b)) return -1;
-  COLLIE_REQUIRE(t->num_users == t->num_items && t->user_emb == t->item_emb,
-                 "export_grads: the tables must be the compact table under both names");
+  if (!users_local)
+    COLLIE_REQUIRE(t->num_users == t->num_items && t->user_emb == t->item_emb,
+                   "export_grads: the tables must be the compact table under both names");
   COLLIE_REQUIRE(send_rows && wire && peer_counts, "export_grads: NULL pointer");
   const int64_t B = b->batch;
   const int D = t->dim;
   COLLIE_REQUIRE(B < (int64_t{1} << 29), "export_grads: batch too large");
   WireBlocks look;
   if (make_blocks(look, lookup_counts, world, D, 1)) return -1;
-  COLLIE_REQUIRE(look.row0[world] <= t->num_users,
+  COLLIE_REQUIRE(look.row0[world] <= t->num_items,
                  "export_grads: the lookup blocks (%lld rows) exceed the compact table (%lld rows)",
-                 static_cast<long long>(look.row0[world]), static_cast<long long>(t->num_users));
+                 static_cast<long long>(look.row0[world]), static_cast<long long>(t->num_items));
   // at most 3B gradient rows; every peer's block has at most 2 (ceil(c / D)) more rows
   const int64_t need_rows = 3 * B + 2 * ((3 * B + D - 1) / D + world);
   COLLIE_REQUIRE(wire_rows >= need_rows, "export_grads: wire holds %lld rows, need %lld",
@@ -1907,14 +1914,22 @@ extern "C" int collie_shard_export_grads(const collie_mf_tables* t, const collie
                  "export workspace too small: need %zu bytes, got %zu", xw.bytes, workspace_bytes);
   auto al16 = [](const void* q) { return reinterpret_cast<uintptr_t>(q) % 16 == 0; };
   const int64_t m = 3 * B;
-  const int64_t nkeys = t->num_users;
-  hipLaunchKernelGGL(wire_rekey_kernel, dim3(static_cast<unsigned>((2 * B + kBlock - 1) / kBlock)),
-                     dim3(kBlock), 0, stream, ws.sort.ekeys, ws.sort.ecodes, B,
-                     static_cast<uint32_t>(t->num_users));
-  if (check_launch("wire_rekey_kernel")) return -2;
-  if (sort_and_segment(ws.sort, nkeys, 0xffffffffu, stream, xw.seg_of)) return -1;
+  int64_t nkeys = t->num_users;
+  uint32_t split = 0xffffffffu, key_sub = 0;
+  if (users_local) {
+    // the forward kernel's own key space: user rows of the shard, then the compact item rows; the
+    // segments of the sort below also serve collie_mf_train_update on the user side
+    nkeys = t->num_users + t->num_items;
+    split = key_sub = static_cast<uint32_t>(t->num_users);
+  } else {
+    hipLaunchKernelGGL(wire_rekey_kernel, dim3(static_cast<unsigned>((2 * B + kBlock - 1) / kBlock)),
+                       dim3(kBlock), 0, stream, ws.sort.ekeys, ws.sort.ecodes, B,
+                       static_cast<uint32_t>(t->num_users));
+    if (check_launch("wire_rekey_kernel")) return -2;
+  }
+  if (sort_and_segment(ws.sort, nkeys, split, stream, xw.seg_of)) return -1;
   hipLaunchKernelGGL(wire_layout_kernel, dim3(1), dim3(64), 0, stream, sorted_keys(ws.sort, nkeys),
-                     xw.seg_of, ws.sort.nseg, m, look, D, xw.lay, peer_counts);
+                     xw.seg_of, ws.sort.nseg, m, look, D, key_sub, xw.lay, peer_counts);
   if (check_launch("wire_layout_kernel")) return -2;
   WireExport p;
   memset(&p, 0, sizeof(p));
@@ -1934,6 +1949,8 @@ extern "C" int collie_shard_export_grads(const collie_mf_tables* t, const collie
   p.send_rows = send_rows;
   p.lay = xw.lay;
   p.wire = wire;
+  p.key_sub = key_sub;
+  p.all_items = users_local ? 1 : 0;
   p.world = world;
   p.D = D;
   const int vec = (D % 4 == 0 && al16(wire) && al16(ws.stage_u) && al16(ws.stage_i)) ? 4 : 1;

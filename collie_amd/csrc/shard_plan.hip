@@ -83,11 +83,18 @@ __device__ __forceinline__ int64_t batch_id(const collie_mf_batch& b, int64_t e,
   return load_idx(b.neg_items, b.neg_dtype, row * b.neg_stride_b + k * b.neg_stride_k);
 }
 
+// local_rank >= 0 ("users are local"): every user of the batch is owned by this rank -- its row is
+// read and updated in place, so only the item ids are planned (entries [B, (2 + K) B) of the batch,
+// stored from 0) and compact_users is simply the local row id / world; a user owned by another rank
+// is reported like an id outside the tables.
 __global__ __launch_bounds__(kBlock) void plan_keys_kernel(const collie_mf_batch b, const Routes r,
+                                                           int local_rank,
                                                            uint32_t* __restrict__ ekeys,
                                                            uint32_t* __restrict__ ecodes,
+                                                           int32_t* __restrict__ cu,
                                                            int64_t* __restrict__ bad_flag) {
   const int64_t total = b.batch * (2 + b.num_neg);
+  const int64_t skip = local_rank >= 0 ? b.batch : 0;
   for (int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; e < total;
        e += static_cast<int64_t>(gridDim.x) * kBlock) {
     int kind;
@@ -98,8 +105,13 @@ __global__ __launch_bounds__(kBlock) void plan_keys_kernel(const collie_mf_batch
       id = id < 0 ? 0 : rows - 1;
     }
     const int64_t owner = id % r.world;
-    ekeys[e] = static_cast<uint32_t>(r.key_base[2 * owner + kind] + id / r.world);
-    ecodes[e] = static_cast<uint32_t>(e);
+    if (e < skip) {
+      if (owner != local_rank) *bad_flag = 1;
+      cu[e] = owner == local_rank ? static_cast<int32_t>(id / r.world) : 0;
+      continue;
+    }
+    ekeys[e - skip] = static_cast<uint32_t>(r.key_base[2 * owner + kind] + id / r.world);
+    ecodes[e - skip] = static_cast<uint32_t>(e);
   }
 }
 
@@ -289,7 +301,8 @@ extern "C" size_t collie_shard_plan_workspace_bytes(int64_t batch, int32_t num_n
 }
 
 extern "C" int collie_shard_plan(const collie_mf_batch* b, int64_t num_users, int64_t num_items,
-                                 int32_t world, int32_t dim, void* workspace, size_t workspace_bytes,
+                                 int32_t world, int32_t dim, int32_t local_rank, void* workspace,
+                                 size_t workspace_bytes,
                                  int32_t* compact_users, int32_t* compact_pos, int64_t* compact_neg,
                                  int64_t* send_rows, int64_t send_capacity, int64_t* route_counts,
                                  collie_stream_t stream_) {
@@ -297,6 +310,7 @@ extern "C" int collie_shard_plan(const collie_mf_batch* b, int64_t num_users, in
   if (validate_batch(b)) return -1;
   COLLIE_REQUIRE(world >= 1 && world <= kMaxWorld, "shard_plan: world must be in [1, %d]", kMaxWorld);
   COLLIE_REQUIRE(dim >= 1, "shard_plan: bad dim");
+  COLLIE_REQUIRE(local_rank >= -1 && local_rank < world, "shard_plan: bad local_rank");
   COLLIE_REQUIRE(num_users >= 1 && num_items >= 1 && num_users + num_items < (int64_t{1} << 31),
                  "shard_plan: bad table sizes");
   COLLIE_REQUIRE(compact_users && compact_pos && compact_neg && send_rows && route_counts,
@@ -316,16 +330,21 @@ extern "C" int collie_shard_plan(const collie_mf_batch* b, int64_t num_users, in
   int64_t grid = (lookups + kBlock - 1) / kBlock;
   if (grid > 8192) grid = 8192;
   hipLaunchKernelGGL(plan_keys_kernel, dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0, stream,
-                     *b, r, ws.sort.ekeys, ws.sort.ecodes, route_counts + nroutes + 1);
+                     *b, r, local_rank, ws.sort.ekeys, ws.sort.ecodes, compact_users,
+                     route_counts + nroutes + 1);
   if (check_launch("plan_keys_kernel")) return -2;
+  // users local: the first B entries of the batch are not planned (the sort sees the item ids only)
+  const int64_t planned = local_rank >= 0 ? lookups - b->batch : lookups;
+  ws.sort.m = planned;
+  ws.sort.ntiles = (planned + kSortTile - 1) / kSortTile;
   const int64_t nkeys = num_users + num_items;
   if (sort_and_segment(ws.sort, nkeys, 0xffffffffu, stream, ws.seg_of)) return -1;
   hipLaunchKernelGGL(plan_layout_kernel, dim3(1), dim3(64), 0, stream, sorted_keys(ws.sort, nkeys),
-                     ws.seg_of, ws.sort.nseg, lookups, r, dim, route_counts, ws.shift);
+                     ws.seg_of, ws.sort.nseg, planned, r, dim, route_counts, ws.shift);
   if (check_launch("plan_layout_kernel")) return -2;
-  hipLaunchKernelGGL(plan_emit_kernel, dim3(static_cast<unsigned>((lookups + kBlock - 1) / kBlock)),
+  hipLaunchKernelGGL(plan_emit_kernel, dim3(static_cast<unsigned>((planned + kBlock - 1) / kBlock)),
                      dim3(kBlock), 0, stream, sorted_keys(ws.sort, nkeys), sorted_vals(ws.sort, nkeys),
-                     ws.seg_of, lookups, b->batch, r, ws.shift, compact_users, compact_pos, compact_neg,
+                     ws.seg_of, planned, b->batch, r, ws.shift, compact_users, compact_pos, compact_neg,
                      send_rows);
   return check_launch("plan_emit_kernel");
 }

@@ -599,7 +599,8 @@ class ShardPlanner:
         self.device = device
         self.buf = None
 
-    def plan(self, users, pos_items, neg_items):
+    def plan(self, users, pos_items, neg_items, local_rank=-1):
+        """local_rank >= 0: this rank owns every user of the batch (only the items are planned)."""
         batch = make_batch(users, pos_items, neg_items)
         B, K = neg_items.shape
         dev = users.device
@@ -615,8 +616,9 @@ class ShardPlanner:
         send_rows = torch.empty(cap, dtype=torch.int64, device=dev)
         counts = torch.empty(2 * self.world + 2, dtype=torch.int64, device=dev)
         check(load().collie_shard_plan(
-            byref(batch), self.num_users, self.num_items, self.world, self.dim, ptr(self.buf),
-            self.buf.numel(), ptr(cu), ptr(cp), ptr(cn), ptr(send_rows), cap, ptr(counts),
+            byref(batch), self.num_users, self.num_items, self.world, self.dim, local_rank,
+            ptr(self.buf), self.buf.numel(), ptr(cu), ptr(cp), ptr(cn), ptr(send_rows), cap,
+            ptr(counts),
             stream_ptr()), 'collie_shard_plan')
         return cu, cp, cn, send_rows, counts
 
@@ -646,7 +648,8 @@ def shard_unpack_bias(buf, peer_counts):
     return out
 
 
-def shard_export_grads(tables, batch, train_ws_buf, lookup_counts, send_rows, grad_scale, workspace):
+def shard_export_grads(tables, batch, train_ws_buf, lookup_counts, send_rows, grad_scale, workspace,
+                       users_local=False):
     """``collie_shard_export_grads``: (wire [rows, dim], peer_counts [world + 1] device int64,
     workspace)."""
     B, D, world = batch.batch, tables.dim, len(lookup_counts)
@@ -659,7 +662,7 @@ def shard_export_grads(tables, batch, train_ws_buf, lookup_counts, send_rows, gr
         workspace = torch.empty(need, dtype=torch.uint8, device=dev)
     check(load().collie_shard_export_grads(
         byref(tables), byref(batch), ptr(train_ws_buf), train_ws_buf.numel(), world,
-        _i64_array(lookup_counts), ptr(send_rows), ptr(grad_scale), ptr(wire), wire_rows,
+        1 if users_local else 0, _i64_array(lookup_counts), ptr(send_rows), ptr(grad_scale), ptr(wire), wire_rows,
         ptr(counts), ptr(workspace), workspace.numel(), stream_ptr()), 'collie_shard_export_grads')
     return wire, counts, workspace
 

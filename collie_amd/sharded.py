@@ -119,12 +119,13 @@ class HipEngine:
         self._row_seg = None
 
     # requester-side plan of one step (collie_shard_plan)
-    def plan(self, model, users, pos_items, neg_items):
+    def plan(self, model, users, pos_items, neg_items, users_local=False):
         if self._planner is None:
             hp = model.hparams
             self._planner = ops.ShardPlanner(hp['num_users'], hp['num_items'], model.comm.world,
                                              hp['embedding_dim'], self.device)
-        return self._planner.plan(users, pos_items, neg_items)
+        return self._planner.plan(users, pos_items, neg_items,
+                                  model.comm.rank if users_local else -1)
 
     def _owner_state(self, model):
         if self._touch is None:
@@ -140,13 +141,18 @@ class HipEngine:
 
     # received lookup buffer + compact ids -> (loss[1], gradient wire buffer, per-owner counts)
     def forward_export(self, model, cw, lookup_counts, send_rows, cu, cp, cn, kind, num_items, codes,
-                       weights, scale):
+                       weights, scale, users_local=False, step=None):
         R, D = cw.shape
         B, K = cn.shape
         cbias = ops.shard_unpack_bias(cw, lookup_counts).view(R, 1)
-        tables = _lib.make_tables(cw, cw, cbias, cbias)     # one table, two id ranges
+        if users_local:     # user rows straight out of this rank's shard, item rows compact
+            nu = model.U_loc
+            tables = _lib.make_tables(model.emb[:nu], cw, model.bias[:nu].view(nu, 1), cbias)
+        else:
+            nu = R
+            tables = _lib.make_tables(cw, cw, cbias, cbias)     # one table, two id ranges
         batch = ops.make_batch(cu, cp, cn)
-        buf = self._train_ws.ensure(B, K, D, R, R)
+        buf = self._train_ws.ensure(B, K, D, nu, R)
         step_id = self._train_ws.next_step()
         cfg = ops.make_loss_cfg(kind, num_items, codes, weights)
         loss = torch.empty(1, dtype=torch.float32, device=self.device)
@@ -156,7 +162,19 @@ class HipEngine:
         if mark is not None:
             mark('gradient_export')     # everything before this mark is K1 (+ its loss finalize)
         wire, counts, self._export_ws = ops.shard_export_grads(
-            tables, batch, buf, lookup_counts, send_rows, scale, self._export_ws)
+            tables, batch, buf, lookup_counts, send_rows, scale, self._export_ws, users_local)
+        if users_local:
+            # the user rows never left: their update runs on the segments the export just built
+            # (the user-bias gradient of a pairwise loss is exactly zero: nothing to do there)
+            hp = model.hparams
+            h = model._HYPER[hp['optimizer']]
+            ocfg = ops.optim_cfg(hp['optimizer'], step, hp['lr'], h.get('beta1', 0.9),
+                                 h.get('beta2', 0.999), h['eps'], 0.0, h.get('lr_decay', 0.0))
+            st = model.state['emb']
+            s1, s2 = st.get('exp_avg', st.get('sum')), st.get('exp_avg_sq')
+            ops.train_update(tables, batch, buf, 0, False, step_id,
+                             {_lib.SIDE_USER: (ocfg, s1[:nu] if s1 is not None else None,
+                                               s2[:nu] if s2 is not None else None, None)}, scale)
         return loss, wire, counts
 
     # optimizer.step() of the combined shard table on the gradient blocks the peers sent
@@ -307,6 +325,30 @@ def shard_batch(batch, rank, world):
     return (users[lo:hi], pos[lo:hi]), neg[lo:hi]
 
 
+def route_batch_to_user_owners(batch, group=None):
+    """
+    Redistributes the ranks' slices of a global batch so that every sample sits on the rank that
+    owns its user row (``user % world``): the slice this function returns can be trained with
+    ``train_step(..., users_local=True)``.  Index plumbing only (96 bytes per sample at K = 10):
+    one count exchange (a host read) and one all-to-all per id tensor.  Samples keep their order
+    inside (source rank, original position); the loss and the updates of a step do not depend on
+    which rank computes a sample, only the floating-point summation order of a row's gradient does.
+    """
+    comm = _Comm(group)
+    (users, pos_items), neg_items = batch
+    if comm.world == 1:
+        return batch
+    G = comm.world
+    owner = users.long() % G
+    order = torch.argsort(owner, stable=True)
+    counts = torch.bincount(owner, minlength=G)
+    got = comm.all_to_all(counts, [1] * G, [1] * G)
+    send_c, recv_c = torch.stack([counts, got]).cpu().tolist()
+    out = [comm.all_to_all(t.index_select(0, order).contiguous(), send_c, recv_c)
+           for t in (users, pos_items, neg_items)]
+    return (out[0], out[1]), out[2]
+
+
 def wire_rows(count, dim, gradient=False):
     """Rows of one peer's block of an exchange buffer (csrc/shard_wire.h): ``count`` embedding (or
     gradient) rows, ``ceil(count / dim)`` rows of bias values and, in the gradient direction, as
@@ -314,17 +356,28 @@ def wire_rows(count, dim, gradient=False):
     return count + (2 if gradient else 1) * ((count + dim - 1) // dim)
 
 
-def plan_torch(users, pos_items, neg_items, U, N, G, dim):
+def plan_torch(users, pos_items, neg_items, U, N, G, dim, local_rank=-1):
     """
     Step 1 of the module docstring with torch index ops (any device; what the gloo tests run).
-    Same outputs, bit for bit, as ``collie_shard_plan`` (``HipEngine.plan``).
+    Same outputs, bit for bit, as ``collie_shard_plan`` (``HipEngine.plan``).  ``local_rank >= 0``:
+    this rank owns every user of the batch, only the items are planned.
     """
     dev = users.device
     B, K = neg_items.shape
+    local_users = None
+    if local_rank >= 0:
+        ul = users.long().clamp(0, U - 1)
+        foreign = ((users.long() != ul) | (ul % G != local_rank))
+        local_users = torch.where(foreign, torch.zeros_like(ul), ul // G).to(torch.int32)
+        users = users[:0]
     uu, inv_u = torch.unique(users.long(), return_inverse=True)
     ui, inv_i = torch.unique(torch.cat([pos_items.long(), neg_items.long().reshape(-1)]),
                              return_inverse=True)
-    bad = (uu[0] < 0) | (uu[-1] >= U) | (ui[0] < 0) | (ui[-1] >= N)
+    bad = (ui[0] < 0) | (ui[-1] >= N)
+    if uu.shape[0]:
+        bad = bad | (uu[0] < 0) | (uu[-1] >= U)
+    if local_users is not None:
+        bad = bad | foreign.any()
     # an id outside the tables stands for the nearest valid row (and is reported): merge it with
     # that row if the batch also holds it
     uu, ui = uu.clamp(0, U - 1), ui.clamp(0, N - 1)
@@ -352,7 +405,7 @@ def plan_torch(users, pos_items, neg_items, U, N, G, dim):
     pad = (per_owner + dim - 1) // dim
     shift = torch.cumsum(pad, 0) - pad
     compact = seg + shift[owner]
-    cu = compact[inv_u].to(torch.int32)
+    cu = compact[inv_u].to(torch.int32) if local_users is None else local_users
     ci = compact[nu + inv_i]
     return (cu, ci[:B].to(torch.int32), ci[B:].reshape(B, K).contiguous(), send_rows, counts)
 
@@ -584,18 +637,19 @@ class ShardedMatrixFactorizationModel:
             steps += name == 'plan'
         return {k: v / max(steps, 1) for k, v in sums.items()}
 
-    def _plan(self, users, pos_items, neg_items):
+    def _plan(self, users, pos_items, neg_items, users_local=False):
         """Steps 1-2 of the module docstring: compact numbering + the request exchange."""
         comm, G = self.comm, self.comm.world
         dev = users.device
         B, K = neg_items.shape
         planner = getattr(self.engine, 'plan', None)
         if planner is not None:
-            cu, cp, cn, send_rows, counts = planner(self, users, pos_items, neg_items)
+            cu, cp, cn, send_rows, counts = planner(self, users, pos_items, neg_items, users_local)
         else:
             cu, cp, cn, send_rows, counts = plan_torch(
                 users, pos_items, neg_items, self.hparams['num_users'],
-                self.hparams['num_items'], G, self.hparams['embedding_dim'])
+                self.hparams['num_items'], G, self.hparams['embedding_dim'],
+                comm.rank if users_local else -1)
         # one small all-to-all: [users, items, B_local, id range flag] per peer
         meta = torch.empty(G, 4, dtype=torch.int64, device=dev)
         meta[:, :2] = counts[:2 * G].reshape(G, 2)
@@ -606,7 +660,9 @@ class ShardedMatrixFactorizationModel:
         # the step.  With plan_ahead() it happens on a side stream while the previous step computes.
         meta_h, got_h = torch.stack([meta, got]).cpu().tolist()
         if any(row[3] for row in got_h):
-            raise IndexError('index out of range in self: a user or item id is outside the tables')
+            raise IndexError('index out of range in self: a user or item id is outside the tables'
+                             + (' (or, with users_local, a user is owned by another rank)'
+                                if users_local else ''))
         send_counts = [r[0] + r[1] for r in meta_h]      # rows this rank requests from each peer
         recv_counts = [r[0] + r[1] for r in got_h]       # rows each peer requests from this rank
         n = sum(send_counts)
@@ -614,9 +670,10 @@ class ShardedMatrixFactorizationModel:
         # rows of the owner's combined table (user rows first, item rows behind them)
         crow = comm.all_to_all(send_rows[:n], send_counts, recv_counts)
         return dict(n=n, B=B, K=K, B_global=B_global, crow=crow, send_counts=send_counts,
-                    recv_counts=recv_counts, cu=cu, cp=cp, cn=cn, send_rows=send_rows)
+                    recv_counts=recv_counts, cu=cu, cp=cp, cn=cn, send_rows=send_rows,
+                    users_local=users_local)
 
-    def plan_ahead(self, batch) -> None:
+    def plan_ahead(self, batch, users_local=False) -> None:
         """
         Optional: plan (steps 1-2) the NEXT ``train_step``'s batch now, on a side stream.  Call it
         right after ``train_step(t)`` returns with the batch of step t + 1: the planner kernels, the
@@ -633,26 +690,27 @@ class ShardedMatrixFactorizationModel:
         if neg_items.dim() == 1:
             neg_items = neg_items.reshape(-1, 1)
         if self.device.type != 'cuda':
-            self._ahead = ((users, pos_items, neg_items), self._plan(users, pos_items, neg_items),
-                           None)
+            self._ahead = ((users, pos_items, neg_items),
+                           self._plan(users, pos_items, neg_items, users_local), None)
             return
         if self._plan_stream is None:
             self._plan_stream = torch.cuda.Stream(device=self.device)
         main = torch.cuda.current_stream(self.device)
         side = self._plan_stream
         with torch.cuda.stream(side):
-            p = self._plan(users, pos_items, neg_items)
+            p = self._plan(users, pos_items, neg_items, users_local)
             ready = torch.cuda.Event()
             ready.record(side)
         for t in (p['crow'], p['cu'], p['cp'], p['cn'], p['send_rows']):
             t.record_stream(main)       # allocated on the side stream, consumed on the main one
         self._ahead = ((users, pos_items, neg_items), p, ready)
 
-    def _take_plan(self, users, pos_items, neg_items):
+    def _take_plan(self, users, pos_items, neg_items, users_local=False):
         ahead, self._ahead = self._ahead, None
         if ahead is not None:
             same = all(a.data_ptr() == b.data_ptr() and a.shape == b.shape
                        for a, b in zip(ahead[0], (users, pos_items, neg_items)))
+            same = same and ahead[1]['users_local'] == users_local
             _, plan, ready = ahead
             if same:
                 if ready is not None:
@@ -660,13 +718,19 @@ class ShardedMatrixFactorizationModel:
                 return plan
             raise RuntimeError('plan_ahead() was called with a different batch than the next '
                                'train_step()')
-        return self._plan(users, pos_items, neg_items)
+        return self._plan(users, pos_items, neg_items, users_local)
 
-    def train_step(self, batch) -> torch.Tensor:
+    def train_step(self, batch, users_local=False) -> torch.Tensor:
         """
         ``calculate_loss`` + ``backward`` + both ``optimizer.step()`` calls for this rank's slice
         ``((users, pos_items), neg_items)`` of the global batch; returns the global-batch loss
         (0-d tensor, identical on every rank).  Collective: every rank must call it.
+
+        ``users_local=True``: the caller guarantees that this rank owns every user of its slice
+        (``user % world == rank``: a loader that hands each rank the interactions of its own users,
+        or ``route_batch_to_user_owners``).  User rows are then read and updated in place -- one
+        of the 2 + K rows a sample looks up and one of its at most 3 gradient rows never travel
+        -- and only item rows are exchanged.  Checked on the device: a foreign user raises.
         """
         (users, pos_items), neg_items = batch
         if neg_items.dim() == 1:
@@ -676,7 +740,7 @@ class ShardedMatrixFactorizationModel:
         D = self.hparams['embedding_dim']
         mark = self._phase_mark
         mark('plan')
-        p = self._take_plan(users, pos_items, neg_items)
+        p = self._take_plan(users, pos_items, neg_items, users_local)
         step = self.steps + 1
         # 3. owners serve the rows: one buffer, one all-to-all
         mark('lookup_exchange')
@@ -694,7 +758,7 @@ class ShardedMatrixFactorizationModel:
         scale = torch.full((1,), p['B'] / p['B_global'], dtype=torch.float32, device=dev)
         loss, gwire, gcounts = eng.forward_export(
             self, cw, p['send_counts'], p['send_rows'], p['cu'], p['cp'], p['cn'], self._loss_kind,
-            self.hparams['num_items'], codes, self._weights, scale)
+            self.hparams['num_items'], codes, self._weights, scale, users_local, step)
         # 5. gradients home: how many rows each owner gets depends on the forward pass (which
         # negative each sample selected), so the counts are exchanged and read back first
         mark('gradient_exchange')

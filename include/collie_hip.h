@@ -392,13 +392,20 @@ int collie_sparse_rows_update_pair_indexed(float* table, float* bias_table, int6
  *   route_counts [2*world + 2] int64: rows per (owner, kind) route; [2*world] = n;
  *                  [2*world + 1] = 1 if an id was outside the tables (it then stands for the
  *                  nearest valid row; the caller raises)
+ * local_rank >= 0 ("users are local"): the caller guarantees that this rank owns every user of the
+ * batch (a loader that hands each rank the interactions of its own users, or
+ * sharded.route_batch_to_user_owners): user rows are then read and updated in place, only the item
+ * ids are planned, compact_users [b] = users[b] / world (the local row), and a user owned by
+ * another rank is reported through route_counts [2*world + 1] like an id outside the tables.
+ * local_rank = -1: users are requested from their owners like items.
  * workspace: collie_shard_plan_workspace_bytes(batch, num_neg, world) bytes (need not be zeroed).
  * world <= 16.
  * ------------------------------------------------------------------------------------------- */
 int64_t collie_shard_wire_rows(const int64_t* counts, int32_t world, int32_t dim, int32_t gradient);
 size_t collie_shard_plan_workspace_bytes(int64_t batch, int32_t num_neg, int32_t world);
 int collie_shard_plan(const collie_mf_batch* b, int64_t num_users, int64_t num_items,
-                      int32_t world, int32_t dim, void* workspace, size_t workspace_bytes,
+                      int32_t world, int32_t dim, int32_t local_rank, void* workspace,
+                      size_t workspace_bytes,
                       int32_t* compact_users, int32_t* compact_pos, int64_t* compact_neg,
                       int64_t* send_rows, int64_t send_capacity, int64_t* route_counts,
                       collie_stream_t stream);
@@ -439,11 +446,18 @@ int collie_shard_unpack_bias(const float* buf, int64_t buf_rows, int32_t dim,
  *   peer_counts [world + 1] int64 (DEVICE, out): gradient rows per owner; [world] = rows of `wire`
  *                  in use.  The caller exchanges the counts and reads them back: the row splits of
  *                  the gradient all-to-all are collie_shard_wire_rows of one count each.
+ * users_local != 0 (collie_shard_plan with local_rank >= 0): t->user_emb / user_bias are this
+ * rank's own user rows [num_users = local users], t->item_emb / item_bias the lookup buffer; only
+ * the item rows are exported, and the call leaves the segments of the whole batch in
+ * train_workspace, so that collie_mf_train_update(t, b, ..., table_mask = 1 << COLLIE_SIDE_USER,
+ * is_bias = 0, ..., grad_scale) applied next updates the user rows in place (no
+ * collie_mf_train_build_segments in between).
  * workspace: collie_shard_export_workspace_bytes(batch). */
 size_t collie_shard_export_workspace_bytes(int64_t batch);
 int collie_shard_export_grads(const collie_mf_tables* t, const collie_mf_batch* b,
                               void* train_workspace, size_t train_workspace_bytes, int32_t world,
-                              const int64_t* lookup_counts, const int64_t* send_rows,
+                              int32_t users_local, const int64_t* lookup_counts,
+                              const int64_t* send_rows,
                               const float* grad_scale, float* wire, int64_t wire_rows,
                               int64_t* peer_counts, void* workspace, size_t workspace_bytes,
                               collie_stream_t stream);

@@ -47,7 +47,7 @@ class CpuOracleEngine:
         return torch.from_numpy(out)
 
     def forward_export(self, model, cw, lookup_counts, send_rows, cu, cp, cn, kind, num_items, codes,
-                       weights, scale):
+                       weights, scale, users_local=False, step=None):
         buf = _np(cw)
         R, D = buf.shape
         first, row0 = self._blocks(lookup_counts, D, 1)
@@ -61,15 +61,24 @@ class CpuOracleEngine:
             dense_of[row0[p]:row0[p] + c] = np.arange(first[p], first[p] + c)
         tables = {'user_embeddings': buf, 'item_embeddings': buf,
                   'user_biases': cbias.reshape(R, 1), 'item_biases': cbias.reshape(R, 1)}
+        if users_local:     # the user rows are this rank's own
+            nu = model.U_loc
+            tables['user_embeddings'] = _np(model.emb)[:nu]
+            tables['user_biases'] = _np(model.bias)[:nu].reshape(nu, 1)
         metadata = {f'm{i}': _np(c) for i, c in enumerate(codes)} or None
         mweights = {f'm{i}': w for i, w in enumerate(weights)} or None
         out = O.calculate_loss(tables, _np(cu), _np(cp), _np(cn), kind, num_items=num_items,
                                metadata=metadata, metadata_weights=mweights)
         s = F32(scale.item())
         gemb = np.zeros((R, D), F32)
-        for name in ('user_embeddings', 'item_embeddings'):
+        for name in ('item_embeddings',) if users_local else ('user_embeddings', 'item_embeddings'):
             rows, vals = out['grads'][name]
             gemb[rows] += vals * s
+        if users_local:     # the user rows never leave: update them here
+            rows, vals = out['grads']['user_embeddings']
+            hp = model.hparams
+            self._rows_update(_np(model.emb), np.asarray(rows, np.int64), vals * s,
+                              hp['optimizer'], step, hp['lr'], model.state['emb'])
         gbias = np.zeros(R, F32)
         rows, vals = out['grads']['item_biases']        # d loss / d user_bias is identically 0
         gbias[rows] = vals[:, 0] * s
@@ -77,7 +86,8 @@ class CpuOracleEngine:
         # sends users, positives and the selected negatives); the other looked-up rows reach the
         # owner's update through the stamps of serve()
         send = np.zeros(R, bool)
-        send[_np(cu)] = True
+        if not users_local:
+            send[_np(cu)] = True
         send[_np(cp)] = True
         send |= (gemb != 0).any(axis=1) | (gbias != 0)
         srows = _np(send_rows)

@@ -18,7 +18,7 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 from collie_amd import metrics as M                      # noqa: E402
 from collie_amd.sharded import (ShardedMatrixFactorizationModel, counter_normal,  # noqa: E402
-                                shard_batch)
+                                route_batch_to_user_owners, shard_batch)
 from oracle import mf_oracle as O                        # noqa: E402
 from sharded_cpu_engine import CpuOracleEngine           # noqa: E402
 
@@ -50,7 +50,9 @@ def full_tables(U, N, D, seed):
     return t
 
 
-def check_training(rank, world, loss, optimizer, bias_optimizer, K, metadata=None):
+def check_training(rank, world, loss, optimizer, bias_optimizer, K, metadata=None, route=False):
+    """route: every sample is moved to the rank that owns its user (route_batch_to_user_owners) and
+    trained with users_local=True -- same global batch, same result."""
     U, N, D, B, steps = 53, 41, 8, 64, 3
     t0 = full_tables(U, N, D, 1)
     weights = {'genre': 0.4} if metadata is not None else None
@@ -73,16 +75,20 @@ def check_training(rank, world, loss, optimizer, bias_optimizer, K, metadata=Non
             pos[B // 2:B // 2 + 4] = pos[0]
         host.append((users, pos, neg))
         batch = ((dev(users.astype(np.int32)), dev(pos.astype(np.int32))), dev(neg))
-        slices.append(shard_batch(batch, rank, world))
+        piece = shard_batch(batch, rank, world)
+        if route:
+            piece = route_batch_to_user_owners(piece)
+            assert bool((piece[0][0].long() % world == rank).all())
+        slices.append(piece)
     for step in range(steps):
         users, pos, neg = host[step]
         kw = {}
         if metadata is not None:
             kw = dict(metadata={'genre': metadata['genre'].cpu().numpy()}, metadata_weights=weights)
         out = ref.step(users, pos, neg, kind, num_items=N, **kw)
-        got = model.train_step(slices[step])
+        got = model.train_step(slices[step], users_local=route)
         if step % 2 == 0 and step + 1 < steps:        # every other step is planned one step ahead
-            model.plan_ahead(slices[step + 1])
+            model.plan_ahead(slices[step + 1], users_local=route)
         np.testing.assert_allclose(got.item(), out['loss'], rtol=2e-5, atol=1e-7)
     sd = model.state_dict()
     for name, want in ref.t.items():
@@ -189,6 +195,13 @@ def check_errors(rank, world):
         pass                                   # every rank learns of it through the exchange
     else:
         raise AssertionError('out-of-range id was not reported')
+    ok = torch.tensor([1, 2, 3, 4], dtype=torch.int32, device=DEV)
+    try:                                       # users 1..4 cannot all belong to one of two ranks
+        model.train_step(((users, ok), neg), users_local=True)
+    except IndexError:
+        pass
+    else:
+        raise AssertionError('a user owned by another rank was not reported')
     try:
         ShardedMatrixFactorizationModel(10, 10, 2, optimizer='adam', device=DEV, engine=engine())
     except ValueError:
@@ -206,6 +219,8 @@ def main():
     check_training(rank, world, 'hinge', 'adagrad', 'adagrad', 1)
     check_training(rank, world, 'warp', 'sgd', 'sgd', 5)
     check_training(rank, world, 'adaptive', 'sparse_adam', 'sparse_adam', 4, {'genre': genre})
+    check_training(rank, world, 'bpr', 'sparse_adam', 'sgd', 10, route=True)
+    check_training(rank, world, 'warp', 'adagrad', 'sparse_adam', 5, {'genre': genre}, route=True)
     check_eval(rank, world)
     check_errors(rank, world)
     dist.barrier()

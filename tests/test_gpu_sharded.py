@@ -36,10 +36,12 @@ def _step(model, opts, batch):
     return loss
 
 
+@pytest.mark.parametrize('users_local', [False, True])
 @pytest.mark.parametrize('loss,optimizer,K,D', [('bpr', 'sparse_adam', 10, 64),
                                                 ('warp', 'adagrad', 5, 32),
                                                 ('hinge', 'sgd', 1, 10)])
-def test_world_1_sharded_step_matches_single_gpu_model(loss, optimizer, K, D):
+def test_world_1_sharded_step_matches_single_gpu_model(loss, optimizer, K, D, users_local):
+    """users_local: user rows are read and updated in place, only item rows take the exchange."""
     from collie_amd.model import MatrixFactorizationModel
     from collie_amd.sharded import ShardedMatrixFactorizationModel
     dev = torch.device('cuda:0')
@@ -60,12 +62,12 @@ def test_world_1_sharded_step_matches_single_gpu_model(loss, optimizer, K, D):
         pos = torch.tensor(rng.zipf(1.2, B) % N, dtype=torch.int32, device=dev)
         neg = torch.tensor(rng.integers(0, N, (B, K)), device=dev)
         l1 = _step(single, opts, ((users, pos), neg))
-        l2 = sharded.train_step(((users, pos), neg))
+        l2 = sharded.train_step(((users, pos), neg), users_local=users_local)
         np.testing.assert_allclose(l2.item(), l1.item(), rtol=1e-6)
     single.check_status()
     # at most user + positive + one negative per sample carry a gradient: only those go home
     sent = sharded.last_exchange['gradient_rows_sent']
-    assert 0 < sent <= 3 * B
+    assert 0 < sent <= (2 if users_local else 3) * B
     assert sent < sharded.last_exchange['rows_requested'] or K == 1
     sd = sharded.state_dict()
     for name in NAMES:
@@ -119,28 +121,40 @@ def test_world_2_on_one_gpu_matches_unsharded_oracle():
     assert 'rank 0: sharded checks ok' in out.stdout and 'rank 1: sharded checks ok' in out.stdout
 
 
+@pytest.mark.parametrize('local_rank', [-1, 0, 2])
 @pytest.mark.parametrize('G', [1, 2, 3, 8])
 @pytest.mark.parametrize('neg_dtype', [torch.int64, torch.int32])
-def test_hip_shard_plan_equals_torch_plan(G, neg_dtype):
+def test_hip_shard_plan_equals_torch_plan(G, neg_dtype, local_rank):
     from collie_amd import ops
     from collie_amd.sharded import plan_torch
     dev = torch.device('cuda:0')
     U, N, B, K, D = 9001, 5003, 3000, 7, 24
+    if local_rank >= G:
+        pytest.skip('rank outside the world')
     rng = np.random.default_rng(G)
     planner = ops.ShardPlanner(U, N, G, D, dev)
     for it in range(3):                                   # the sort scratch is reused
-        users = torch.tensor(rng.zipf(1.2, B) % U, dtype=torch.int32, device=dev)
+        users = rng.zipf(1.2, B) % U
+        if local_rank >= 0:                               # users this rank owns
+            users = np.minimum(users // G * G + local_rank, (U - 1 - local_rank) // G * G + local_rank)
+        users = torch.tensor(users, dtype=torch.int32, device=dev)
         pos = torch.tensor(rng.integers(0, N, B), dtype=torch.int64, device=dev)
         neg = torch.tensor(rng.integers(0, N, (B, K)), device=dev).to(neg_dtype)
         if it == 2:
             neg = neg.t().contiguous().t()                # strided negatives
-        cu, cp, cn, rows, counts = planner.plan(users, pos, neg)
-        tu, tp, tn, trows, tcounts = plan_torch(users, pos, neg, U, N, G, D)
+        cu, cp, cn, rows, counts = planner.plan(users, pos, neg, local_rank)
+        tu, tp, tn, trows, tcounts = plan_torch(users, pos, neg, U, N, G, D, local_rank)
+        assert int(counts[2 * G + 1]) == 0
         assert torch.equal(counts, tcounts)
         n = int(counts[2 * G])
         assert torch.equal(rows[:n], trows)
         assert torch.equal(cu, tu) and torch.equal(cp, tp) and torch.equal(cn, tn)
     bad = pos.clone()
     bad[5] = N
-    counts = planner.plan(users, bad, neg)[4]
+    counts = planner.plan(users, bad, neg, local_rank)[4]
     assert int(counts[2 * G + 1]) == 1
+    if local_rank >= 0 and G > 1:                         # a user of another rank is reported too
+        foreign = users.clone()
+        foreign[7] = (local_rank + 1) % G
+        assert int(planner.plan(foreign, pos, neg, local_rank)[4][2 * G + 1]) == 1
+        assert int(plan_torch(foreign, pos, neg, U, N, G, D, local_rank)[4][2 * G + 1]) == 1
