@@ -311,15 +311,22 @@ def main_sharded(args, world, rank, device):
                                             bias_optimizer='sgd', loss='bpr', device=device, seed=0)
     n_distinct = min(args.steps + args.warmup, 16)
     batches = synthetic_batches(n_distinct, local_batch, device, args.dist, seed=1234 + rank)
+    ul = args.users_local
+    if ul:
+        # every rank trains the interactions of the users it owns (what a loader that partitions
+        # the interactions by user % world hands out; same id distribution): user rows stay local
+        last = (NUM_USERS - 1 - rank) // world * world + rank
+        batches = [((torch.clamp(u // world * world + rank, max=last), p), n)
+                   for (u, p), n in batches]
     for i in range(args.warmup):
-        model.train_step(batches[i % n_distinct])
+        model.train_step(batches[i % n_distinct], users_local=ul)
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        loss = model.train_step(batches[(args.warmup + i) % n_distinct])
+        loss = model.train_step(batches[(args.warmup + i) % n_distinct], users_local=ul)
         if args.plan_ahead and i + 1 < args.steps:  # size the next step's exchanges meanwhile
-            model.plan_ahead(batches[(args.warmup + i + 1) % n_distinct])
+            model.plan_ahead(batches[(args.warmup + i + 1) % n_distinct], users_local=ul)
     dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -327,7 +334,7 @@ def main_sharded(args, world, rank, device):
     # its time on this rank (plan / row exchange / compute / gradient exchange / owner update)
     model.profile_phases(True)
     for i in range(min(args.steps, 10)):
-        model.train_step(batches[i % n_distinct])
+        model.train_step(batches[i % n_distinct], users_local=ul)
     phases = model.phase_times()
     model.profile_phases(False)
     rccl = rccl_selftest(device, world, backend)
@@ -348,7 +355,11 @@ def main_sharded(args, world, rank, device):
                 'batch_per_gpu': local_batch, 'global_batch': local_batch * world,
                 'id_distribution': args.dist,
                 'parallelism': f'tables row-sharded over {world} GPUs (owner = row mod {world}), '
-                               'RCCL all-to-all lookup + gradient exchange',
+                               'RCCL all-to-all lookup + gradient exchange'
+                               + ('; samples sit on the rank that owns their user (user rows are '
+                                  'not exchanged)' if ul else ''),
+                'bytes_per_rank_per_step': {k: model.last_exchange.get(k)
+                                            for k in ('bytes_in', 'bytes_out')},
                 'single_gpu_same_workload': "the 'c4' object of the N=1 line (python bench.py): "
                                             'same tables and global batch on one GPU, fused route',
                 'final_loss': float(loss.item()),
@@ -518,6 +529,9 @@ def main():
                     help='N > 1: do NOT plan step t + 1 on a side stream while step t computes '
                          '(ShardedMatrixFactorizationModel.plan_ahead hides the first host read of '
                          'a step behind the previous one; on by default, see DESIGN.md 6)')
+    ap.add_argument('--no-users-local', dest='users_local', action='store_false',
+                    help='N > 1: draw every rank\'s users from the whole table (user rows then take '
+                         'the exchange like item rows) instead of from the users the rank owns')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--eval-users', type=int, default=65536,
                     help='users in the eval leg (0 = skip it)')
