@@ -103,8 +103,6 @@ SIGNATURES = {
     'collie_mf_train_export_grad': (ctypes.c_int, [POINTER(Tables), POINTER(Batch), c_void_p,
                                                    c_size_t, c_int32, c_int32, c_int32, c_void_p,
                                                    c_void_p, c_void_p, c_void_p, c_void_p]),
-    'collie_mf_train_gradient_rows': (ctypes.c_int, [POINTER(Tables), POINTER(Batch), c_void_p,
-                                                     c_size_t, c_void_p, c_void_p, c_void_p]),
     'collie_mf_train_update_needs_segments': (ctypes.c_int, [POINTER(Tables), POINTER(Batch),
                                                              c_int32]),
     'collie_mf_train_update_all': (ctypes.c_int, [POINTER(Tables), POINTER(Batch), c_void_p,
@@ -123,21 +121,6 @@ SIGNATURES = {
                                                     c_size_t, c_void_p, c_void_p, c_void_p]),
     'collie_mf_batch_copy': (ctypes.c_int, [POINTER(Batch), POINTER(Batch), c_void_p]),
     'collie_sparse_rows_workspace_bytes': (c_size_t, [c_int64, c_int32]),
-    'collie_sparse_rows_update': (ctypes.c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int32,
-                                                 c_void_p, c_int64, POINTER(OptimCfg), c_void_p,
-                                                 c_void_p, c_void_p, c_size_t, c_void_p,
-                                                 c_void_p]),
-    'collie_sparse_rows_update_pair': (ctypes.c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p,
-                                                      c_int32, c_void_p, c_void_p, c_int64,
-                                                      POINTER(OptimCfg), POINTER(OptimCfg), c_void_p,
-                                                      c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
-                                                      c_void_p, c_void_p]),
-    'collie_sparse_rows_update_pair_indexed': (ctypes.c_int, [c_void_p, c_void_p, c_int64, c_int32,
-                                                              c_void_p, c_int32, c_void_p, c_void_p,
-                                                              c_void_p, c_int64, POINTER(OptimCfg),
-                                                              POINTER(OptimCfg), c_void_p, c_void_p,
-                                                              c_void_p, c_void_p, c_void_p, c_size_t,
-                                                              c_void_p, c_void_p]),
     'collie_shard_wire_rows': (c_int64, [c_void_p, c_int32, c_int32, c_int32]),
     'collie_shard_plan_workspace_bytes': (c_size_t, [c_int64, c_int32, c_int32]),
     'collie_shard_plan': (ctypes.c_int, [POINTER(Batch), c_int64, c_int64, c_int32, c_int32, c_int32,

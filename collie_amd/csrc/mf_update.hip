@@ -740,26 +740,10 @@ __global__ __launch_bounds__(kBlock) void export_touched_kernel(const uint8_t* _
   if (i < rows) out[i] = touch[i] == touch_tag(step) ? 1 : 0;
 }
 
-// rows that own a segment of the sorted batch = rows some (sample, role) entry points at: the only
-// rows whose gradient can differ from zero (the row-sharded step sends just these home)
-__global__ __launch_bounds__(kBlock) void mark_gradient_rows_kernel(
-    const uint32_t* __restrict__ keys, const uint32_t* __restrict__ seg_start,
-    const uint32_t* __restrict__ nseg, uint32_t split, uint8_t* __restrict__ user_mask,
-    uint8_t* __restrict__ item_mask) {
-  const uint32_t s = blockIdx.x * kBlock + threadIdx.x;
-  if (s >= nseg[0]) return;
-  const uint32_t key = keys[seg_start[s]];
-  if (key < split) user_mask[key] = 1;
-  else item_mask[key - split] = 1;
-}
-
 // entries of a stand-alone sparse gradient: key = row id (clamped), code = position in vals
-// (val_index == NULL: entry i owns vals row i; else vals row val_index[i], < 0: a looked-up row with
-// a zero gradient, which is touched but reads nothing)
 __global__ __launch_bounds__(kBlock) void coo_entries_kernel(const void* __restrict__ rows,
                                                              int dtype, int64_t m,
                                                              int64_t num_rows,
-                                                             const int32_t* __restrict__ val_index,
                                                              uint32_t* __restrict__ ekeys,
                                                              uint32_t* __restrict__ ecodes,
                                                              int32_t* __restrict__ status) {
@@ -767,7 +751,6 @@ __global__ __launch_bounds__(kBlock) void coo_entries_kernel(const void* __restr
   if (i >= m) return;
   int64_t r = load_idx(rows, dtype, i);
   uint32_t code = static_cast<uint32_t>(i);
-  if (val_index) code = val_index[i] < 0 ? kCodeNone : static_cast<uint32_t>(val_index[i]);
   if (r < 0 || r >= num_rows) {
     if (status) atomicOr(status, 1);
     r = 0;
@@ -1676,143 +1659,12 @@ extern "C" int collie_mf_train_export_grad(const collie_mf_tables* t, const coll
   return 0;
 }
 
-extern "C" int collie_mf_train_gradient_rows(const collie_mf_tables* t, const collie_mf_batch* b,
-                                             void* workspace, size_t workspace_bytes,
-                                             uint8_t* user_mask, uint8_t* item_mask,
-                                             collie_stream_t stream_) {
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
-  if (validate_tables(t) || validate_batch(b)) return -1;
-  COLLIE_REQUIRE(user_mask && item_mask, "gradient_rows: NULL mask");
-  TrainWs ws = carve_train_ws(workspace, b->batch, b->num_neg, t->dim, t->num_users, t->num_items);
-  COLLIE_REQUIRE(workspace != nullptr && workspace_bytes >= ws.bytes,
-                 "workspace too small: need %zu bytes, got %zu", ws.bytes, workspace_bytes);
-  const int64_t m = 3 * b->batch;
-  const int64_t nkeys = t->num_users + t->num_items;
-  hipLaunchKernelGGL(mark_gradient_rows_kernel, dim3(static_cast<unsigned>((m + kBlock - 1) / kBlock)),
-                     dim3(kBlock), 0, stream, sorted_keys(ws.sort, nkeys), ws.sort.seg_start,
-                     ws.sort.nseg, static_cast<uint32_t>(t->num_users), user_mask, item_mask);
-  return check_launch("mark_gradient_rows_kernel");
-}
-
 extern "C" size_t collie_sparse_rows_workspace_bytes(int64_t m, int32_t dim) {
   if (m < 1 || dim < 1) return 0;
   Carver c(nullptr);
   SortWs s;
   carve_sort_ws(c, s, m, dim);
   return align_up(c.off, 256);
-}
-
-extern "C" int collie_sparse_rows_update(float* table, int64_t num_rows, int32_t dim,
-                                         const void* rows, int32_t rows_dtype, const float* vals,
-                                         int64_t m, const collie_optim_cfg* cfg, float* state1,
-                                         float* state2, void* workspace, size_t workspace_bytes,
-                                         int32_t* status, collie_stream_t stream_) {
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
-  COLLIE_REQUIRE(table && rows && vals && cfg, "sparse_rows_update: NULL pointer");
-  COLLIE_REQUIRE(num_rows >= 1 && num_rows < (int64_t{1} << 31) && dim >= 1,
-                 "sparse_rows_update: bad table shape");
-  COLLIE_REQUIRE(m >= 1 && m < (int64_t{1} << 30), "sparse_rows_update: bad entry count");
-  Carver c(workspace);
-  SortWs s;
-  carve_sort_ws(c, s, m, dim);
-  COLLIE_REQUIRE(workspace && workspace_bytes >= align_up(c.off, 256),
-                 "workspace too small: need %zu bytes, got %zu", align_up(c.off, 256),
-                 workspace_bytes);
-  hipLaunchKernelGGL(coo_entries_kernel, dim3(static_cast<unsigned>((m + kBlock - 1) / kBlock)),
-                     dim3(kBlock), 0, stream, rows, rows_dtype, m, num_rows, nullptr, s.ekeys,
-                     s.ecodes, status);
-  if (check_launch("coo_entries_kernel")) return -2;
-  if (sort_and_segment(s, num_rows, 0xffffffffu, stream)) return -1;
-  UpdParams p;
-  memset(&p, 0, sizeof(p));
-  fill_sorted(p, s, num_rows, 0xffffffffu);
-  p.D = dim;
-  p.step = cfg->step;
-  TableDesc& d = p.d[0];
-  d.table = table;
-  d.stage = vals;
-  d.s1 = cfg->algo == COLLIE_OPT_SGD ? nullptr : state1;
-  d.s2 = cfg->algo == COLLIE_OPT_SPARSE_ADAM ? state2 : nullptr;
-  COLLIE_REQUIRE(cfg->algo != COLLIE_OPT_ADAM,
-                 "Adam does not support sparse gradients, please consider SparseAdam instead");
-  if (make_hyper(d.h, cfg, 0, true, d.s1, d.s2)) return -1;
-  if (dim == 1) {
-    if (!small_coalesce(m))
-      hipLaunchKernelGGL(piece_bias_kernel<false>, dim3(piece_bias_grid(m)), dim3(kBlock), 0, stream,
-                       p);
-    hipLaunchKernelGGL(bias_rows_kernel<false>, dim3(bias_grid(m)), dim3(kBlock), 0, stream, p);
-    return check_launch("sparse_rows_update");
-  }
-  return launch_emb<false>(p, m, stream);
-}
-
-extern "C" int collie_sparse_rows_update_pair_indexed(
-    float* table, float* bias_table, int64_t num_rows, int32_t dim, const void* rows,
-    int32_t rows_dtype, const int32_t* val_index, const float* vals, const float* bias_vals, int64_t m,
-                                              const collie_optim_cfg* cfg,
-                                              const collie_optim_cfg* bias_cfg, float* state1,
-                                              float* state2, float* bias_state1, float* bias_state2,
-                                              void* workspace, size_t workspace_bytes,
-                                              int32_t* status, collie_stream_t stream_) {
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
-  COLLIE_REQUIRE(table && bias_table && rows && vals && bias_vals && cfg && bias_cfg,
-                 "sparse_rows_update_pair: NULL pointer");
-  COLLIE_REQUIRE(num_rows >= 1 && num_rows < (int64_t{1} << 31) && dim >= 2,
-                 "sparse_rows_update_pair: bad table shape");
-  COLLIE_REQUIRE(m >= 1 && m < (int64_t{1} << 30), "sparse_rows_update_pair: bad entry count");
-  COLLIE_REQUIRE(cfg->algo != COLLIE_OPT_ADAM && bias_cfg->algo != COLLIE_OPT_ADAM,
-                 "Adam does not support sparse gradients, please consider SparseAdam instead");
-  Carver c(workspace);
-  SortWs s;
-  carve_sort_ws(c, s, m, dim);
-  COLLIE_REQUIRE(workspace && workspace_bytes >= align_up(c.off, 256),
-                 "workspace too small: need %zu bytes, got %zu", align_up(c.off, 256),
-                 workspace_bytes);
-  hipLaunchKernelGGL(coo_entries_kernel, dim3(static_cast<unsigned>((m + kBlock - 1) / kBlock)),
-                     dim3(kBlock), 0, stream, rows, rows_dtype, m, num_rows, val_index, s.ekeys,
-                     s.ecodes, status);
-  if (check_launch("coo_entries_kernel")) return -2;
-  if (sort_and_segment(s, num_rows, 0xffffffffu, stream)) return -1;
-  // the two tables share the row list, so one coalesce serves both updates
-  UpdParams p;
-  memset(&p, 0, sizeof(p));
-  fill_sorted(p, s, num_rows, 0xffffffffu);
-  p.D = dim;
-  p.step = cfg->step;
-  p.d[0].table = table;
-  p.d[0].stage = vals;
-  p.d[0].s1 = cfg->algo == COLLIE_OPT_SGD ? nullptr : state1;
-  p.d[0].s2 = cfg->algo == COLLIE_OPT_SPARSE_ADAM ? state2 : nullptr;
-  if (make_hyper(p.d[0].h, cfg, 0, true, p.d[0].s1, p.d[0].s2)) return -1;
-  UpdParams q;
-  memset(&q, 0, sizeof(q));
-  fill_sorted(q, s, num_rows, 0xffffffffu);
-  q.D = 1;
-  q.step = bias_cfg->step;
-  q.d[0].table = bias_table;
-  q.d[0].stage = bias_vals;
-  q.d[0].s1 = bias_cfg->algo == COLLIE_OPT_SGD ? nullptr : bias_state1;
-  q.d[0].s2 = bias_cfg->algo == COLLIE_OPT_SPARSE_ADAM ? bias_state2 : nullptr;
-  if (make_hyper(q.d[0].h, bias_cfg, 0, true, q.d[0].s1, q.d[0].s2)) return -1;
-  if (launch_emb<false>(p, m, stream)) return -2;
-  if (!small_coalesce(m))
-    hipLaunchKernelGGL(piece_bias_kernel<false>, dim3(piece_bias_grid(m)), dim3(kBlock), 0, stream, q);
-  hipLaunchKernelGGL(bias_rows_kernel<false>, dim3(bias_grid(m)), dim3(kBlock), 0, stream, q);
-  return check_launch("sparse_rows_update_pair");
-}
-
-extern "C" int collie_sparse_rows_update_pair(float* table, float* bias_table, int64_t num_rows,
-                                              int32_t dim, const void* rows, int32_t rows_dtype,
-                                              const float* vals, const float* bias_vals, int64_t m,
-                                              const collie_optim_cfg* cfg,
-                                              const collie_optim_cfg* bias_cfg, float* state1,
-                                              float* state2, float* bias_state1, float* bias_state2,
-                                              void* workspace, size_t workspace_bytes,
-                                              int32_t* status, collie_stream_t stream) {
-  return collie_sparse_rows_update_pair_indexed(table, bias_table, num_rows, dim, rows, rows_dtype,
-                                                nullptr, vals, bias_vals, m, cfg, bias_cfg, state1,
-                                                state2, bias_state1, bias_state2, workspace,
-                                                workspace_bytes, status, stream);
 }
 
 // ---- row-sharded step ----------------------------------------------------------------------------------
@@ -2137,7 +1989,7 @@ extern "C" int collie_dense_rows_update(float* table, int64_t num_rows, int32_t 
                  "workspace too small: need %zu bytes, got %zu", align_up(c.off, 256),
                  workspace_bytes);
   hipLaunchKernelGGL(coo_entries_kernel, dim3(static_cast<unsigned>((m + kBlock - 1) / kBlock)),
-                     dim3(kBlock), 0, stream, rows, rows_dtype, m, num_rows, nullptr, s.ekeys,
+                     dim3(kBlock), 0, stream, rows, rows_dtype, m, num_rows, s.ekeys,
                      s.ecodes, status);
   if (check_launch("coo_entries_kernel")) return -2;
   if (sort_and_segment(s, num_rows, 0xffffffffu, stream)) return -1;

@@ -234,59 +234,6 @@ def train_export_grad(tables, batch, ws_buf, side, is_bias, step_id):
     return all_rows, full
 
 
-def train_gradient_rows(tables, batch, ws_buf, user_mask, item_mask):
-    """Marks (uint8 = 1) the rows that own gradient entries of the segmented batch."""
-    check(load().collie_mf_train_gradient_rows(
-        byref(tables), byref(batch), ptr(ws_buf), ws_buf.numel(), ptr(user_mask), ptr(item_mask),
-        stream_ptr()), 'collie_mf_train_gradient_rows')
-
-
-def sparse_rows_update(table, rows, vals, cfg, state1=None, state2=None, status=None,
-                       workspace=None):
-    """``optimizer.step()`` of SGD / Adagrad / SparseAdam on an uncoalesced COO gradient."""
-    require_hip(table, 'table')
-    rows = rows.contiguous()
-    vals = vals.contiguous().float()
-    m = rows.shape[0]
-    if m == 0:
-        return workspace
-    dim = table.shape[1] if table.dim() == 2 else 1
-    need = int(load().collie_sparse_rows_workspace_bytes(m, dim))
-    if workspace is None or workspace.numel() < need:
-        workspace = torch.empty(need, dtype=torch.uint8, device=table.device)
-    check(load().collie_sparse_rows_update(
-        ptr(table), table.shape[0], dim, ptr(rows), idx_dtype(rows), ptr(vals), m, byref(cfg),
-        ptr(state1), ptr(state2), ptr(workspace), workspace.numel(), ptr(status), stream_ptr()),
-        'collie_sparse_rows_update')
-    return workspace
-
-
-def sparse_rows_update_pair(table, bias_table, rows, vals, bias_vals, cfg, bias_cfg, state,
-                            bias_state, status=None, workspace=None, val_index=None):
-    """``sparse_rows_update`` for an embedding table and its bias table over one row list: one
-    coalesce, two updates (``collie_sparse_rows_update_pair``).  state = (state1, state2)."""
-    require_hip(table, 'table')
-    rows = rows.contiguous()
-    vals = vals.contiguous().float()
-    bias_vals = bias_vals.contiguous().float()
-    m = rows.shape[0]
-    if m == 0:
-        return workspace
-    dim = table.shape[1]
-    need = int(load().collie_sparse_rows_workspace_bytes(m, dim))
-    if workspace is None or workspace.numel() < need:
-        workspace = torch.empty(need, dtype=torch.uint8, device=table.device)
-    if val_index is not None:
-        assert val_index.dtype == torch.int32 and val_index.shape[0] == m
-        val_index = val_index.contiguous()
-    check(load().collie_sparse_rows_update_pair_indexed(
-        ptr(table), ptr(bias_table), table.shape[0], dim, ptr(rows), idx_dtype(rows),
-        ptr(val_index), ptr(vals), ptr(bias_vals), m, byref(cfg), byref(bias_cfg), ptr(state[0]),
-        ptr(state[1]), ptr(bias_state[0]), ptr(bias_state[1]), ptr(workspace), workspace.numel(),
-        ptr(status), stream_ptr()), 'collie_sparse_rows_update_pair_indexed')
-    return workspace
-
-
 def optim_cfg(algo, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, lr_decay=0.0):
     return OptimCfg(_lib.OPT_ALGOS[algo] if isinstance(algo, str) else int(algo), int(step),
                     float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),

@@ -9,7 +9,7 @@ Layout.  One process per GPU.  Global row ``r`` of a table lives on rank ``r mod
 ``r div G`` (round robin: balanced under Zipf-distributed ids).  A rank keeps its user rows and its
 item rows in ONE combined table ``emb [U_loc + N_loc, D]`` (user rows first) with a parallel
 ``bias [U_loc + N_loc]`` and parallel optimizer state, so that a request for rows of both kinds is one
-gather and the owner-side optimizer step is one ``collie_sparse_rows_update`` call.
+gather and the owner-side optimizer step is one ``collie_shard_owner_update`` call.
 
 Training step on a rank (``train_step``), for its slice of the global batch:
   1. distinct user rows and item rows of the slice (positives and all K negatives), ordered by

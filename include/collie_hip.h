@@ -312,54 +312,9 @@ int collie_mf_train_export_grad(const collie_mf_tables* t, const collie_mf_batch
                                 float* vals_out, int32_t* count_out, uint8_t* touched_out,
                                 collie_stream_t stream);
 
-/* Rows that own gradient entries of the batch, after collie_mf_train_build_segments: sets
- * user_mask[u] = 1 / item_mask[i] = 1 (uint8 [num_users] / [num_items], zeroed by the caller; both
- * may be one array when the two id ranges share a table) for the users, positives and the one
- * negative per sample a loss selected -- a superset of the rows whose gradient is not zero.  The
- * row-sharded step (reference: the sparse gradient of nn.Embedding(sparse=True),
- * collie/model/matrix_factorization.py:105-118, whose COO rows these are) sends only these home. */
-int collie_mf_train_gradient_rows(const collie_mf_tables* t, const collie_mf_batch* b,
-                                  void* workspace, size_t workspace_bytes, uint8_t* user_mask,
-                                  uint8_t* item_mask, collie_stream_t stream);
-
-/* torch.optim.{SparseAdam,Adagrad,SGD}.step on an UNCOALESCED sparse COO gradient of one table
- * (torch/optim/_functional.py:41-84): rows [m] (int32/int64) with values vals [m, dim].  Sorts,
- * sums duplicates in input order (deterministic) and updates the rows in place.  Used by the
- * row-sharded multi-GPU step (owners apply the gradient rows they receive) and by the generic
- * route.  workspace: collie_sparse_rows_workspace_bytes(m, dim) bytes (need not be zeroed). */
+/* Scratch of the stand-alone row-list updates (collie_dense_rows_update): sort + segment buffers
+ * for m (row, value) entries of width dim (need not be zeroed). */
 size_t collie_sparse_rows_workspace_bytes(int64_t m, int32_t dim);
-int collie_sparse_rows_update(float* table, int64_t num_rows, int32_t dim, const void* rows,
-                              int32_t rows_dtype, const float* vals, int64_t m,
-                              const collie_optim_cfg* cfg, float* state1, float* state2,
-                              void* workspace, size_t workspace_bytes, int32_t* status,
-                              collie_stream_t stream);
-
-/* The same step for an embedding table [num_rows, dim] and its bias table [num_rows, 1] whose
- * gradients share ONE row list (the owner side of the row-sharded step: every received row carries
- * an embedding gradient and a bias gradient): one coalesce, two updates.  Equivalent to two
- * collie_sparse_rows_update calls, without the second sort.  workspace as above for (m, dim). */
-int collie_sparse_rows_update_pair(float* table, float* bias_table, int64_t num_rows, int32_t dim,
-                                   const void* rows, int32_t rows_dtype, const float* vals,
-                                   const float* bias_vals, int64_t m, const collie_optim_cfg* cfg,
-                                   const collie_optim_cfg* bias_cfg, float* state1, float* state2,
-                                   float* bias_state1, float* bias_state2, void* workspace,
-                                   size_t workspace_bytes, int32_t* status, collie_stream_t stream);
-
-/* collie_sparse_rows_update_pair with the gradient values given indirectly: entry e of `rows` owns
- * row val_index[e] of vals / bias_vals, or no value at all if val_index[e] < 0 -- a row that was
- * looked up but received a zero gradient: it is still touched (SparseAdam decays its moments), but
- * nothing is read for it.  The row-sharded step sends home only the gradient rows that are not zero
- * (about a quarter of the looked-up rows with 10 negatives per positive) and the owner marks the
- * rest of the rows it served this way.  val_index == NULL: the identity. */
-int collie_sparse_rows_update_pair_indexed(float* table, float* bias_table, int64_t num_rows,
-                                           int32_t dim, const void* rows, int32_t rows_dtype,
-                                           const int32_t* val_index, const float* vals,
-                                           const float* bias_vals, int64_t m,
-                                           const collie_optim_cfg* cfg,
-                                           const collie_optim_cfg* bias_cfg, float* state1,
-                                           float* state2, float* bias_state1, float* bias_state2,
-                                           void* workspace, size_t workspace_bytes, int32_t* status,
-                                           collie_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Row-sharded training (no counterpart in the reference, which has no multi-GPU path for the
