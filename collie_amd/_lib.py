@@ -16,7 +16,7 @@ I32, I64 = 0, 1
 LOSS_BPR, LOSS_HINGE, LOSS_ADAPTIVE_BPR, LOSS_ADAPTIVE_HINGE, LOSS_WARP = range(5)
 OPT_SGD, OPT_ADAGRAD, OPT_SPARSE_ADAM, OPT_ADAM = range(4)
 SIDE_USER, SIDE_ITEM = 0, 1
-MAX_META = 4
+MAX_META = 16
 MAX_NEG = 63
 
 LOSS_KINDS = {'bpr': LOSS_BPR, 'hinge': LOSS_HINGE, 'adaptive_bpr': LOSS_ADAPTIVE_BPR,

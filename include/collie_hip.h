@@ -59,7 +59,7 @@ enum { COLLIE_SIDE_USER = 0, COLLIE_SIDE_ITEM = 1 };
 /* explicit-feedback losses (collie/model/base/base_pipeline.py:287-292) */
 enum { COLLIE_EXPLICIT_MSE = 0, COLLIE_EXPLICIT_MAE = 1 };
 
-#define COLLIE_MAX_META 4
+#define COLLIE_MAX_META 16
 #define COLLIE_MAX_NEG 63 /* fused training path: one wave lane per (positive|negative) score */
 
 /* The four parameter tables of MatrixFactorizationModel._setup_model

@@ -163,6 +163,40 @@ def test_fused_calculate_loss_and_grads_vs_reference(golden_dir, dev):
                     close(vals.cpu().numpy(), ref, scale=gscale)
 
 
+@pytest.mark.parametrize('kind,K,D', [('adaptive_bpr', 6, 64), ('warp', 5, 128), ('hinge', 1, 10)])
+def test_fused_loss_with_many_metadata_arrays_vs_oracle(dev, kind, K, D):
+    """``metadata_for_loss`` is a dict of any size in the reference
+    (metadata_utils.py:60-71); the fused kernels take up to COLLIE_MAX_META = 16 arrays."""
+    from oracle import mf_oracle as O
+    from collie_amd import _lib, ops
+    assert _lib.MAX_META == 16
+    U, N, B, M = 300, 200, 512, 7
+    rng = np.random.default_rng(K)
+    t = O.init_tables(U, N, D, rng)
+    t['user_embeddings'] *= 8
+    t['item_embeddings'] *= 8
+    t['item_biases'] = (rng.standard_normal((N, 1)) * 0.05).astype(np.float32)
+    metadata = {f'm{i}': rng.integers(0, 2 + i, N) for i in range(M)}
+    weights = {f'm{i}': 0.05 + 0.02 * i for i in range(M)}          # sum 0.77 <= 1
+    users = rng.integers(0, U, B)
+    pos = rng.integers(0, N, B)
+    neg = rng.integers(0, N, (B, K))
+    want = O.calculate_loss(t, users, pos, neg, kind, num_items=N, metadata=metadata,
+                            metadata_weights=weights)
+    td = to_dev({n: t[n] for n in NAMES}, dev)
+    codes = [torch.tensor(metadata[f'm{i}'], dtype=torch.int32, device=dev) for i in range(M)]
+    f = Fused(td, torch.tensor(users, dtype=torch.int32, device=dev),
+              torch.tensor(pos, dtype=torch.int32, device=dev), torch.tensor(neg, device=dev), kind,
+              dev, codes=codes, weights=[weights[f'm{i}'] for i in range(M)])
+    close(f.loss.item(), want['loss'])
+    gscale = max(np.abs(want['grads']['item_embeddings'][1]).max(), 1e-12)
+    rows, vals = f.export(_lib.SIDE_ITEM, False)
+    np.testing.assert_array_equal(rows.cpu().numpy(), want['grads']['item_embeddings'][0])
+    close(vals.cpu().numpy(), want['grads']['item_embeddings'][1], scale=gscale)
+    with pytest.raises(ValueError):
+        ops.make_loss_cfg(kind, N, codes * 3, [0.01] * (3 * M))
+
+
 ALGO_STATE = {'sparse_adam': ('exp_avg', 'exp_avg_sq'), 'adam': ('exp_avg', 'exp_avg_sq'),
               'adagrad': ('sum', None), 'sgd': (None, None)}
 
