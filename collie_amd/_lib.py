@@ -150,6 +150,13 @@ SIGNATURES = {
     'collie_mf_eval_topk_static': (ctypes.c_int, [POINTER(Tables), c_void_p, c_int64, c_int64,
                                                   c_int64, c_int64, c_int64, c_int32, c_int32,
                                                   c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    'collie_mf_eval_bf16x3_ok': (c_int32, [c_int32, c_int32]),
+    'collie_mf_eval_split_bf16x3': (ctypes.c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
+    'collie_mf_eval_bf16x3_workspace_bytes': (c_size_t, [c_int64, c_int64]),
+    'collie_mf_eval_topk_bf16x3': (ctypes.c_int, [POINTER(Tables), c_void_p, c_void_p, c_int64,
+                                                  c_int64, c_int64, c_int64, c_int64, c_int32,
+                                                  c_int32, c_float, c_float, c_void_p, c_void_p,
+                                                  c_void_p, c_size_t, c_void_p]),
     'collie_mf_eval_merge_topk': (ctypes.c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32,
                                                  c_void_p, c_void_p, c_void_p]),
     'collie_mf_eval_pos_scores': (ctypes.c_int, [POINTER(Tables), c_void_p, c_int64, c_void_p,

@@ -667,6 +667,274 @@ __global__ __launch_bounds__(kBlockDma) void eval_gemm_dma_kernel(const EvalPara
   }
 }
 
+// ---- K6c: the MAP@k scoring pass on bf16 MFMA, split x 3 (COLLIE_EVAL_BF16X3, opt-in) --------------
+// x = hi + mid + lo with hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid) carries 24
+// significant bits, so  u . i ~= sum over the six products of total order <= 2 (hi hi, hi mid,
+// mid hi, mid mid, hi lo, lo hi) -- each one v_mfma_f32_32x32x16_bf16 accumulating in f32 -- agrees
+// with the f32 dot product to a few ulp, at 6 x 32 cycles per 16 k against 8 x 64 cycles on the f32
+// instruction (2.7x fewer MFMA cycles).  The scores of this pass are NOT the reference's bits, so
+// they only RANK: every slot keeps its 16 best candidates, the merge keeps 16 per user, those are
+// re-scored with the exact chain (chain_dot: the bits of the f32 pass) and the k <= 12 best of the
+// re-scored list are emitted in (score desc, id asc) order.  A result differs from the f32 pass only
+// if an item of the true top-k ranks below 16th in the approximate order, i.e. if more than 16 - k
+// items sit within ~1e-7 (relative) of the k-th score.
+// Same geometry as eval_gemm_dma_kernel: 8 waves = 256 users per workgroup share a 64-item tile that
+// LDS-DMA writes into one of two buffers; an item's three bf16 rows are contiguous in the split
+// table ([num_items, 3, dim] bf16, collie_mf_eval_split_bf16x3), 16-byte chunk c of split s of tile
+// row r lives at slot r * RC + s * CPR + (c ^ (r % S)).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ uint32_t bf16_rne(float x) {
+  const uint32_t u = __float_as_uint(x);
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+// x -> (hi, mid, lo) bf16 bit patterns; the two residuals are exact in f32
+__device__ __forceinline__ void split_bf16x3(float x, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+  hi = bf16_rne(x);
+  const float r1 = x - __uint_as_float(hi << 16);
+  mid = bf16_rne(r1);
+  const float r2 = r1 - __uint_as_float(mid << 16);
+  lo = bf16_rne(r2);
+}
+
+__global__ __launch_bounds__(kBlock) void split_bf16x3_kernel(const float* __restrict__ src,
+                                                              int64_t rows, int dim,
+                                                              uint16_t* __restrict__ out) {
+  const int64_t total = rows * dim;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < total; i += stride) {
+    const int64_t r = i / dim;
+    const int c = static_cast<int>(i - r * dim);
+    uint32_t hi, mid, lo;
+    split_bf16x3(src[i], hi, mid, lo);
+    uint16_t* o = out + r * 3 * dim + c;
+    o[0] = static_cast<uint16_t>(hi);
+    o[dim] = static_cast<uint16_t>(mid);
+    o[2 * dim] = static_cast<uint16_t>(lo);
+  }
+}
+
+struct Bf16Params {
+  EvalParams e;
+  const uint16_t* item_split;   // [num_items, 3, dim] bf16
+};
+
+template <int D16>
+__global__ __launch_bounds__(kBlockDma) void eval_gemm_bf16x3_kernel(const Bf16Params bp) {
+  const EvalParams& p = bp.e;
+  constexpr int D = D16 * 16;
+  constexpr int CPR = D / 8;                     // 16-byte chunks per bf16 row
+  constexpr int RC = 3 * CPR;                    // chunks per item (hi, mid, lo rows)
+  constexpr int S = CPR < 16 ? CPR : 16;         // swizzle span
+  constexpr int kTileF4 = kTileItems * RC;
+  constexpr int kPerWave = RC / kWavesDma;
+  constexpr int kBufF4 = kTileF4 + kTileItems / 4;
+  static_assert(kPerWave * kWavesDma == RC, "embedding_dim 64 or 128");
+  __shared__ float4 smem[2 * kBufF4];
+
+  const int lane = lane_id();
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const int col = lane & 31;
+  const int h = lane >> 5;
+
+  const int64_t uslot = static_cast<int64_t>(blockIdx.x) * kUsersPerBlockDma + wave * 32 + col;
+  const bool user_ok = uslot < p.n_users;
+  int64_t uid = p.user_ids[user_ok ? uslot : p.n_users - 1];
+  if (uid < 0) uid = 0;
+  if (uid >= p.t.num_users) uid = p.t.num_users - 1;
+  const float* urow = p.t.user_emb + uid * D;
+  const float ub = p.t.user_bias[uid];
+  // B fragments: lane (col, h) holds user element k = 16 q + 8 h + j in element j of k-block q
+  bf16x8 bhi[D16], bmid[D16], blo[D16];
+#pragma unroll
+  for (int q = 0; q < D16; ++q) {
+    const f32x4 x0 = *reinterpret_cast<const f32x4*>(urow + 16 * q + 8 * h);
+    const f32x4 x1 = *reinterpret_cast<const f32x4*>(urow + 16 * q + 8 * h + 4);
+    uint32_t w[3][4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      uint32_t a, b, c;
+      split_bf16x3(j < 4 ? x0[j & 3] : x1[j & 3], a, b, c);
+      if (j & 1) {
+        w[0][j >> 1] |= a << 16;
+        w[1][j >> 1] |= b << 16;
+        w[2][j >> 1] |= c << 16;
+      } else {
+        w[0][j >> 1] = a;
+        w[1][j >> 1] = b;
+        w[2][j >> 1] = c;
+      }
+    }
+    const uint4 v0 = make_uint4(w[0][0], w[0][1], w[0][2], w[0][3]);
+    const uint4 v1 = make_uint4(w[1][0], w[1][1], w[1][2], w[1][3]);
+    const uint4 v2 = make_uint4(w[2][0], w[2][1], w[2][2], w[2][3]);
+    bhi[q] = __builtin_bit_cast(bf16x8, v0);
+    bmid[q] = __builtin_bit_cast(bf16x8, v1);
+    blo[q] = __builtin_bit_cast(bf16x8, v2);
+  }
+
+  float top_s[kCap];
+  int top_i[kCap];
+#pragma unroll
+  for (int i = 0; i < kCap; ++i) {
+    top_s[i] = -INFINITY;
+    top_i[i] = 0x7fffffff;
+  }
+  const int k = p.k;
+  float thr = -INFINITY;
+
+  const int64_t chunk_items = static_cast<int64_t>(p.tiles_per_chunk) * kTileItems;
+  const int64_t chunk_begin = p.item_begin + static_cast<int64_t>(blockIdx.y) * chunk_items;
+  int64_t chunk_end = chunk_begin + chunk_items;
+  if (chunk_end > p.item_end) chunk_end = p.item_end;
+  const int64_t last_row = p.item_end - 1;
+
+  auto issue = [&](int64_t base, int buf) {
+    float4* dst = smem + buf * kBufF4;
+#pragma unroll
+    for (int n = 0; n < kPerWave; ++n) {
+      const int I = wave * kPerWave + n;
+      const int i = I * kWave + lane;
+      const int r = i / RC;
+      const int c = i % RC;
+      const int sp = c / CPR;
+      const int cc = (c % CPR) ^ (r & (S - 1));
+      int64_t item = base + r;
+      if (item > last_row) item = last_row;
+      dma_to_lds<16>(bp.item_split + (item * 3 + sp) * D + cc * 8, dst + I * kWave);
+    }
+    if (wave == 0) {
+      int64_t item = base + lane;
+      if (item > last_row) item = last_row;
+      dma_to_lds<4>(p.t.item_bias + item, dst + kTileF4);
+    }
+  };
+
+#pragma unroll
+  for (int q = 0; q < D16; ++q) asm volatile("" : "+v"(bhi[q]), "+v"(bmid[q]), "+v"(blo[q]));
+  float ub_ready = ub;
+  asm volatile("" : "+v"(ub_ready));
+
+  int buf = 0;
+  if (chunk_begin < chunk_end) issue(chunk_begin, 0);
+  for (int64_t base = chunk_begin; base < chunk_end; base += kTileItems) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (base + kTileItems < chunk_end) issue(base + kTileItems, buf ^ 1);
+    const float4* tile = smem + buf * kBufF4;
+    const float* tile_bias = reinterpret_cast<const float*>(tile + kTileF4);
+    const bool full = base + kTileItems <= chunk_end;
+#pragma unroll 1
+    for (int sub = 0; sub < kTileItems / 32; ++sub) {
+      f32x16 acc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+      const int r = sub * 32 + col;
+      const float4* arow = tile + r * RC;
+      const int sw = r & (S - 1);
+      // A fragments of k-block q: chunk 2 q + h of each of the item's three rows
+      float4 n_hi = arow[(0 + h) ^ sw];
+      float4 n_mid = arow[CPR + ((0 + h) ^ sw)];
+      float4 n_lo = arow[2 * CPR + ((0 + h) ^ sw)];
+#pragma unroll
+      for (int q = 0; q < D16; ++q) {
+        const bf16x8 ahi = __builtin_bit_cast(bf16x8, n_hi);
+        const bf16x8 amid = __builtin_bit_cast(bf16x8, n_mid);
+        const bf16x8 alo = __builtin_bit_cast(bf16x8, n_lo);
+        if (q + 1 < D16) {
+          const int cn = (2 * (q + 1) + h) ^ sw;
+          n_hi = arow[cn];
+          n_mid = arow[CPR + cn];
+          n_lo = arow[2 * CPR + cn];
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi[q], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo[q], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(amid, bmid[q], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(amid, bhi[q], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bmid[q], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi[q], acc, 0, 0, 0);
+      }
+      float smax = -INFINITY;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 b4 = *reinterpret_cast<const float4*>(tile_bias + sub * 32 + 8 * g + 4 * h);
+        acc[4 * g + 0] = finish_score(acc[4 * g + 0], ub, b4.x);
+        acc[4 * g + 1] = finish_score(acc[4 * g + 1], ub, b4.y);
+        acc[4 * g + 2] = finish_score(acc[4 * g + 2], ub, b4.z);
+        acc[4 * g + 3] = finish_score(acc[4 * g + 3], ub, b4.w);
+      }
+      if (!full) {
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+          const int row = sub * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
+          if (base + row >= chunk_end) acc[rr] = -INFINITY;
+        }
+      }
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) smax = fmaxf(smax, acc[rr]);
+      if (smax > thr) {
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+          if (acc[rr] > thr) {
+            const int row = sub * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
+            float cs = acc[rr];
+            int ci = static_cast<int>((base + row) * p.id_stride + p.id_offset);
+#pragma unroll
+            for (int i = 0; i < kCap; ++i) {
+              const bool better = cs > top_s[i];
+              const float ts = top_s[i];
+              const int ti = top_i[i];
+              top_s[i] = better ? cs : ts;
+              top_i[i] = better ? ci : ti;
+              cs = better ? ts : cs;
+              ci = better ? ti : ci;
+            }
+#pragma unroll
+            for (int i = 0; i < kCap; ++i) thr = i == k - 1 ? top_s[i] : thr;
+          }
+        }
+      }
+    }
+    buf ^= 1;
+  }
+  if (!user_ok) return;
+  const int nslots = p.nchunks * 2;
+  const int64_t slot = uslot * nslots + blockIdx.y * 2 + h;
+#pragma unroll
+  for (int i = 0; i < kCap; ++i) {
+    p.cand_scores[slot * kCap + i] = i < k ? top_s[i] : -INFINITY;
+    p.cand_ids[slot * kCap + i] = i < k ? top_i[i] : 0x7fffffff;
+  }
+}
+
+// the candidates the approximate pass kept, re-scored with the exact chain of the f32 pass
+__global__ __launch_bounds__(kBlock) void rescore_kernel(const collie_mf_tables t,
+                                                         const int64_t* __restrict__ user_ids,
+                                                         int64_t n_users, int kk, int D8,
+                                                         int64_t id_stride, int64_t id_offset,
+                                                         const int64_t* __restrict__ ids,
+                                                         float* __restrict__ out_scores,
+                                                         int32_t* __restrict__ out_ids) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= n_users * kk) return;
+  const int64_t u = i / kk;
+  const int64_t gid = ids[i];
+  float s = -INFINITY;
+  int32_t id = 0x7fffffff;
+  if (gid >= 0) {
+    int64_t uid = user_ids[u];
+    if (uid < 0) uid = 0;
+    if (uid >= t.num_users) uid = t.num_users - 1;
+    const int64_t row = (gid - id_offset) / id_stride;
+    s = finish_score(chain_dot(t.user_emb + uid * t.dim, t.item_emb + row * t.dim, t.dim, D8),
+                     t.user_bias[uid], t.item_bias[row]);
+    id = static_cast<int32_t>(gid);
+  }
+  out_scores[i] = s;
+  out_ids[i] = id;
+}
+
 // one wave per user: k rounds of "best remaining candidate" over the user's n candidates
 __global__ __launch_bounds__(kBlock) void merge_topk_kernel(const float* __restrict__ cand_scores,
                                                             const int32_t* __restrict__ cand_ids,
@@ -1127,6 +1395,118 @@ extern "C" int collie_mf_eval_topk_static(const collie_mf_tables* t, const int64
   // of the previous call's contents has to be cleared
   return eval_topk_impl(t, user_ids, n_users, item_begin, item_end, id_stride, id_offset, k,
                         has_y_range, y_lo, y_hi, topk_scores, topk_ids, ws, stream);
+}
+
+// ---- bf16 x 3 scoring pass (opt-in) ---------------------------------------------------------------
+namespace {
+constexpr int kBf16MaxK = 12;   // 16 candidates kept per user: at least 4 beyond k absorb the rounding
+
+struct Bf16Ws {
+  collie::EvalWs e;
+  float* ms;       // [n_users, kCap] merged approximate scores
+  int64_t* mi;     // [n_users, kCap] their ids
+  float* rs;       // [n_users, kCap] exact scores
+  int32_t* ri;
+  size_t bytes;
+};
+
+Bf16Ws carve_bf16_ws(void* base, int64_t n_users, int64_t n_items_shard) {
+  Bf16Ws w;
+  w.e = carve_eval_ws(base, n_users, n_items_shard);
+  Carver c(base);
+  c.off = w.e.bytes;
+  const size_t n = static_cast<size_t>(n_users) * kCap;
+  w.ms = c.take<float>(n);
+  w.mi = c.take<int64_t>(n);
+  w.rs = c.take<float>(n);
+  w.ri = c.take<int32_t>(n);
+  w.bytes = align_up(c.off, 256);
+  return w;
+}
+}  // namespace
+
+extern "C" int32_t collie_mf_eval_bf16x3_ok(int32_t dim, int32_t k) {
+  return (dim == 64 || dim == 128) && k >= 1 && k <= kBf16MaxK ? 1 : 0;
+}
+
+extern "C" int collie_mf_eval_split_bf16x3(const float* table, int64_t rows, int32_t dim,
+                                           void* out, collie_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  COLLIE_REQUIRE(table && out && rows >= 1 && dim >= 1, "split_bf16x3: bad arguments");
+  int64_t blocks = (rows * dim + kBlock - 1) / kBlock;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(split_bf16x3_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0,
+                     stream, table, rows, dim, static_cast<uint16_t*>(out));
+  return check_launch("split_bf16x3_kernel");
+}
+
+extern "C" size_t collie_mf_eval_bf16x3_workspace_bytes(int64_t n_users, int64_t n_items_shard) {
+  if (n_users < 1 || n_items_shard < 1) return 0;
+  return carve_bf16_ws(nullptr, n_users, n_items_shard).bytes;
+}
+
+extern "C" int collie_mf_eval_topk_bf16x3(const collie_mf_tables* t, const void* item_split,
+                                          const int64_t* user_ids, int64_t n_users,
+                                          int64_t item_begin, int64_t item_end, int64_t id_stride,
+                                          int64_t id_offset, int32_t k, int32_t has_y_range,
+                                          float y_lo, float y_hi, float* topk_scores,
+                                          int64_t* topk_ids, void* workspace,
+                                          size_t workspace_bytes, collie_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (check_topk_args(t, user_ids, n_users, item_begin, item_end, id_stride, id_offset, k,
+                      topk_scores, topk_ids))
+    return -1;
+  COLLIE_REQUIRE(item_split != nullptr, "eval_topk_bf16x3: NULL split table");
+  COLLIE_REQUIRE(collie_mf_eval_bf16x3_ok(t->dim, k),
+                 "eval_topk_bf16x3: embedding_dim must be 64 or 128 and k <= %d (use collie_mf_eval_topk)",
+                 kBf16MaxK);
+  auto al16 = [](const void* q) { return reinterpret_cast<uintptr_t>(q) % 16 == 0; };
+  COLLIE_REQUIRE(al16(t->user_emb) && al16(item_split), "eval_topk_bf16x3: unaligned tables");
+  Bf16Ws ws = carve_bf16_ws(workspace, n_users, item_end - item_begin);
+  COLLIE_REQUIRE(workspace != nullptr && workspace_bytes >= ws.bytes,
+                 "eval workspace too small: need %zu bytes, got %zu", ws.bytes, workspace_bytes);
+  const int kk = k + 6 < kCap ? k + 6 : kCap;     // candidates kept beyond k
+  Bf16Params bp;
+  memset(&bp, 0, sizeof(bp));
+  EvalParams& p = bp.e;
+  p.t = *t;
+  p.user_ids = user_ids;
+  p.n_users = n_users;
+  p.item_begin = item_begin;
+  p.item_end = item_end;
+  p.id_stride = id_stride;
+  p.id_offset = id_offset;
+  p.k = kk;
+  p.cand_scores = ws.e.cand_scores;
+  p.cand_ids = ws.e.cand_ids;
+  p.D8 = d8_bucket(t->dim);
+  bp.item_split = static_cast<const uint16_t*>(item_split);
+  const EvalGeom g = eval_geom(n_users, item_end - item_begin, kUsersPerBlockDma);
+  p.nchunks = g.nchunks;
+  p.tiles_per_chunk = g.tiles_per_chunk;
+  dim3 grid(static_cast<unsigned>((n_users + kUsersPerBlockDma - 1) / kUsersPerBlockDma),
+            static_cast<unsigned>(g.nchunks));
+  if (t->dim == 128)
+    hipLaunchKernelGGL((eval_gemm_bf16x3_kernel<8>), grid, dim3(kBlockDma), 0, stream, bp);
+  else
+    hipLaunchKernelGGL((eval_gemm_bf16x3_kernel<4>), grid, dim3(kBlockDma), 0, stream, bp);
+  if (check_launch("eval_gemm_bf16x3_kernel")) return -1;
+  const dim3 mgrid(static_cast<unsigned>((n_users + kWaves - 1) / kWaves));
+  // 16 per slot -> kk per user in the approximate order ...
+  hipLaunchKernelGGL(merge_topk_kernel, mgrid, dim3(kBlock), 0, stream, ws.e.cand_scores,
+                     ws.e.cand_ids, n_users, p.nchunks * 2 * kCap, kk, 0, 0.0f, 0.0f, ws.ms, ws.mi, kk,
+                     0, static_cast<float*>(nullptr), static_cast<int32_t*>(nullptr));
+  if (check_launch("merge_topk_kernel")) return -1;
+  // ... exact scores for those ...
+  hipLaunchKernelGGL(rescore_kernel, dim3(static_cast<unsigned>((n_users * kk + kBlock - 1) / kBlock)),
+                     dim3(kBlock), 0, stream, *t, user_ids, n_users, kk, p.D8, id_stride, id_offset,
+                     ws.mi, ws.rs, ws.ri);
+  if (check_launch("rescore_kernel")) return -1;
+  // ... and the k best of them in the exact order
+  hipLaunchKernelGGL(merge_topk_kernel, mgrid, dim3(kBlock), 0, stream, ws.rs, ws.ri, n_users, kk, k,
+                     has_y_range, y_lo, y_hi, topk_scores, topk_ids, k, 0,
+                     static_cast<float*>(nullptr), static_cast<int32_t*>(nullptr));
+  return check_launch("merge_topk_kernel");
 }
 
 extern "C" int collie_mf_eval_merge_topk(const float* cand_scores, const int32_t* cand_ids,

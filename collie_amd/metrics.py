@@ -78,7 +78,7 @@ def _csr_slice(targets: csr_matrix, user_ids, device):
 
 
 def _per_user(tables, user_slots, indptr, indices, n_items, k, y_range, want, ws=None,
-              item_range=None):
+              item_range=None, split=None):
     """Per-user (ap, rr, auc) device tensors for one launch-sized group of users.  ``indptr`` may
     be a callable returning ``(indptr, indices)``: MAP@k alone needs the CSR rows only after the
     scoring pass, so the host slices them while the GPU scores."""
@@ -88,9 +88,15 @@ def _per_user(tables, user_slots, indptr, indices, n_items, k, y_range, want, ws
     lo_i, hi_i = item_range if item_range is not None else (0, n_items)
     ws = ws or ops.EvalWorkspace(dev)
     topk_ids = pos = counts = None
+
+    def topk():     # split: the item table's bf16 x 3 image (opt-in scoring pass, MAP@k alone)
+        if split is not None:
+            return ops.eval_topk_bf16x3(tables, split, user_slots, lo_i, hi_i, k, y_range, ws)[1]
+        return ops.eval_topk(tables, user_slots, lo_i, hi_i, k, y_range, ws)[1]
+
     if callable(indptr):
         if want_ap and not (want_rr or want_auc):
-            _, topk_ids = ops.eval_topk(tables, user_slots, lo_i, hi_i, k, y_range, ws)
+            topk_ids = topk()
             want_ap = False             # done; the launch is in flight while the CSR is sliced
         indptr, indices = indptr()
         if topk_ids is not None:
@@ -107,7 +113,7 @@ def _per_user(tables, user_slots, indptr, indices, n_items, k, y_range, want, ws
             ops.eval_rank_counts(tables, user_slots, indptr, lo, hi, best_s, best_id, lo_i, hi_i,
                                  counts)
     elif want_ap:
-        _, topk_ids = ops.eval_topk(tables, user_slots, lo_i, hi_i, k, y_range, ws)
+        topk_ids = topk()
     return ops.eval_metrics(topk_ids, k, n, n_items, indptr, indices, pos, counts, y_range,
                             want_ap, want_rr, want_auc)
 
@@ -226,6 +232,12 @@ def evaluate_in_batches(
         y = model.hparams.get('y_range')
         y = tuple(y) if y is not None else None
         ws = ops.EvalWorkspace(torch.device(device) if not isinstance(device, torch.device) else device)
+        # opt-in (COLLIE_EVAL_BF16X3=1 or model.eval_bf16x3 = True): MAP@k alone ranks the catalogue
+        # on bf16 MFMA (three-way split) and re-scores 16 candidates per user exactly
+        split = None
+        if (want == (True, False, False) and _bf16x3_wanted(model)
+                and ops.eval_bf16x3_ok(model.hparams.embedding_dim, k)):
+            split = ops.eval_split_items(model.item_embeddings.weight.data)
         per_user = {n: [] for n in ('ap', 'rr', 'auc')}
         csr = []                        # test_interactions.mat.tocsr(), built on first use
 
@@ -239,7 +251,7 @@ def evaluate_in_batches(
                 group = test_users[s:s + USERS_PER_LAUNCH]
                 slots = torch.from_numpy(group.astype(np.int64)).to(tables_device(model))
                 ap, rr, au = _per_user(tables, slots, partial(csr_rows, group, slots.device), None,
-                                       n_items, k, y, want, ws)
+                                       n_items, k, y, want, ws, split=split)
                 for n, v in (('ap', ap), ('rr', rr), ('auc', au)):
                     if v is not None:
                         per_user[n].append(v)
@@ -266,6 +278,11 @@ def evaluate_in_batches(
         _log_metrics(model=model, logger=logger, metric_list=metric_list, all_scores=all_scores,
                      verbose=verbose)
     return all_scores[0] if len(all_scores) == 1 else all_scores
+
+
+def _bf16x3_wanted(model):
+    import os
+    return bool(getattr(model, 'eval_bf16x3', False)) or os.environ.get('COLLIE_EVAL_BF16X3') == '1'
 
 
 def tables_device(model):

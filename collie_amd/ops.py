@@ -672,6 +672,45 @@ def eval_topk(tables, user_ids, item_begin, item_end, k, y_range, ws, id_stride=
     return scores, ids
 
 
+def eval_bf16x3_ok(dim, k):
+    """Can the opt-in bf16 x 3 scoring pass take this shape (``collie_mf_eval_bf16x3_ok``)?"""
+    return bool(load().collie_mf_eval_bf16x3_ok(int(dim), int(k)))
+
+
+def eval_split_items(item_emb):
+    """The item table's bf16 x 3 image ``[rows, 3, dim]`` for ``eval_topk_bf16x3``; valid until
+    the table changes."""
+    require_hip(item_emb, 'item_embeddings')
+    assert item_emb.dtype == torch.float32 and item_emb.is_contiguous()
+    rows, dim = item_emb.shape
+    out = torch.empty(rows, 3, dim, dtype=torch.bfloat16, device=item_emb.device)
+    check(load().collie_mf_eval_split_bf16x3(ptr(item_emb), rows, dim, ptr(out), stream_ptr()),
+          'collie_mf_eval_split_bf16x3')
+    return out
+
+
+def eval_topk_bf16x3(tables, item_split, user_ids, item_begin, item_end, k, y_range, ws,
+                     id_stride=1, id_offset=0):
+    """``eval_topk`` with the catalogue pass on bf16 MFMA (three-way split, exact re-scoring of
+    16 candidates per user): same scores, ids equal unless > 16 - k items tie the k-th to ~1e-7."""
+    require_hip(user_ids, 'user_ids')
+    assert user_ids.dtype == torch.int64 and user_ids.is_contiguous()
+    assert item_split.dtype == torch.bfloat16 and item_split.is_contiguous()
+    n = user_ids.shape[0]
+    dev = user_ids.device
+    need = int(load().collie_mf_eval_bf16x3_workspace_bytes(n, item_end - item_begin))
+    if ws.buf is None or ws.buf.numel() < need:
+        ws.buf = torch.empty(need, dtype=torch.uint8, device=dev)
+    scores = torch.empty(n, k, dtype=torch.float32, device=dev)
+    ids = torch.empty(n, k, dtype=torch.int64, device=dev)
+    has_y, lo, hi = _y(y_range)
+    check(load().collie_mf_eval_topk_bf16x3(
+        byref(tables), ptr(item_split), ptr(user_ids), n, item_begin, item_end, id_stride,
+        id_offset, k, has_y, lo, hi, ptr(scores), ptr(ids), ptr(ws.buf), ws.buf.numel(),
+        stream_ptr()), 'collie_mf_eval_topk_bf16x3')
+    return scores, ids
+
+
 def eval_topk_static(tables, user_ids, item_begin, item_end, k, y_range, scores, ids,
                      id_stride=1, id_offset=0):
     """``eval_topk`` into caller-provided ``scores`` / ``ids`` [n, k] without any allocation: the

@@ -480,6 +480,29 @@ int collie_mf_eval_topk_static(const collie_mf_tables* t, const int64_t* user_id
                                float y_hi, float* topk_scores, int64_t* topk_ids,
                                collie_stream_t stream);
 
+/* collie_mf_eval_topk with the catalogue pass on bf16 MFMA (v_mfma_f32_32x32x16_bf16), OPT-IN: every
+ * f32 value is split into three bf16 terms (hi + mid + lo = 24 significant bits) and the six products
+ * of total order <= 2 are accumulated in f32 -- 2.7x fewer MFMA cycles than the exact-f32 instruction
+ * -- which only RANKS: the 16 best candidates per user in that order are re-scored with the exact
+ * chain of collie_mf_eval_topk and the k best of them are emitted, so scores are the same bits and
+ * ids differ only if more than 16 - k items lie within ~1e-7 (relative) of the k-th score.
+ * Reference: preds.topk(k) of collie/metrics.py:171 on the scores of :102-107.  Limits
+ * (collie_mf_eval_bf16x3_ok): embedding_dim 64 or 128, k <= 12, one round; callers fall back to
+ * collie_mf_eval_topk otherwise.
+ *   collie_mf_eval_split_bf16x3: out = bf16 [rows, 3, dim] (6 * rows * dim bytes, 16-byte aligned),
+ *       the item table's split image; valid until the table changes (once per evaluate call).
+ *   workspace: collie_mf_eval_bf16x3_workspace_bytes(n_users, item_end - item_begin). */
+int32_t collie_mf_eval_bf16x3_ok(int32_t dim, int32_t k);
+int collie_mf_eval_split_bf16x3(const float* table, int64_t rows, int32_t dim, void* out,
+                                collie_stream_t stream);
+size_t collie_mf_eval_bf16x3_workspace_bytes(int64_t n_users, int64_t n_items_shard);
+int collie_mf_eval_topk_bf16x3(const collie_mf_tables* t, const void* item_split,
+                               const int64_t* user_ids, int64_t n_users, int64_t item_begin,
+                               int64_t item_end, int64_t id_stride, int64_t id_offset, int32_t k,
+                               int32_t has_y_range, float y_lo, float y_hi, float* topk_scores,
+                               int64_t* topk_ids, void* workspace, size_t workspace_bytes,
+                               collie_stream_t stream);
+
 /* Catalog-sharded evaluation: merge per-shard top-k candidate lists (cand_* [n_users, nslots,
  * slot_len]: every shard's own top-k in slot_len >= its length entries, unused entries = (-inf,
  * INT32_MAX)) into the global top-k, any k <= nslots * slot_len (metrics.py:170-175 allows any

@@ -314,3 +314,93 @@ def test_evaluate_in_batches_metric_subsets_agree_on_dma_shape(dev):
     np.testing.assert_allclose(got, ref, rtol=1e-5)
     assert evaluate_in_batches([mapk], test, model, k=10, verbose=False) == got[0]
     assert evaluate_in_batches([mrr, auc], test, model, k=10, verbose=False) == got[1:]
+
+
+# ---- the opt-in bf16 x 3 scoring pass (collie_mf_eval_topk_bf16x3) ----------------------------------
+@pytest.mark.parametrize('D,N,U,k', [(64, 5003, 300, 10), (128, 2048, 70, 12), (128, 70001, 520, 10),
+                                     (64, 777, 129, 1)])
+def test_bf16x3_topk_exact_on_exactly_representable_scores(dev, D, N, U, k):
+    """Grid-valued embeddings are bf16 numbers: the split is exact (mid = lo = 0), every product is
+    exact, so the pass must give the oracle's (score desc, id asc) ids and scores, ties included."""
+    from oracle import mf_oracle as O
+    from collie_amd import ops
+    rng = np.random.default_rng(D + N)
+    tables = {'user_embeddings': (rng.integers(-4, 5, (U, D)) / 8).astype(np.float32),
+              'item_embeddings': (rng.integers(-4, 5, (N, D)) / 8).astype(np.float32),
+              'user_biases': (rng.integers(-8, 9, (U, 1)) / 16).astype(np.float32),
+              'item_biases': (rng.integers(-8, 9, (N, 1)) / 16).astype(np.float32)}
+    model = make_model(tables, dev)
+    t = model._tables()
+    users = np.sort(rng.choice(U, min(U, 600), replace=False))
+    preds = O.get_preds(tables, users, N)
+    ws = ops.EvalWorkspace(dev)
+    slots = torch.tensor(users, dtype=torch.int64, device=dev)
+    split = ops.eval_split_items(model.item_embeddings.weight.data)
+    scores, ids = ops.eval_topk_bf16x3(t, split, slots, 0, N, k, None, ws)
+    ref = O.topk_ids(preds, k)
+    np.testing.assert_array_equal(ids.cpu().numpy(), ref)
+    np.testing.assert_array_equal(scores.cpu().numpy(), np.take_along_axis(preds, ref, axis=1))
+
+
+@pytest.mark.parametrize('D,N,U,k,stride,y_range', [(128, 70001, 1500, 10, 1, None),
+                                                    (64, 30011, 700, 12, 1, (0.0, 5.0)),
+                                                    (128, 9000, 260, 5, 3, None),
+                                                    (64, 129, 40, 10, 1, None)])
+def test_bf16x3_topk_equals_the_f32_pass_on_random_tables(dev, D, N, U, k, stride, y_range):
+    """Random tables (every mantissa bit in use): ids and scores of the bf16 x 3 pass equal the
+    exact-f32 pass -- the scores bit for bit (they come from the same chain), the ids because 16
+    candidates per user absorb the ~1e-7 ranking error of the split products."""
+    from collie_amd import ops
+    rng = np.random.default_rng(N)
+    tables = {'user_embeddings': rng.normal(0, 0.3, (U, D)).astype(np.float32),
+              'item_embeddings': rng.normal(0, 0.3, (N, D)).astype(np.float32),
+              'user_biases': rng.normal(0, 0.05, (U, 1)).astype(np.float32),
+              'item_biases': rng.normal(0, 0.05, (N, 1)).astype(np.float32)}
+    model = make_model(tables, dev)
+    t = model._tables()
+    ws, ws2 = ops.EvalWorkspace(dev), ops.EvalWorkspace(dev)
+    slots = torch.arange(U, dtype=torch.int64, device=dev)
+    split = ops.eval_split_items(model.item_embeddings.weight.data)
+    # the split really is a 24-bit representation
+    parts = split.float().cpu().numpy()
+    back = (parts[:, 0].astype(np.float64) + parts[:, 1] + parts[:, 2])
+    np.testing.assert_allclose(back, tables['item_embeddings'], rtol=2 ** -22, atol=1e-30)
+    want_s, want_i = ops.eval_topk(t, slots, 0, N, k, y_range, ws, stride, 1 if stride > 1 else 0)
+    got_s, got_i = ops.eval_topk_bf16x3(t, split, slots, 0, N, k, y_range, ws2, stride,
+                                        1 if stride > 1 else 0)
+    assert torch.equal(got_i, want_i)
+    assert torch.equal(got_s, want_s)
+    # an item sub-range (a shard of the catalogue)
+    lo, hi = N // 3, N - 7
+    want_s, want_i = ops.eval_topk(t, slots, lo, hi, k, y_range, ws)
+    got_s, got_i = ops.eval_topk_bf16x3(t, split, slots, lo, hi, k, y_range, ws2)
+    assert torch.equal(got_i, want_i) and torch.equal(got_s, want_s)
+
+
+def test_bf16x3_limits_and_evaluate_in_batches_opt_in(dev):
+    from collie_amd import _lib, metrics as M, ops
+    from collie_amd.interactions import Interactions
+    assert ops.eval_bf16x3_ok(128, 10) and ops.eval_bf16x3_ok(64, 12)
+    assert not ops.eval_bf16x3_ok(32, 10) and not ops.eval_bf16x3_ok(128, 13)
+    rng = np.random.default_rng(5)
+    U, N, D = 400, 3000, 64
+    tables = {'user_embeddings': rng.normal(0, 0.3, (U, D)).astype(np.float32),
+              'item_embeddings': rng.normal(0, 0.3, (N, D)).astype(np.float32),
+              'user_biases': rng.normal(0, 0.05, (U, 1)).astype(np.float32),
+              'item_biases': rng.normal(0, 0.05, (N, 1)).astype(np.float32)}
+    model = make_model(tables, dev)
+    ws = ops.EvalWorkspace(dev)
+    slots = torch.arange(U, dtype=torch.int64, device=dev)
+    split = ops.eval_split_items(model.item_embeddings.weight.data)
+    with pytest.raises(_lib.CollieHipError):
+        ops.eval_topk_bf16x3(model._tables(), split, slots, 0, N, 13, None, ws)
+    rows = np.repeat(np.arange(U), 5)
+    cols = rng.integers(0, N, rows.shape[0])
+    test = Interactions(users=rows, items=cols, num_users=U, num_items=N, allow_missing_ids=True,
+                        num_negative_samples=1, max_number_of_samples_to_consider=0, seed=0)
+    want = M.evaluate_in_batches([M.mapk], test, model, k=10, verbose=False)
+    model.eval_bf16x3 = True
+    got = M.evaluate_in_batches([M.mapk], test, model, k=10, verbose=False)
+    assert got == want
+    both = M.evaluate_in_batches([M.mapk, M.mrr], test, model, k=10, verbose=False)   # f32 route
+    assert both[0] == want
