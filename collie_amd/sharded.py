@@ -643,7 +643,14 @@ class ShardedMatrixFactorizationModel:
         dev = users.device
         B, K = neg_items.shape
         planner = getattr(self.engine, 'plan', None)
-        if planner is not None:
+        if B == 0:
+            # a rank without samples in this step (a routed batch can leave one empty) requests
+            # nothing; it still serves rows, receives gradients and joins every collective
+            cu = cp = torch.empty(0, dtype=torch.int32, device=dev)
+            cn = torch.empty(0, K, dtype=torch.int64, device=dev)
+            send_rows = torch.empty(0, dtype=torch.int64, device=dev)
+            counts = torch.zeros(2 * G + 2, dtype=torch.int64, device=dev)
+        elif planner is not None:
             cu, cp, cn, send_rows, counts = planner(self, users, pos_items, neg_items, users_local)
         else:
             cu, cp, cn, send_rows, counts = plan_torch(
@@ -749,16 +756,14 @@ class ShardedMatrixFactorizationModel:
                              [wire_rows(c, D) for c in p['send_counts']])
         # 4. fused forward on the compact table + gradient rows into the owners' blocks
         mark('forward')
-        codes = []
-        for c in self._codes or []:          # category codes of the compact rows (items only)
-            cc = torch.zeros(cw.shape[0], dtype=torch.int32, device=dev)
-            cc[p['cp'].long()] = c[pos_items.long()]
-            cc[p['cn'].reshape(-1).long()] = c[neg_items.reshape(-1).long()]
-            codes.append(cc)
-        scale = torch.full((1,), p['B'] / p['B_global'], dtype=torch.float32, device=dev)
-        loss, gwire, gcounts = eng.forward_export(
-            self, cw, p['send_counts'], p['send_rows'], p['cu'], p['cp'], p['cn'], self._loss_kind,
-            self.hparams['num_items'], codes, self._weights, scale, users_local, step)
+        scale = torch.full((1,), p['B'] / max(p['B_global'], 1), dtype=torch.float32, device=dev)
+        if p['B'] == 0:
+            loss = torch.zeros(1, dtype=torch.float32, device=dev)
+            gwire = torch.empty(0, D, dtype=torch.float32, device=dev)
+            gcounts = torch.zeros(G + 1, dtype=torch.int64, device=dev)
+        else:
+            loss, gwire, gcounts = self._forward_export(p, cw, pos_items, neg_items, scale,
+                                                        users_local, step)
         # 5. gradients home: how many rows each owner gets depends on the forward pass (which
         # negative each sample selected), so the counts are exchanged and read back first
         mark('gradient_exchange')
@@ -779,6 +784,19 @@ class ShardedMatrixFactorizationModel:
                                   bytes_in=int(cw.shape[0]) * D * 4,
                                   bytes_out=int(sum(gsplit_send)) * D * 4)
         return total.reshape(())
+
+    def _forward_export(self, p, cw, pos_items, neg_items, scale, users_local, step):
+        """Step 4 of the module docstring for a non-empty slice."""
+        dev, eng = self.device, self.engine
+        codes = []
+        for c in self._codes or []:          # category codes of the compact rows (items only)
+            cc = torch.zeros(cw.shape[0], dtype=torch.int32, device=dev)
+            cc[p['cp'].long()] = c[pos_items.long()]
+            cc[p['cn'].reshape(-1).long()] = c[neg_items.reshape(-1).long()]
+            codes.append(cc)
+        return eng.forward_export(
+            self, cw, p['send_counts'], p['send_rows'], p['cu'], p['cp'], p['cn'], self._loss_kind,
+            self.hparams['num_items'], codes, self._weights, scale, users_local, step)
 
     # ---- evaluation --------------------------------------------------------------------------------
     def _user_tile(self, uids):

@@ -103,6 +103,34 @@ def check_training(rank, world, loss, optimizer, bias_optimizer, K, metadata=Non
             np.testing.assert_allclose(have, want, rtol=1e-4, atol=2e-7, err_msg=name)
 
 
+def check_empty_slice(rank, world):
+    """Every user of the step belongs to rank 0: after routing, the other ranks have no sample.
+    They still serve rows, take gradients and join the collectives; the result is the oracle's."""
+    U, N, D, B, K = 40, 30, 8, 24, 3
+    t0 = full_tables(U, N, D, 5)
+    model = ShardedMatrixFactorizationModel(U, N, K, embedding_dim=D, lr=1e-2, bias_lr=1e-2,
+                                            optimizer='sparse_adam', bias_optimizer='sgd', loss='bpr',
+                                            device=DEV, engine=engine(), init=False)
+    model.load_full_state_dict({f'{k}.weight': dev(v.copy()) for k, v in t0.items()})
+    ref = O.TrainState(t0, optimizer='sparse_adam', bias_optimizer='sgd', lr=1e-2, bias_lr=1e-2,
+                       sparse=True)
+    rng = np.random.default_rng(3)
+    for step in range(2):
+        users = rng.integers(0, U // world, B) * world          # owner 0
+        pos = rng.integers(0, N, B)
+        neg = rng.integers(0, N, (B, K))
+        out = ref.step(users, pos, neg, model._loss_kind, num_items=N)
+        batch = ((dev(users.astype(np.int32)), dev(pos.astype(np.int32))), dev(neg))
+        piece = route_batch_to_user_owners(shard_batch(batch, rank, world))
+        assert piece[0][0].shape[0] == (B if rank == 0 else 0)
+        got = model.train_step(piece, users_local=True)
+        np.testing.assert_allclose(got.item(), out['loss'], rtol=2e-5, atol=1e-7)
+    sd = model.state_dict()
+    for name in ('user_embeddings', 'item_embeddings', 'item_biases'):
+        np.testing.assert_allclose(sd[f'{name}.weight'].cpu().numpy(), ref.t[name], rtol=1e-4,
+                                   atol=2e-7, err_msg=name)
+
+
 def check_init(rank, world):
     U, N, D = 37, 29, 16
     m = ShardedMatrixFactorizationModel(U, N, 3, embedding_dim=D, device=DEV, engine=engine(),
@@ -221,6 +249,7 @@ def main():
     check_training(rank, world, 'adaptive', 'sparse_adam', 'sparse_adam', 4, {'genre': genre})
     check_training(rank, world, 'bpr', 'sparse_adam', 'sgd', 10, route=True)
     check_training(rank, world, 'warp', 'adagrad', 'sparse_adam', 5, {'genre': genre}, route=True)
+    check_empty_slice(rank, world)
     check_eval(rank, world)
     check_errors(rank, world)
     dist.barrier()

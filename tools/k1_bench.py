@@ -25,6 +25,7 @@ def main():
     ap.add_argument('--item-range', type=int, default=0)
     ap.add_argument('--sort-users', action='store_true')
     ap.add_argument('--no-grad', action='store_true')
+    ap.add_argument('--no-stamps', action='store_true', help='COLLIE_NO_STAMPS: what the stamps cost')
     args = ap.parse_args()
     U, N, D = {'c2': (138_493, 26_744, 64), 'c4': (100_000_000, 10_000_000, 128),
                'c3': (1_000_000, 1_000_000, 128)}[args.shape]
@@ -51,13 +52,14 @@ def main():
     cfg = ops.make_loss_cfg(args.kind, N)
     loss = torch.empty(1, device=dev)
     status = torch.zeros(1, dtype=torch.int32, device=dev)
+    need = (0 if args.no_grad else 1) | (ops.NO_STAMPS if args.no_stamps else 0)
     for i in range(3):
-        ops.train_forward(t, batches[i % 4], cfg, buf, not args.no_grad, ws.next_step(), loss, None, None, status)
+        ops.train_forward(t, batches[i % 4], cfg, buf, need, ws.next_step(), loss, None, None, status)
     torch.cuda.synchronize()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     ev[0].record()
     for i in range(args.iters):
-        ops.train_forward(t, batches[i % 4], cfg, buf, not args.no_grad, ws.next_step(), loss, None, None, status)
+        ops.train_forward(t, batches[i % 4], cfg, buf, need, ws.next_step(), loss, None, None, status)
     ev[1].record()
     torch.cuda.synchronize()
     ms = ev[0].elapsed_time(ev[1]) / args.iters
