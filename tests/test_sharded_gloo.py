@@ -20,14 +20,21 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def test_world_size_2_training_and_eval_match_unsharded_oracle():
+import pytest
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_world_size_n_training_and_eval_match_unsharded_oracle(world):
+    """world 3: shards, batch slices and wire blocks of unequal sizes."""
     env = dict(os.environ, OMP_NUM_THREADS='2', HSA_ENABLE_IPC_MODE_LEGACY='0')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node',
+           str(world),
            '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
            os.path.join(ROOT, 'tests', 'sharded_worker.py')]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-4000:] + out.stderr[-4000:]
-    assert 'rank 0: sharded checks ok' in out.stdout and 'rank 1: sharded checks ok' in out.stdout
+    for r in range(world):
+        assert f'rank {r}: sharded checks ok' in out.stdout
 
 
 def test_world_size_1_needs_no_process_group():
