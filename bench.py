@@ -137,7 +137,7 @@ def pmc_traffic(shape, batch):
     MI355X_MICROARCH.md prescribes for gfx950).  A PMC pass cannot run inside the timed benchmark,
     so the number is read, not measured live; None when no pass was recorded for this workload.
     """
-    for rnd in ('r02', 'r01'):              # the newest committed passes of this command
+    for rnd in ('r03', 'r02', 'r01'):              # the newest committed passes of this command
         path = os.path.join(ROOT, 'profiles', f'{rnd}_pmc_traffic.json')
         try:
             with open(path) as f:
