@@ -108,6 +108,10 @@ __device__ __forceinline__ int64_t xcd_tile(int64_t b, int64_t ntiles) {
   return x * q + (x < r ? x : r) + j;
 }
 
+// The entries of a tile are first brought into digit order inside LDS (their rank among the tile's
+// entries of the same digit is known from the ballots), then written out in that order: consecutive
+// lanes then write consecutive addresses of a bucket's run instead of 64 scattered 4-byte stores per
+// instruction (ML-20M shape, 3 M entries: 36.5 -> see DESIGN.md K3a).
 template <int BITS>
 __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, int64_t m,
@@ -115,8 +119,13 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
     uint32_t* __restrict__ vals_out) {
   constexpr int RADIX = 1 << BITS;
   constexpr int kWaves = kBlock / kWave;
+  constexpr int DPT = RADIX / kBlock;          // digits per thread in the tile-local scan
+  static_assert(DPT * kBlock == RADIX, "radix is a multiple of the workgroup size");
   __shared__ uint32_t wcount[kWaves][RADIX];
-  __shared__ uint32_t gbase[RADIX];
+  __shared__ uint32_t gbase[RADIX];            // global position of the tile's first entry of a digit
+  __shared__ uint32_t lstart[RADIX];           // tile-local position of it
+  __shared__ uint32_t skey[kSortTile], sval[kSortTile];
+  __shared__ uint32_t wave_tot[kWaves];
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
   const int w = tid / kWave;
@@ -125,7 +134,8 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
 
   // wave-striped tile: wave w owns entries [w*512, (w+1)*512) of the tile, iteration-major
   const int64_t tile = xcd_tile(blockIdx.x, ntiles);
-  const int64_t wbase = tile * kSortTile + w * (kWave * kItems);
+  const int64_t tbase = tile * kSortTile;
+  const int64_t wbase = tbase + w * (kWave * kItems);
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   uint32_t key[kItems], val[kItems], rnk[kItems];
   volatile uint32_t* mycount = wcount[w];
@@ -152,7 +162,12 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
     rnk[i] = old + before;
   }
   __syncthreads();
-  for (int d = tid; d < RADIX; d += kBlock) {
+  // per digit: the waves' counts become offsets inside the digit's run of this tile; per thread
+  // DPT consecutive digits, then one exclusive scan over the workgroup for the runs' starts
+  uint32_t dcount[DPT], mine = 0;
+#pragma unroll
+  for (int j = 0; j < DPT; ++j) {
+    const int d = tid * DPT + j;
     uint32_t run = 0;
 #pragma unroll
     for (int i = 0; i < kWaves; ++i) {
@@ -160,7 +175,25 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
       wcount[i][d] = run;
       run += c;
     }
+    dcount[j] = run;
+    mine += run;
     gbase[d] = hist[static_cast<int64_t>(d) * ntiles + tile];
+  }
+  uint32_t inc = mine;
+#pragma unroll
+  for (int o = 1; o < kWave; o <<= 1) {
+    const uint32_t up = __shfl_up(inc, o, kWave);
+    if (lane >= o) inc += up;
+  }
+  if (lane == kWave - 1) wave_tot[w] = inc;
+  __syncthreads();
+  uint32_t before_me = inc - mine;
+#pragma unroll
+  for (int i = 0; i < kWaves; ++i) before_me += i < w ? wave_tot[i] : 0u;
+#pragma unroll
+  for (int j = 0; j < DPT; ++j) {
+    lstart[tid * DPT + j] = before_me;
+    before_me += dcount[j];
   }
   __syncthreads();
 #pragma unroll
@@ -168,9 +201,23 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
     const int64_t idx = wbase + i * kWave + lane;
     if (idx < m) {
       const uint32_t digit = (key[i] >> shift) & (RADIX - 1);
-      const uint32_t pos = gbase[digit] + wcount[w][digit] + rnk[i];
-      keys_out[pos] = key[i];
-      vals_out[pos] = val[i];
+      const uint32_t lp = lstart[digit] + wcount[w][digit] + rnk[i];
+      skey[lp] = key[i];
+      sval[lp] = val[i];
+    }
+  }
+  __syncthreads();
+  const int64_t left = m - tbase;
+  const int n_here = left < kSortTile ? static_cast<int>(left) : kSortTile;
+#pragma unroll
+  for (int i = 0; i < kItems; ++i) {
+    const int j = i * kBlock + tid;
+    if (j < n_here) {
+      const uint32_t k = skey[j];
+      const uint32_t digit = (k >> shift) & (RADIX - 1);
+      const uint32_t pos = gbase[digit] + (static_cast<uint32_t>(j) - lstart[digit]);
+      keys_out[pos] = k;
+      vals_out[pos] = sval[j];
     }
   }
 }
