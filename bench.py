@@ -346,9 +346,14 @@ def main_sharded(args, world, rank, device):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        loss = model.train_step(batches[(args.warmup + i) % n_distinct], users_local=ul)
-        if args.plan_ahead and i + 1 < args.steps:  # size the next step's exchanges meanwhile
-            model.plan_ahead(batches[(args.warmup + i + 1) % n_distinct], users_local=ul)
+        # the next step's exchanges are sized meanwhile: its plan is queued inside this step
+        # (next_batch=) or, with --plan-side-stream, on a second stream after it (plan_ahead())
+        nxt = (batches[(args.warmup + i + 1) % n_distinct]
+               if args.plan_ahead and i + 1 < args.steps else None)
+        loss = model.train_step(batches[(args.warmup + i) % n_distinct], users_local=ul,
+                                next_batch=None if args.plan_side_stream else nxt)
+        if nxt is not None and args.plan_side_stream:
+            model.plan_ahead(nxt, users_local=ul)
     dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -548,9 +553,11 @@ def main():
     ap.add_argument('--sharded-shape', choices=['c2', 'c4'], default='c4',
                     help="tables of the N > 1 run (default: configs[3], north_star's scaling config)")
     ap.add_argument('--no-plan-ahead', dest='plan_ahead', action='store_false',
-                    help='N > 1: do NOT plan step t + 1 on a side stream while step t computes '
-                         '(ShardedMatrixFactorizationModel.plan_ahead hides the first host read of '
-                         'a step behind the previous one; on by default, see DESIGN.md 6)')
+                    help='N > 1: do NOT plan step t + 1 while step t computes (train_step(next_batch=) '
+                         'queues the next plan in front of the owner update, so the host reads of a '
+                         'step never idle the GPU; on by default, see DESIGN.md 6)')
+    ap.add_argument('--plan-side-stream', action='store_true',
+                    help='N > 1: plan ahead with plan_ahead() on a second stream instead')
     ap.add_argument('--no-users-local', dest='users_local', action='store_false',
                     help='N > 1: draw every rank\'s users from the whole table (user rows then take '
                          'the exchange like item rows) instead of from the users the rank owns')

@@ -122,7 +122,8 @@ SIGNATURES = {
     'collie_mf_batch_copy': (ctypes.c_int, [POINTER(Batch), POINTER(Batch), c_void_p]),
     'collie_sparse_rows_workspace_bytes': (c_size_t, [c_int64, c_int32]),
     'collie_shard_wire_rows': (c_int64, [c_void_p, c_int32, c_int32, c_int32]),
-    'collie_shard_plan_workspace_bytes': (c_size_t, [c_int64, c_int32, c_int32]),
+    'collie_shard_plan_workspace_bytes': (c_size_t, [c_int64, c_int32, c_int32, c_int64, c_int64,
+                                                    c_int32]),
     'collie_shard_plan': (ctypes.c_int, [POINTER(Batch), c_int64, c_int64, c_int32, c_int32, c_int32,
                                          c_void_p, c_size_t, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_int64, c_void_p, c_void_p]),

@@ -352,13 +352,19 @@ __global__ __launch_bounds__(kBlock) void emb_rows_kernel(const UpdParams p) {
   }
 }
 
-// bias tables: 16 lanes per segment stride its entries, fixed-shape butterfly sum.
+// bias tables.  The sum of a segment has a fixed shape: 16 lanes stride its entries, then a butterfly
+// (offsets 8, 4, 2, 1).  Nearly every segment of a batch with uniform ids has one or two entries, so
+// a wave first takes 64 segments, ONE PER LANE: a lane whose segment has at most four entries forms
+// the same sum by itself -- for entries e0..e3 the butterfly gives (e0 + e2) + (e1 + e3), absent
+// entries being +0 -- and only the longer segments (and those summed piecewise) are then reduced
+// four at a time by 16-lane groups as before.  The read-modify-write of the bias, its moments and
+// its stamps runs on all 64 lanes at once (16 times the rows in flight of one group per segment).
 // d loss / d user_bias is identically zero for every pairwise loss (the user bias cancels in
 // s+ - s-); the reference's value is only the fp32 residue of (+g) + (-g) in coalesce order, so
 // the user-bias gradient is produced as an exact 0 (stage == NULL; the row is still "touched").
 template <bool EXPORT>
 __global__ __launch_bounds__(kBlock) void bias_rows_kernel(const UpdParams p) {
-  constexpr int LPS = 16;  // lanes per segment
+  constexpr int LPS = 16;  // lanes per long segment
   constexpr int GPW = kWave / LPS;
   const int lane = lane_id();
   const int grp = lane / LPS;
@@ -374,9 +380,9 @@ __global__ __launch_bounds__(kBlock) void bias_rows_kernel(const UpdParams p) {
   const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
   if (EXPORT && blockIdx.x == 0 && threadIdx.x == 0)
     *p.count_out = static_cast<int32_t>(p.export_side ? nseg - first1 : first1);
-  for (int64_t seg0 = (static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + threadIdx.x / kWave) * GPW;
-       seg0 < nseg; seg0 += nwaves * GPW) {
-    const int64_t seg = seg0 + grp;
+  for (int64_t seg0 = (static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + threadIdx.x / kWave) * kWave;
+       seg0 < nseg; seg0 += nwaves * kWave) {
+    const int64_t seg = seg0 + lane;
     bool active = seg < nseg;
     uint32_t start = 0, end = 0, key = 0;
     if (active) {
@@ -388,25 +394,71 @@ __global__ __launch_bounds__(kBlock) void bias_rows_kernel(const UpdParams p) {
     const TableDesc& t = p.d[side];
     if (EXPORT ? side != p.export_side : t.table == nullptr) active = false;
     const int64_t row = side ? key - p.split : key;
-    float acc = 0.0f;
     const uint32_t lbase = active ? p.long_base[seg] : kNoPiece;
-    if (lbase != kNoPiece) {
-      if (t.stage) {
-        const uint32_t npc = (end - start + kPieceLen - 1) / kPieceLen;
-        for (uint32_t i = lig; i < npc; i += LPS) acc += p.partial[lbase + i];
-      }
-    } else if (active && t.stage) {
-      for (uint32_t e = start + lig; e < end; e += LPS) {
-        const uint32_t c = p.vals[e];
-        if (c != kCodeNone) {
-          const float gv = t.stage[c & kCodeMask];
-          acc += (c & kCodeNeg) ? -gv : gv;
+    const bool summed = active && t.stage != nullptr;           // (no stage: the gradient is 0)
+    const bool quick = summed && lbase == kNoPiece && end - start <= 4;
+    float acc = 0.0f;
+    if (quick) {
+      float e[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        e[i] = 0.0f;
+        if (start + i < end) {
+          const uint32_t c = p.vals[start + i];
+          if (c != kCodeNone) {
+            const float gv = t.stage[c & kCodeMask];
+            e[i] += (c & kCodeNeg) ? -gv : gv;
+          }
         }
       }
+      acc = (e[0] + e[2]) + (e[1] + e[3]);
     }
-    acc = group_sum<LPS>(acc);
+    // the long segments of these 64, four per round, in lane order
+    uint64_t todo = __ballot(summed && !quick);
+    while (todo) {
+      const uint64_t round = todo;
+      int src = 0;
+      bool have = false;
+#pragma unroll
+      for (int i = 0; i < GPW; ++i) {
+        if (todo) {
+          const int b = __ffsll(static_cast<unsigned long long>(todo)) - 1;
+          todo &= todo - 1;
+          if (i == grp) {
+            src = b;
+            have = true;
+          }
+        }
+      }
+      const uint32_t s_start = __shfl(start, src, kWave);
+      const uint32_t s_end = __shfl(end, src, kWave);
+      const uint32_t s_lbase = __shfl(lbase, src, kWave);
+      const int s_side = __shfl(side, src, kWave);
+      const float* stage = p.d[s_side].stage;
+      float a = 0.0f;
+      if (have) {
+        if (s_lbase != kNoPiece) {
+          const uint32_t npc = (s_end - s_start + kPieceLen - 1) / kPieceLen;
+          for (uint32_t i = lig; i < npc; i += LPS) a += p.partial[s_lbase + i];
+        } else {
+          for (uint32_t e = s_start + lig; e < s_end; e += LPS) {
+            const uint32_t c = p.vals[e];
+            if (c != kCodeNone) {
+              const float gv = stage[c & kCodeMask];
+              a += (c & kCodeNeg) ? -gv : gv;
+            }
+          }
+        }
+      }
+      a = group_sum<LPS>(a);
+      // back to the lane that owns the segment: it was the nth long one of this round
+      const int nth = __popcll(static_cast<unsigned long long>(round & ((uint64_t{1} << lane) - 1)));
+      const bool mine = ((round >> lane) & 1) && nth < GPW;
+      const float got = __shfl(a, (nth < GPW ? nth : 0) * LPS, kWave);
+      if (mine) acc = got;
+    }
     const float g = acc * scale;
-    if (active && lig == 0) {
+    if (active) {
       if (EXPORT) {
         const int64_t oseg = side ? seg - first1 : seg;
         p.rows_out[oseg] = row;
@@ -1193,7 +1245,7 @@ int launch_emb(const UpdParams& p, int64_t segs, hipStream_t stream) {
 }
 
 unsigned bias_grid(int64_t segs) {
-  int64_t blocks = (segs + 4 * kWavesPerBlock - 1) / (4 * kWavesPerBlock);
+  int64_t blocks = (segs + kWave * kWavesPerBlock - 1) / (kWave * kWavesPerBlock);
   if (blocks > 4 * kUpdateBlocks) blocks = 4 * kUpdateBlocks;
   if (blocks < 1) blocks = 1;
   return static_cast<unsigned>(blocks);

@@ -10,6 +10,14 @@
 // number (owner, kind, id ascending: the order in which rows are requested from / returned by the
 // owners), and the entry -> segment map rewrites the batch in compact numbers.
 //
+// When the batch is dense in the planned key space (at most kDirectKeysPerLookup keys per lookup:
+// the 11.5 M item lookups of a 1 M batch over 10 M items, say) the same numbering comes cheaper
+// without a sort ("direct" route): one byte mark per looked-up key (plain stores), the marks folded
+// into 64-key bit words with a running count (two streaming passes over the key space, 1 byte + 16
+// bytes per 64 keys), the distinct rows written out in key order from the words, and every element
+// of the batch numbered by ONE 16-byte read: words[key / 64].count + popcount(bits below the key).
+// Same outputs bit for bit (tests/test_gpu_sharded.py runs both routes against plan_torch).
+//
 // Wire layout (one all-to-all each way, embedding rows and their bias values in ONE buffer): every
 // exchange buffer is a matrix of dim-float rows; the block of one peer holds its c embedding rows
 // followed by ceil(c / dim) rows that carry the c bias values (gradient direction: then as many rows
@@ -34,7 +42,8 @@ struct Routes {
   int64_t row_base[2 * kMaxWorld];       // owner-side row offset of the route's kind (0 | U_loc(owner))
 };
 
-void make_routes(Routes& r, int64_t U, int64_t N, int world) {
+// plan_users == false ("users are local"): the user routes are empty -- the key space is the items'
+void make_routes(Routes& r, int64_t U, int64_t N, int world, bool plan_users) {
   r.world = world;
   r.num_users = U;
   r.num_items = N;
@@ -46,10 +55,41 @@ void make_routes(Routes& r, int64_t U, int64_t N, int world) {
       const int q = 2 * o + kind;
       r.row_base[q] = kind ? u_loc : 0;
       r.key_base[q] = key;
-      key += kind ? n_loc : u_loc;
+      key += kind ? n_loc : (plan_users ? u_loc : 0);
     }
   }
-  r.key_base[2 * world] = key;   // == U + N
+  r.key_base[2 * world] = key;   // == (U) + N
+}
+
+// ---- which route plans a batch -------------------------------------------------------------------
+constexpr int64_t kDirectKeysPerLookup = 64;
+constexpr int kWordsPerBlock = 256;     // 64-key words per workgroup of the direct route
+constexpr int kScanBlock = 1024;
+
+bool use_direct(int64_t nkeys, int64_t planned) {
+  return planned > 0 && nkeys <= kDirectKeysPerLookup * planned;
+}
+
+struct DirectWs {
+  uint8_t* marks;          // [nwords * 64] one byte per key: looked up in this batch
+  uint4* words;            // [nwords] {bits 0-31, bits 32-63, distinct keys before the word, -}
+  uint32_t* blk;           // [nblocks + 1] distinct keys of a workgroup's words, then their prefix
+  int64_t* shift;          // [world]
+  int64_t nwords, nblocks;
+  size_t bytes;
+};
+
+DirectWs carve_direct_ws(void* base, int64_t nkeys, int world) {
+  Carver c(base);
+  DirectWs w;
+  w.nwords = (nkeys + 63) / 64;
+  w.nblocks = (w.nwords + kWordsPerBlock - 1) / kWordsPerBlock;
+  w.marks = c.take<uint8_t>(w.nblocks * kWordsPerBlock * 64);
+  w.words = c.take<uint4>(w.nblocks * kWordsPerBlock);
+  w.blk = c.take<uint32_t>(w.nblocks + 1);
+  w.shift = c.take<int64_t>(world);
+  w.bytes = align_up(c.off, 256);
+  return w;
 }
 
 struct PlanWs {
@@ -87,10 +127,13 @@ __device__ __forceinline__ int64_t batch_id(const collie_mf_batch& b, int64_t e,
 // read and updated in place, so only the item ids are planned (entries [B, (2 + K) B) of the batch,
 // stored from 0) and compact_users is simply the local row id / world; a user owned by another rank
 // is reported like an id outside the tables.
+// DIRECT: instead of a (key, element) entry for the sort, the key's byte in `marks` is set.
+template <bool DIRECT>
 __global__ __launch_bounds__(kBlock) void plan_keys_kernel(const collie_mf_batch b, const Routes r,
                                                            int local_rank,
                                                            uint32_t* __restrict__ ekeys,
                                                            uint32_t* __restrict__ ecodes,
+                                                           uint8_t* __restrict__ marks,
                                                            int32_t* __restrict__ cu,
                                                            int64_t* __restrict__ bad_flag) {
   const int64_t total = b.batch * (2 + b.num_neg);
@@ -110,8 +153,13 @@ __global__ __launch_bounds__(kBlock) void plan_keys_kernel(const collie_mf_batch
       cu[e] = owner == local_rank ? static_cast<int32_t>(id / r.world) : 0;
       continue;
     }
-    ekeys[e - skip] = static_cast<uint32_t>(r.key_base[2 * owner + kind] + id / r.world);
-    ecodes[e - skip] = static_cast<uint32_t>(e);
+    const int64_t key = r.key_base[2 * owner + kind] + id / r.world;
+    if (DIRECT) {
+      if (marks[key] == 0) marks[key] = 1;   // (read first: most keys of a dense batch are marked already)
+    } else {
+      ekeys[e - skip] = static_cast<uint32_t>(key);
+      ecodes[e - skip] = static_cast<uint32_t>(e);
+    }
   }
 }
 
@@ -173,6 +221,169 @@ __global__ __launch_bounds__(kBlock) void plan_emit_kernel(
   else cn[e - 2 * B] = compact;
   if (j == 0 || keys[j - 1] != key)
     send_rows[seg] = r.row_base[q] + (static_cast<int64_t>(key) - r.key_base[q]);
+}
+
+// ---- direct route --------------------------------------------------------------------------------
+// one thread per 64-key word: the 64 mark bytes become a bit mask; the word keeps its own count
+// until plan_rows_kernel replaces it by the running count; the workgroup's total goes to blk.
+__global__ __launch_bounds__(kWordsPerBlock) void plan_bits_kernel(const uint8_t* __restrict__ marks,
+                                                                 uint4* __restrict__ words,
+                                                                 uint32_t* __restrict__ blk) {
+  __shared__ uint32_t wsum[kWordsPerBlock / 64];
+  const int64_t w = static_cast<int64_t>(blockIdx.x) * kWordsPerBlock + threadIdx.x;
+  const uint4* src = reinterpret_cast<const uint4*>(marks + w * 64);
+  uint32_t half[2] = {0u, 0u};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const uint4 v = src[q];
+    const uint32_t x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int byte = 0; byte < 4; ++byte)
+        if ((x[i] >> (8 * byte)) & 0xffu) half[q >> 1] |= 1u << ((q & 1) * 16 + i * 4 + byte);
+  }
+  const uint32_t cnt = __popc(half[0]) + __popc(half[1]);
+  words[w] = make_uint4(half[0], half[1], cnt, 0u);
+  uint32_t s = cnt;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if (threadIdx.x % 64 == 0) wsum[threadIdx.x / 64] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t t = 0;
+    for (int i = 0; i < kWordsPerBlock / 64; ++i) t += wsum[i];
+    blk[blockIdx.x] = t;
+  }
+}
+
+// one workgroup: blk[i] <- distinct keys before workgroup i's words, blk[n] <- all distinct keys
+__global__ __launch_bounds__(kScanBlock) void plan_scan_kernel(uint32_t* __restrict__ blk, int64_t n) {
+  __shared__ uint32_t part[kScanBlock / 64];
+  __shared__ uint32_t carry_s;
+  const int tid = threadIdx.x, lane = tid % 64, wv = tid / 64;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < n; base += kScanBlock) {
+    const int64_t i = base + tid;
+    const uint32_t v = i < n ? blk[i] : 0u;
+    uint32_t inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t o = __shfl_up(inc, off, 64);
+      if (lane >= off) inc += o;
+    }
+    if (lane == 63) part[wv] = inc;
+    __syncthreads();
+    uint32_t before = carry_s;
+    for (int j = 0; j < wv; ++j) before += part[j];
+    if (i < n) blk[i] = before + inc - v;
+    __syncthreads();
+    if (tid == kScanBlock - 1) carry_s = before + inc;
+    __syncthreads();
+  }
+  if (tid == 0) blk[n] = carry_s;
+}
+
+// one workgroup per kWordsPerBlock words: running counts into the words, and the workgroup's distinct
+// keys -- gathered in key order in LDS first, so that the rows to request leave as coalesced stores
+__global__ __launch_bounds__(kWordsPerBlock) void plan_rows_kernel(uint4* __restrict__ words,
+                                                                 const uint32_t* __restrict__ blk,
+                                                                 const Routes r,
+                                                                 int64_t* __restrict__ send_rows) {
+  __shared__ uint16_t lkey[kWordsPerBlock * 64];
+  __shared__ uint32_t wsum[kWordsPerBlock / 64];
+  const int tid = threadIdx.x, lane = tid % 64, wv = tid / 64;
+  const int64_t w = static_cast<int64_t>(blockIdx.x) * kWordsPerBlock + tid;
+  uint4 word = words[w];
+  const uint32_t cnt = word.z;
+  uint32_t inc = cnt;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t o = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += o;
+  }
+  if (lane == 63) wsum[wv] = inc;
+  __syncthreads();
+  uint32_t local = inc - cnt;
+  uint32_t total = 0;
+  for (int j = 0; j < kWordsPerBlock / 64; ++j) {
+    if (j < wv) local += wsum[j];
+    total += wsum[j];
+  }
+  const uint32_t before = blk[blockIdx.x];
+  word.z = before + local;
+  words[w] = word;
+  uint64_t bits = (static_cast<uint64_t>(word.y) << 32) | word.x;
+  uint32_t at = local;
+  while (bits) {
+    const int bit = __ffsll(static_cast<unsigned long long>(bits)) - 1;
+    bits &= bits - 1;
+    lkey[at++] = static_cast<uint16_t>(tid * 64 + bit);
+  }
+  __syncthreads();
+  const int64_t key0 = static_cast<int64_t>(blockIdx.x) * kWordsPerBlock * 64;
+  for (uint32_t j = tid; j < total; j += kWordsPerBlock) {
+    const int64_t key = key0 + lkey[j];
+    const int q = route_of(r, static_cast<uint32_t>(key));
+    send_rows[static_cast<int64_t>(before) + j] = r.row_base[q] + (key - r.key_base[q]);
+  }
+}
+
+__device__ __forceinline__ int64_t rank_of_key(const uint4* __restrict__ words, int64_t key) {
+  const uint4 w = words[key >> 6];
+  const uint64_t bits = (static_cast<uint64_t>(w.y) << 32) | w.x;
+  const uint64_t below = bits & ((uint64_t{1} << (key & 63)) - 1);
+  return static_cast<int64_t>(w.z) + __popcll(static_cast<unsigned long long>(below));
+}
+
+// plan_layout_kernel of the direct route: a route starts at the rank of its first key
+__global__ __launch_bounds__(64) void plan_direct_layout_kernel(const uint4* __restrict__ words,
+                                                                const uint32_t* __restrict__ blk,
+                                                                int64_t nblocks, const Routes r, int dim,
+                                                                int64_t* __restrict__ route_counts,
+                                                                int64_t* __restrict__ shift) {
+  __shared__ int64_t first[2 * kMaxWorld + 1];
+  const int nroutes = 2 * r.world;
+  const int64_t nkeys = r.key_base[nroutes];
+  const int64_t total = blk[nblocks];
+  if (static_cast<int>(threadIdx.x) <= nroutes) {
+    const int64_t k = r.key_base[threadIdx.x];
+    first[threadIdx.x] = k < nkeys ? rank_of_key(words, k) : total;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  int64_t pad = 0;
+  for (int o = 0; o < r.world; ++o) {
+    shift[o] = pad;
+    const int64_t rows = first[2 * o + 2] - first[2 * o];
+    pad += (rows + dim - 1) / dim;
+  }
+  for (int q = 0; q < nroutes; ++q) route_counts[q] = first[q + 1] - first[q];
+  route_counts[nroutes] = total;
+}
+
+// one thread per planned element of the batch, in batch order (coalesced stores)
+__global__ __launch_bounds__(kBlock) void plan_direct_emit_kernel(
+    const collie_mf_batch b, const Routes r, int local_rank, const uint4* __restrict__ words,
+    const int64_t* __restrict__ shift, int32_t* __restrict__ cu, int32_t* __restrict__ cp,
+    int64_t* __restrict__ cn) {
+  const int64_t B = b.batch;
+  const int64_t total = B * (2 + b.num_neg);
+  const int64_t skip = local_rank >= 0 ? B : 0;
+  for (int64_t e = skip + static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; e < total;
+       e += static_cast<int64_t>(gridDim.x) * kBlock) {
+    int kind;
+    int64_t id = batch_id(b, e, kind);
+    const int64_t rows = kind ? r.num_items : r.num_users;
+    if (id < 0 || id >= rows) id = id < 0 ? 0 : rows - 1;   // as plan_keys_kernel (reported there)
+    const int64_t owner = id % r.world;
+    const int64_t key = r.key_base[2 * owner + kind] + id / r.world;
+    const int64_t compact = rank_of_key(words, key) + shift[owner];
+    if (e < B) cu[e] = static_cast<int32_t>(compact);
+    else if (e < 2 * B) cp[e - B] = static_cast<int32_t>(compact);
+    else cn[e - 2 * B] = compact;
+  }
 }
 
 // owner side of the lookup exchange: the rows the peers requested, written as the peers' blocks of the
@@ -295,9 +506,17 @@ extern "C" int collie_shard_unpack_bias(const float* buf, int64_t buf_rows, int3
   return check_launch("unpack_bias_kernel");
 }
 
-extern "C" size_t collie_shard_plan_workspace_bytes(int64_t batch, int32_t num_neg, int32_t world) {
-  if (batch < 1 || num_neg < 1 || world < 1 || world > kMaxWorld) return 0;
-  return carve_plan_ws(nullptr, batch * (2 + static_cast<int64_t>(num_neg)), world).bytes;
+extern "C" size_t collie_shard_plan_workspace_bytes(int64_t batch, int32_t num_neg, int32_t world,
+                                                    int64_t num_users, int64_t num_items,
+                                                    int32_t local_rank) {
+  if (batch < 1 || num_neg < 1 || world < 1 || world > kMaxWorld || num_users < 1 || num_items < 1 ||
+      num_users + num_items >= (int64_t{1} << 31))
+    return 0;
+  const int64_t lookups = batch * (2 + static_cast<int64_t>(num_neg));
+  const int64_t planned = local_rank >= 0 ? lookups - batch : lookups;
+  const int64_t nkeys = (local_rank >= 0 ? 0 : num_users) + num_items;
+  if (use_direct(nkeys, planned)) return carve_direct_ws(nullptr, nkeys, world).bytes;
+  return carve_plan_ws(nullptr, lookups, world).bytes;
 }
 
 extern "C" int collie_shard_plan(const collie_mf_batch* b, int64_t num_users, int64_t num_items,
@@ -320,24 +539,51 @@ extern "C" int collie_shard_plan(const collie_mf_batch* b, int64_t num_users, in
   COLLIE_REQUIRE(send_capacity >= max_rows, "shard_plan: send_rows holds %lld rows, need %lld",
                  static_cast<long long>(send_capacity), static_cast<long long>(max_rows));
   Routes r;
-  make_routes(r, num_users, num_items, world);
+  make_routes(r, num_users, num_items, world, local_rank < 0);
+  const int nroutes = 2 * world;
+  // users local: the first B entries of the batch are not planned (only the item ids are)
+  const int64_t planned = local_rank >= 0 ? lookups - b->batch : lookups;
+  const int64_t nkeys = r.key_base[nroutes];
+  COLLIE_CHECK_HIP(hipMemsetAsync(route_counts, 0, sizeof(int64_t) * (nroutes + 2), stream));
+  int64_t grid = (lookups + kBlock - 1) / kBlock;
+  if (grid > 8192) grid = 8192;
+  if (use_direct(nkeys, planned)) {
+    DirectWs ws = carve_direct_ws(workspace, nkeys, world);
+    COLLIE_REQUIRE(workspace && workspace_bytes >= ws.bytes,
+                   "shard_plan: workspace too small: need %zu bytes, got %zu", ws.bytes,
+                   workspace_bytes);
+    COLLIE_CHECK_HIP(hipMemsetAsync(ws.marks, 0, static_cast<size_t>(ws.nblocks) * kWordsPerBlock * 64,
+                                    stream));
+    hipLaunchKernelGGL(plan_keys_kernel<true>, dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0,
+                       stream, *b, r, local_rank, nullptr, nullptr, ws.marks, compact_users,
+                       route_counts + nroutes + 1);
+    if (check_launch("plan_keys_kernel")) return -2;
+    hipLaunchKernelGGL(plan_bits_kernel, dim3(static_cast<unsigned>(ws.nblocks)),
+                       dim3(kWordsPerBlock), 0, stream, ws.marks, ws.words, ws.blk);
+    if (check_launch("plan_bits_kernel")) return -2;
+    hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(kScanBlock), 0, stream, ws.blk, ws.nblocks);
+    if (check_launch("plan_scan_kernel")) return -2;
+    hipLaunchKernelGGL(plan_rows_kernel, dim3(static_cast<unsigned>(ws.nblocks)),
+                       dim3(kWordsPerBlock), 0, stream, ws.words, ws.blk, r, send_rows);
+    if (check_launch("plan_rows_kernel")) return -2;
+    hipLaunchKernelGGL(plan_direct_layout_kernel, dim3(1), dim3(64), 0, stream, ws.words, ws.blk,
+                       ws.nblocks, r, dim, route_counts, ws.shift);
+    if (check_launch("plan_direct_layout_kernel")) return -2;
+    hipLaunchKernelGGL(plan_direct_emit_kernel, dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0,
+                       stream, *b, r, local_rank, ws.words, ws.shift, compact_users, compact_pos,
+                       compact_neg);
+    return check_launch("plan_direct_emit_kernel");
+  }
   PlanWs ws = carve_plan_ws(workspace, lookups, world);
   COLLIE_REQUIRE(workspace && workspace_bytes >= ws.bytes,
                  "shard_plan: workspace too small: need %zu bytes, got %zu", ws.bytes,
                  workspace_bytes);
-  const int nroutes = 2 * world;
-  COLLIE_CHECK_HIP(hipMemsetAsync(route_counts, 0, sizeof(int64_t) * (nroutes + 2), stream));
-  int64_t grid = (lookups + kBlock - 1) / kBlock;
-  if (grid > 8192) grid = 8192;
-  hipLaunchKernelGGL(plan_keys_kernel, dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0, stream,
-                     *b, r, local_rank, ws.sort.ekeys, ws.sort.ecodes, compact_users,
+  hipLaunchKernelGGL(plan_keys_kernel<false>, dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0,
+                     stream, *b, r, local_rank, ws.sort.ekeys, ws.sort.ecodes, nullptr, compact_users,
                      route_counts + nroutes + 1);
   if (check_launch("plan_keys_kernel")) return -2;
-  // users local: the first B entries of the batch are not planned (the sort sees the item ids only)
-  const int64_t planned = local_rank >= 0 ? lookups - b->batch : lookups;
   ws.sort.m = planned;
   ws.sort.ntiles = (planned + kSortTile - 1) / kSortTile;
-  const int64_t nkeys = num_users + num_items;
   if (sort_and_segment(ws.sort, nkeys, 0xffffffffu, stream, ws.seg_of)) return -1;
   hipLaunchKernelGGL(plan_layout_kernel, dim3(1), dim3(64), 0, stream, sorted_keys(ws.sort, nkeys),
                      ws.seg_of, ws.sort.nseg, planned, r, dim, route_counts, ws.shift);

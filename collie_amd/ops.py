@@ -538,7 +538,7 @@ def shard_wire_rows(counts, dim, gradient):
 
 
 class ShardPlanner:
-    """Sort scratch of the requester-side plan + the per-step plan call (``collie_shard_plan``)."""
+    """Scratch of the requester-side plan + the per-step plan call (``collie_shard_plan``)."""
 
     def __init__(self, num_users, num_items, world, dim, device):
         self.num_users, self.num_items = int(num_users), int(num_items)
@@ -551,7 +551,8 @@ class ShardPlanner:
         batch = make_batch(users, pos_items, neg_items)
         B, K = neg_items.shape
         dev = users.device
-        need = int(load().collie_shard_plan_workspace_bytes(B, K, self.world))
+        need = int(load().collie_shard_plan_workspace_bytes(B, K, self.world, self.num_users,
+                                                            self.num_items, local_rank))
         if need == 0:
             raise _lib.CollieHipError('collie_shard_plan_workspace_bytes: bad sizes')
         if self.buf is None or self.buf.numel() < need:

@@ -163,9 +163,15 @@ class HipEngine:
             mark('gradient_export')     # everything before this mark is K1 (+ its loss finalize)
         wire, counts, self._export_ws = ops.shard_export_grads(
             tables, batch, buf, lookup_counts, send_rows, scale, self._export_ws, users_local)
-        if users_local:
+        if not users_local:
+            return loss, wire, counts
+
+        def local_user_rows():
             # the user rows never left: their update runs on the segments the export just built
-            # (the user-bias gradient of a pairwise loss is exactly zero: nothing to do there)
+            # (the user-bias gradient of a pairwise loss is exactly zero: nothing to do there).
+            # Handed back as a callable: train_step launches it AFTER the copy of the gradient counts
+            # to the host has been queued, so that the host's wait for the counts ends while this
+            # kernel still runs and the GPU never idles for the read.
             hp = model.hparams
             h = model._HYPER[hp['optimizer']]
             ocfg = ops.optim_cfg(hp['optimizer'], step, hp['lr'], h.get('beta1', 0.9),
@@ -175,7 +181,7 @@ class HipEngine:
             ops.train_update(tables, batch, buf, 0, False, step_id,
                              {_lib.SIDE_USER: (ocfg, s1[:nu] if s1 is not None else None,
                                                s2[:nu] if s2 is not None else None, None)}, scale)
-        return loss, wire, counts
+        return loss, wire, counts, local_user_rows
 
     # optimizer.step() of the combined shard table on the gradient blocks the peers sent
     def owner_update(self, model, wire, peer_counts, step):
@@ -478,6 +484,7 @@ class ShardedMatrixFactorizationModel:
         self.last_exchange = {}
         self._ahead = None          # (batch tensors, plan, ready event) of plan_ahead()
         self._plan_stream = None
+        self._pinned = {}           # small page-locked host buffers of the two count reads
 
     @staticmethod
     def _new_state(algo, table):
@@ -637,8 +644,27 @@ class ShardedMatrixFactorizationModel:
             steps += name == 'plan'
         return {k: v / max(steps, 1) for k, v in sums.items()}
 
-    def _plan(self, users, pos_items, neg_items, users_local=False):
-        """Steps 1-2 of the module docstring: compact numbering + the request exchange."""
+    def _host_read(self, name, dev_tensor):
+        """Queue the copy of a small device tensor to the host; returns a function that waits for
+        THAT copy (not for the stream) and returns the values as nested lists."""
+        if dev_tensor.device.type != 'cuda':
+            return dev_tensor.tolist
+        pin = self._pinned.get(name)
+        if pin is None or pin.shape != dev_tensor.shape:
+            pin = self._pinned[name] = torch.empty(dev_tensor.shape, dtype=dev_tensor.dtype,
+                                                   pin_memory=True)
+        pin.copy_(dev_tensor, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+
+        def read():
+            done.synchronize()
+            return pin.tolist()
+        return read
+
+    def _plan_start(self, users, pos_items, neg_items, users_local=False):
+        """Steps 1-2 of the module docstring up to the host read: compact numbering, the exchange
+        of the counts, and their copy to the host queued (``_plan_finish`` waits for it)."""
         comm, G = self.comm, self.comm.world
         dev = users.device
         B, K = neg_items.shape
@@ -664,21 +690,33 @@ class ShardedMatrixFactorizationModel:
         meta[:, 3] = counts[2 * G + 1]
         got = comm.all_to_all(meta, [1] * G, [1] * G)
         # The split sizes of the row exchanges must be known to the host: the first read-back of
-        # the step.  With plan_ahead() it happens on a side stream while the previous step computes.
-        meta_h, got_h = torch.stack([meta, got]).cpu().tolist()
+        # the step.  Planned inside the previous step (train_step(next_batch=...)) or on a side
+        # stream (plan_ahead()), it completes while the previous step still computes.
+        return dict(B=B, K=K, cu=cu, cp=cp, cn=cn, send_rows=send_rows, users_local=users_local,
+                    read=self._host_read('plan', torch.stack([meta, got])))
+
+    def _plan_finish(self, p):
+        """The host read of a started plan + the exchange of the requested row numbers."""
+        read = p.pop('read', None)
+        if read is None:
+            return p
+        meta_h, got_h = read()
         if any(row[3] for row in got_h):
             raise IndexError('index out of range in self: a user or item id is outside the tables'
                              + (' (or, with users_local, a user is owned by another rank)'
-                                if users_local else ''))
+                                if p['users_local'] else ''))
         send_counts = [r[0] + r[1] for r in meta_h]      # rows this rank requests from each peer
         recv_counts = [r[0] + r[1] for r in got_h]       # rows each peer requests from this rank
         n = sum(send_counts)
-        B_global = sum(r[2] for r in got_h)
         # rows of the owner's combined table (user rows first, item rows behind them)
-        crow = comm.all_to_all(send_rows[:n], send_counts, recv_counts)
-        return dict(n=n, B=B, K=K, B_global=B_global, crow=crow, send_counts=send_counts,
-                    recv_counts=recv_counts, cu=cu, cp=cp, cn=cn, send_rows=send_rows,
-                    users_local=users_local)
+        crow = self.comm.all_to_all(p['send_rows'][:n], send_counts, recv_counts)
+        p.update(n=n, B_global=sum(r[2] for r in got_h), crow=crow, send_counts=send_counts,
+                 recv_counts=recv_counts)
+        return p
+
+    def _plan(self, users, pos_items, neg_items, users_local=False):
+        """Steps 1-2 of the module docstring: compact numbering + the request exchange."""
+        return self._plan_finish(self._plan_start(users, pos_items, neg_items, users_local))
 
     def plan_ahead(self, batch, users_local=False) -> None:
         """
@@ -722,12 +760,12 @@ class ShardedMatrixFactorizationModel:
             if same:
                 if ready is not None:
                     torch.cuda.current_stream(self.device).wait_event(ready)
-                return plan
+                return self._plan_finish(plan)      # (a plan started by train_step(next_batch=))
             raise RuntimeError('plan_ahead() was called with a different batch than the next '
                                'train_step()')
         return self._plan(users, pos_items, neg_items, users_local)
 
-    def train_step(self, batch, users_local=False) -> torch.Tensor:
+    def train_step(self, batch, users_local=False, next_batch=None) -> torch.Tensor:
         """
         ``calculate_loss`` + ``backward`` + both ``optimizer.step()`` calls for this rank's slice
         ``((users, pos_items), neg_items)`` of the global batch; returns the global-batch loss
@@ -738,6 +776,15 @@ class ShardedMatrixFactorizationModel:
         or ``route_batch_to_user_owners``).  User rows are then read and updated in place -- one
         of the 2 + K rows a sample looks up and one of its at most 3 gradient rows never travel
         -- and only item rows are exchanged.  Checked on the device: a foreign user raises.
+
+        ``next_batch``: this rank's slice of the NEXT step, if the caller has it already (a loader
+        that runs one batch ahead).  Its plan -- which depends on ids only -- is then queued INSIDE
+        this step, on the same stream, in front of the owner update: the host's read of its counts
+        completes while the owner update still runs, the next ``train_step`` (which must be called
+        with that batch and the same ``users_local``) finds its plan ready, and the GPU never waits
+        for the host at a step boundary.  Unlike ``plan_ahead()`` nothing runs concurrently, so the
+        bandwidth-bound kernels of the step are not slowed down by the planner.  Collective like the
+        step itself: every rank passes a next batch, or none does.
         """
         (users, pos_items), neg_items = batch
         if neg_items.dim() == 1:
@@ -757,19 +804,35 @@ class ShardedMatrixFactorizationModel:
         # 4. fused forward on the compact table + gradient rows into the owners' blocks
         mark('forward')
         scale = torch.full((1,), p['B'] / max(p['B_global'], 1), dtype=torch.float32, device=dev)
+        local_rows = None
         if p['B'] == 0:
             loss = torch.zeros(1, dtype=torch.float32, device=dev)
             gwire = torch.empty(0, D, dtype=torch.float32, device=dev)
             gcounts = torch.zeros(G + 1, dtype=torch.int64, device=dev)
         else:
-            loss, gwire, gcounts = self._forward_export(p, cw, pos_items, neg_items, scale,
-                                                        users_local, step)
+            loss, gwire, gcounts, *rest = self._forward_export(p, cw, pos_items, neg_items, scale,
+                                                               users_local, step)
+            local_rows = rest[0] if rest else None
         # 5. gradients home: how many rows each owner gets depends on the forward pass (which
-        # negative each sample selected), so the counts are exchanged and read back first
+        # negative each sample selected), so the counts are exchanged and read back first -- the
+        # step's second host read.  Its copy is queued BEFORE the work that does not depend on it
+        # (the update of the local user rows, the plan of the next batch), and the host waits for
+        # the copy alone.
         mark('gradient_exchange')
         cnt_send = gcounts[:G]
         cnt_recv = comm.all_to_all(cnt_send, [1] * G, [1] * G)
-        send_c, recv_c = torch.stack([cnt_send, cnt_recv]).cpu().tolist()
+        read_counts = self._host_read('grad', torch.stack([cnt_send, cnt_recv]))
+        if local_rows is not None:
+            mark('local_user_rows')
+            local_rows()
+        if next_batch is not None:
+            mark('plan_next')
+            (nu_, np_), nn_ = next_batch
+            if nn_.dim() == 1:
+                nn_ = nn_.reshape(-1, 1)
+            self._ahead = ((nu_, np_, nn_), self._plan_start(nu_, np_, nn_, users_local), None)
+        mark('gradient_exchange')
+        send_c, recv_c = read_counts()
         gsplit_send = [wire_rows(c, D, True) for c in send_c]
         gsplit_recv = [wire_rows(c, D, True) for c in recv_c]
         grecv = comm.all_to_all(gwire[:sum(gsplit_send)], gsplit_send, gsplit_recv)

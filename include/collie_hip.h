@@ -335,7 +335,9 @@ size_t collie_sparse_rows_workspace_bytes(int64_t m, int32_t dim);
  * collie_shard_plan replaces, for one rank's batch ((users, pos_items), neg_items)
  * (base_pipeline.py:603-613), the host-side de-duplication a sharded nn.Embedding lookup would
  * need: finds the distinct user / item rows the batch looks up (stable radix sort of the (2 + K) B
- * ids: the cost is proportional to the lookups, not to the tables), orders them by (owner = id mod
+ * ids: cost proportional to the lookups, not to the tables; or, when the planned tables hold at
+ * most 64 rows per lookup, one mark per looked-up row + a popcount scan over the marks -- same
+ * outputs), orders them by (owner = id mod
  * world, kind = user|item, id) -- the order in which they are requested from and returned by the
  * owners -- and rewrites the batch in compact row numbers = rows of the lookup buffer the owners will
  * fill (so the numbers skip the bias rows between two owners' blocks).
@@ -353,11 +355,12 @@ size_t collie_sparse_rows_workspace_bytes(int64_t m, int32_t dim);
  * ids are planned, compact_users [b] = users[b] / world (the local row), and a user owned by
  * another rank is reported through route_counts [2*world + 1] like an id outside the tables.
  * local_rank = -1: users are requested from their owners like items.
- * workspace: collie_shard_plan_workspace_bytes(batch, num_neg, world) bytes (need not be zeroed).
- * world <= 16.
+ * workspace: collie_shard_plan_workspace_bytes(batch, num_neg, world, num_users, num_items,
+ * local_rank) bytes for the same arguments (need not be zeroed; 0: bad arguments).  world <= 16.
  * ------------------------------------------------------------------------------------------- */
 int64_t collie_shard_wire_rows(const int64_t* counts, int32_t world, int32_t dim, int32_t gradient);
-size_t collie_shard_plan_workspace_bytes(int64_t batch, int32_t num_neg, int32_t world);
+size_t collie_shard_plan_workspace_bytes(int64_t batch, int32_t num_neg, int32_t world,
+                                         int64_t num_users, int64_t num_items, int32_t local_rank);
 int collie_shard_plan(const collie_mf_batch* b, int64_t num_users, int64_t num_items,
                       int32_t world, int32_t dim, int32_t local_rank, void* workspace,
                       size_t workspace_bytes,

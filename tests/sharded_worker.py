@@ -86,8 +86,11 @@ def check_training(rank, world, loss, optimizer, bias_optimizer, K, metadata=Non
         if metadata is not None:
             kw = dict(metadata={'genre': metadata['genre'].cpu().numpy()}, metadata_weights=weights)
         out = ref.step(users, pos, neg, kind, num_items=N, **kw)
-        got = model.train_step(slices[step], users_local=route)
-        if step % 2 == 0 and step + 1 < steps:        # every other step is planned one step ahead
+        # the plan of a step is made, in turn: inside the step itself, on a side stream after the
+        # previous step (plan_ahead), inside the previous step (next_batch=)
+        nxt = slices[step + 1] if step % 3 == 1 and step + 1 < steps else None
+        got = model.train_step(slices[step], users_local=route, next_batch=nxt)
+        if step % 3 == 0 and step + 1 < steps:
             model.plan_ahead(slices[step + 1], users_local=route)
         np.testing.assert_allclose(got.item(), out['loss'], rtol=2e-5, atol=1e-7)
     sd = model.state_dict()

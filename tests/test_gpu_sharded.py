@@ -124,11 +124,16 @@ def test_world_2_on_one_gpu_matches_unsharded_oracle():
 @pytest.mark.parametrize('local_rank', [-1, 0, 2])
 @pytest.mark.parametrize('G', [1, 2, 3, 8])
 @pytest.mark.parametrize('neg_dtype', [torch.int64, torch.int32])
-def test_hip_shard_plan_equals_torch_plan(G, neg_dtype, local_rank):
+@pytest.mark.parametrize('route', ['direct', 'sort', 'direct_many_blocks'])
+def test_hip_shard_plan_equals_torch_plan(G, neg_dtype, local_rank, route):
     from collie_amd import ops
     from collie_amd.sharded import plan_torch
     dev = torch.device('cuda:0')
-    U, N, B, K, D = 9001, 5003, 3000, 7, 24
+    # the library marks the looked-up rows of tables with at most 64 rows per lookup ("direct"),
+    # and sorts the ids of sparser batches: same outputs either way
+    U, N, B, K, D = {'direct': (9001, 5003, 3000, 7, 24),
+                     'sort': (3_000_001, 2_000_003, 500, 3, 24),
+                     'direct_many_blocks': (1_200_001, 700_001, 40_000, 5, 8)}[route]
     if local_rank >= G:
         pytest.skip('rank outside the world')
     rng = np.random.default_rng(G)

@@ -39,9 +39,18 @@ for i in range(steps):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
 print(f'B={B} with plan_ahead: {dt * 1e3:.3f} ms/step, {B * 11 / dt / 1e9:.3f} G interactions/s')
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for i in range(steps):
+    m.train_step(batches[i % 8], users_local=users_local,
+                 next_batch=batches[(i + 1) % 8] if i + 1 < steps else None)
+torch.cuda.synchronize()
+dt_next = (time.perf_counter() - t0) / steps
+print(f'B={B} with next_batch: {dt_next * 1e3:.3f} ms/step, {B * 11 / dt_next / 1e9:.3f} G interactions/s')
 m.profile_phases(True)
 for i in range(10):
-    m.train_step(batches[i % 8], users_local=users_local)
+    m.train_step(batches[i % 8], users_local=users_local,
+                 next_batch=batches[(i + 1) % 8] if i + 1 < 10 else None)
 phases = {k: round(v, 3) for k, v in m.phase_times().items()}
 print('phase ms:', phases)
 m.profile_phases(False)
@@ -50,6 +59,7 @@ if out_json:
     with open(out_json, 'w') as f:
         json.dump({'shape': sys.argv[3] if len(sys.argv) > 3 else 'c2', 'world': 1, 'batch': B, 'users_local': users_local,
                    'ms_per_step': round(dt0 * 1e3, 3), 'ms_per_step_plan_ahead': round(dt * 1e3, 3),
+                   'ms_per_step_next_batch': round(dt_next * 1e3, 3),
                    'phase_ms': phases, 'exchange': m.last_exchange}, f, indent=1)
 if os.environ.get('PROFILE'):
     from torch.profiler import ProfilerActivity, profile
