@@ -476,6 +476,76 @@ __global__ __launch_bounds__(kBlock) void bias_rows_kernel(const UpdParams p) {
   }
 }
 
+// Batches whose segments are long on average (tables much smaller than the batch: the ML-20M shape has
+// 18 entries per row at B = 1 M): 16 lanes per segment from the start, four segments per wave.
+template <bool EXPORT>
+__global__ __launch_bounds__(kBlock) void bias_rows_group_kernel(const UpdParams p) {
+  constexpr int LPS = 16;  // lanes per segment
+  constexpr int GPW = kWave / LPS;
+  const int lane = lane_id();
+  const int grp = lane / LPS;
+  const int lig = lane % LPS;
+  const uint32_t nseg = p.nseg[0];
+  const uint32_t first1 = p.nseg[1];
+  const float scale = p.grad_scale ? *p.grad_scale : 1.0f;
+  const float nl0 = p.dyn ? p.dyn->neg_lr[p.dyn_base] : p.d[0].h.neg_lr;
+  const float nl1 = p.dyn ? p.dyn->neg_lr[p.dyn_base + 1] : p.d[1].h.neg_lr;
+  const float bc0 = p.dyn ? p.dyn->bc2_sqrt[p.dyn_base] : p.d[0].h.bc2_sqrt;
+  const float bc1 = p.dyn ? p.dyn->bc2_sqrt[p.dyn_base + 1] : p.d[1].h.bc2_sqrt;
+  const int step = p.dyn ? p.dyn->step : p.step;
+  const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+  if (EXPORT && blockIdx.x == 0 && threadIdx.x == 0)
+    *p.count_out = static_cast<int32_t>(p.export_side ? nseg - first1 : first1);
+  for (int64_t seg0 = (static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + threadIdx.x / kWave) * GPW;
+       seg0 < nseg; seg0 += nwaves * GPW) {
+    const int64_t seg = seg0 + grp;
+    bool active = seg < nseg;
+    uint32_t start = 0, end = 0, key = 0;
+    if (active) {
+      start = p.seg_start[seg];
+      end = p.seg_start[seg + 1];
+      key = p.keys[start];
+    }
+    const int side = key >= p.split ? 1 : 0;
+    const TableDesc& t = p.d[side];
+    if (EXPORT ? side != p.export_side : t.table == nullptr) active = false;
+    const int64_t row = side ? key - p.split : key;
+    float acc = 0.0f;
+    const uint32_t lbase = active ? p.long_base[seg] : kNoPiece;
+    if (lbase != kNoPiece) {
+      if (t.stage) {
+        const uint32_t npc = (end - start + kPieceLen - 1) / kPieceLen;
+        for (uint32_t i = lig; i < npc; i += LPS) acc += p.partial[lbase + i];
+      }
+    } else if (active && t.stage) {
+      for (uint32_t e = start + lig; e < end; e += LPS) {
+        const uint32_t c = p.vals[e];
+        if (c != kCodeNone) {
+          const float gv = t.stage[c & kCodeMask];
+          acc += (c & kCodeNeg) ? -gv : gv;
+        }
+      }
+    }
+    acc = group_sum<LPS>(acc);
+    const float g = acc * scale;
+    if (active && lig == 0) {
+      if (EXPORT) {
+        const int64_t oseg = side ? seg - first1 : seg;
+        p.rows_out[oseg] = row;
+        p.vals_out[oseg] = g;
+      } else {
+        float s1 = t.s1 ? t.s1[row] : 0.0f;
+        float s2 = t.s2 ? t.s2[row] : 0.0f;
+        t.table[row] = apply_update2(t.h, side ? nl1 : nl0, side ? bc1 : bc0, t.table[row], g, s1, s2);
+        if (t.s1) t.s1[row] = s1;
+        if (t.s2) t.s2[row] = s2;
+        if (t.row_stamp) t.row_stamp[row] = step;
+        if (t.seg_stamp) t.seg_stamp[row] = step;
+      }
+    }
+  }
+}
+
 // ---- small batches: coalesce and update in ONE launch, without a sort --------------------------------
 // At most kSmallMax entries (the reference's default batch of 1,024 samples): every launch costs more
 // than its work, so the sort, the embedding-row update and the bias-row update become one kernel.
@@ -1244,11 +1314,24 @@ int launch_emb(const UpdParams& p, int64_t segs, hipStream_t stream) {
   return check_launch("emb_rows_kernel");
 }
 
-unsigned bias_grid(int64_t segs) {
-  int64_t blocks = (segs + kWave * kWavesPerBlock - 1) / (kWave * kWavesPerBlock);
+unsigned bias_grid(int64_t segs, int segs_per_wave) {
+  int64_t blocks = (segs + segs_per_wave * kWavesPerBlock - 1) / (segs_per_wave * kWavesPerBlock);
   if (blocks > 4 * kUpdateBlocks) blocks = 4 * kUpdateBlocks;
   if (blocks < 1) blocks = 1;
   return static_cast<unsigned>(blocks);
+}
+
+// entries: upper bound of the segments; nkeys: size of the key space they fall into.  Sparse batches
+// (at most two entries per key on average) take the lane-per-segment kernel.
+template <bool EXPORT>
+int launch_bias_rows(const UpdParams& p, int64_t entries, int64_t nkeys, hipStream_t stream) {
+  if (2 * nkeys >= entries)
+    hipLaunchKernelGGL(bias_rows_kernel<EXPORT>, dim3(bias_grid(entries, kWave)), dim3(kBlock), 0,
+                       stream, p);
+  else
+    hipLaunchKernelGGL(bias_rows_group_kernel<EXPORT>, dim3(bias_grid(entries, 4)), dim3(kBlock), 0,
+                       stream, p);
+  return check_launch("bias_rows_kernel");
 }
 
 unsigned piece_bias_grid(int64_t entries) {
@@ -1482,9 +1565,7 @@ extern "C" int collie_mf_train_update(const collie_mf_tables* t, const collie_mf
     if (!small_coalesce(3 * b->batch))
       hipLaunchKernelGGL(piece_bias_kernel<false>, dim3(piece_bias_grid(3 * b->batch)), dim3(kBlock),
                          0, stream, p);
-    hipLaunchKernelGGL(bias_rows_kernel<false>, dim3(bias_grid(3 * b->batch)), dim3(kBlock), 0,
-                       stream, p);
-    if (check_launch("bias_rows_kernel")) return -2;
+    if (launch_bias_rows<false>(p, 3 * b->batch, t->num_users + t->num_items, stream)) return -2;
   } else if (launch_emb<false>(p, 3 * b->batch, stream)) {
     return -2;
   }
@@ -1696,9 +1777,7 @@ extern "C" int collie_mf_train_export_grad(const collie_mf_tables* t, const coll
     if (!small_coalesce(3 * b->batch))
       hipLaunchKernelGGL(piece_bias_kernel<true>, dim3(piece_bias_grid(3 * b->batch)), dim3(kBlock),
                        0, stream, p);
-    hipLaunchKernelGGL(bias_rows_kernel<true>, dim3(bias_grid(3 * b->batch)), dim3(kBlock), 0,
-                       stream, p);
-    if (check_launch("export_grad")) return -2;
+    if (launch_bias_rows<true>(p, 3 * b->batch, t->num_users + t->num_items, stream)) return -2;
   } else if (launch_emb<true>(p, 3 * b->batch, stream)) {
     return -2;
   }
@@ -1939,8 +2018,7 @@ extern "C" int collie_shard_owner_update(float* emb, float* bias, int64_t num_ro
     if (launch_emb<false>(p, m, stream)) return -2;
     if (!small_coalesce(m))
       hipLaunchKernelGGL(piece_bias_kernel<false>, dim3(piece_bias_grid(m)), dim3(kBlock), 0, stream, q);
-    hipLaunchKernelGGL(bias_rows_kernel<false>, dim3(bias_grid(m)), dim3(kBlock), 0, stream, q);
-    if (check_launch("bias_rows_kernel")) return -2;
+    if (launch_bias_rows<false>(q, m, num_rows, stream)) return -2;
   }
   // looked-up item rows without a gradient entry: SparseAdam decays their moments (K5b)
   const int64_t items = num_rows - item_base;
@@ -2067,8 +2145,7 @@ extern "C" int collie_dense_rows_update(float* table, int64_t num_rows, int32_t 
     if (!small_coalesce(m))
       hipLaunchKernelGGL(piece_bias_kernel<false>, dim3(piece_bias_grid(m)), dim3(kBlock), 0, stream,
                        p);
-    hipLaunchKernelGGL(bias_rows_kernel<false>, dim3(bias_grid(m)), dim3(kBlock), 0, stream, p);
-    if (check_launch("dense_rows_update")) return -2;
+    if (launch_bias_rows<false>(p, m, num_rows, stream)) return -2;
   } else if (launch_emb<false>(p, m, stream)) {
     return -2;
   }

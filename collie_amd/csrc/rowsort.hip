@@ -36,46 +36,17 @@ __global__ __launch_bounds__(kBlock) void radix_hist_kernel(const uint32_t* __re
   (void)totals;
 }
 
-// one workgroup per digit: the number of keys with that digit = the sum of its per-tile counts.
-// (Formerly every tile added its counts to totals[] with global atomics: ntiles x RADIX atomics on
-// RADIX addresses, which cost more than the histogram itself.)
-__global__ __launch_bounds__(kBlock) void radix_totals_kernel(const uint32_t* __restrict__ hist,
-                                                              int64_t ntiles,
-                                                              uint32_t* __restrict__ totals) {
-  __shared__ uint32_t sh[kBlock / kWave];
-  const uint32_t* row = hist + static_cast<int64_t>(blockIdx.x) * ntiles;
-  uint32_t local = 0;
-  for (int64_t i = threadIdx.x; i < ntiles; i += kBlock) local += row[i];
-#pragma unroll
-  for (int o = kWave / 2; o > 0; o >>= 1) local += __shfl_xor(local, o, kWave);
-  if ((threadIdx.x & (kWave - 1)) == 0) sh[threadIdx.x / kWave] = local;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t t = 0;
-    for (int w = 0; w < kBlock / kWave; ++w) t += sh[w];
-    totals[blockIdx.x] = t;
-  }
-}
-
-// one workgroup per digit: exclusive scan of that digit's per-tile counts, offset by the number
-// of keys with a smaller digit.
+// one workgroup per digit: exclusive scan of that digit's per-tile counts (positions inside the
+// digit's bucket) and the bucket's size.  Where a bucket starts -- the keys with a smaller digit --
+// is added by the scatter kernel from the RADIX sizes (one small scan per workgroup there instead of
+// one more launch per pass here).  (The first version had every tile add its counts to totals[]
+// with global atomics: ntiles x RADIX atomics on RADIX addresses cost more than the histogram.)
 __global__ __launch_bounds__(kBlock) void radix_scan_kernel(uint32_t* __restrict__ hist,
                                                             int64_t ntiles,
-                                                            const uint32_t* __restrict__ totals) {
+                                                            uint32_t* __restrict__ totals) {
   __shared__ uint32_t sh[kBlock];
   const int d = blockIdx.x;
   const int tid = threadIdx.x;
-  uint32_t below = 0;
-  for (int i = tid; i < d; i += kBlock) below += totals[i];
-  sh[tid] = below;
-  __syncthreads();
-  for (int o = kBlock / 2; o > 0; o >>= 1) {
-    if (tid < o) sh[tid] += sh[tid + o];
-    __syncthreads();
-  }
-  const uint32_t digit_base = sh[0];
-  __syncthreads();
-
   uint32_t* row = hist + static_cast<int64_t>(d) * ntiles;
   const int64_t per = (ntiles + kBlock - 1) / kBlock;
   const int64_t lo = tid * per;
@@ -90,7 +61,8 @@ __global__ __launch_bounds__(kBlock) void radix_scan_kernel(uint32_t* __restrict
     sh[tid] += add;
     __syncthreads();
   }
-  uint32_t running = digit_base + sh[tid] - local;
+  if (tid == kBlock - 1) totals[d] = sh[tid];
+  uint32_t running = sh[tid] - local;
   for (int64_t i = lo; i < hi; ++i) {
     const uint32_t c = row[i];
     row[i] = running;
@@ -115,8 +87,8 @@ __device__ __forceinline__ int64_t xcd_tile(int64_t b, int64_t ntiles) {
 template <int BITS>
 __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, int64_t m,
-    int shift, const uint32_t* __restrict__ hist, int64_t ntiles, uint32_t* __restrict__ keys_out,
-    uint32_t* __restrict__ vals_out) {
+    int shift, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ totals, int64_t ntiles,
+    uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
   constexpr int RADIX = 1 << BITS;
   constexpr int kWaves = kBlock / kWave;
   constexpr int DPT = RADIX / kBlock;          // digits per thread in the tile-local scan
@@ -125,7 +97,7 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
   __shared__ uint32_t gbase[RADIX];            // global position of the tile's first entry of a digit
   __shared__ uint32_t lstart[RADIX];           // tile-local position of it
   __shared__ uint32_t skey[kSortTile], sval[kSortTile];
-  __shared__ uint32_t wave_tot[kWaves];
+  __shared__ uint32_t wave_tot[kWaves], wave_big[kWaves];
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
   const int w = tid / kWave;
@@ -164,7 +136,8 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
   __syncthreads();
   // per digit: the waves' counts become offsets inside the digit's run of this tile; per thread
   // DPT consecutive digits, then one exclusive scan over the workgroup for the runs' starts
-  uint32_t dcount[DPT], mine = 0;
+  // (the same scan, over the bucket sizes of the whole input, gives where every bucket starts)
+  uint32_t dcount[DPT], mine = 0, big[DPT], big_mine = 0, in_bucket[DPT];
 #pragma unroll
   for (int j = 0; j < DPT; ++j) {
     const int d = tid * DPT + j;
@@ -177,23 +150,37 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
     }
     dcount[j] = run;
     mine += run;
-    gbase[d] = hist[static_cast<int64_t>(d) * ntiles + tile];
+    big[j] = totals[d];
+    big_mine += big[j];
+    in_bucket[j] = hist[static_cast<int64_t>(d) * ntiles + tile];
   }
-  uint32_t inc = mine;
+  uint32_t inc = mine, big_inc = big_mine;
 #pragma unroll
   for (int o = 1; o < kWave; o <<= 1) {
     const uint32_t up = __shfl_up(inc, o, kWave);
-    if (lane >= o) inc += up;
+    const uint32_t big_up = __shfl_up(big_inc, o, kWave);
+    if (lane >= o) {
+      inc += up;
+      big_inc += big_up;
+    }
   }
-  if (lane == kWave - 1) wave_tot[w] = inc;
+  if (lane == kWave - 1) {
+    wave_tot[w] = inc;
+    wave_big[w] = big_inc;
+  }
   __syncthreads();
-  uint32_t before_me = inc - mine;
+  uint32_t before_me = inc - mine, big_before = big_inc - big_mine;
 #pragma unroll
-  for (int i = 0; i < kWaves; ++i) before_me += i < w ? wave_tot[i] : 0u;
+  for (int i = 0; i < kWaves; ++i) {
+    before_me += i < w ? wave_tot[i] : 0u;
+    big_before += i < w ? wave_big[i] : 0u;
+  }
 #pragma unroll
   for (int j = 0; j < DPT; ++j) {
     lstart[tid * DPT + j] = before_me;
     before_me += dcount[j];
+    gbase[tid * DPT + j] = big_before + in_bucket[j];
+    big_before += big[j];
   }
   __syncthreads();
 #pragma unroll
@@ -505,12 +492,10 @@ int run_pass(const SortWs& s, const uint32_t* kin, const uint32_t* vin, uint32_t
   const dim3 grid(static_cast<unsigned>(s.ntiles));
   hipLaunchKernelGGL(radix_hist_kernel<BITS>, grid, dim3(kBlock), 0, stream, kin, s.m, shift,
                      s.hist, s.ntiles, totals);
-  hipLaunchKernelGGL(radix_totals_kernel, dim3(1u << BITS), dim3(kBlock), 0, stream, s.hist,
-                     s.ntiles, totals);
   hipLaunchKernelGGL(radix_scan_kernel, dim3(1u << BITS), dim3(kBlock), 0, stream, s.hist,
                      s.ntiles, totals);
   hipLaunchKernelGGL((radix_scatter_kernel<BITS>), grid, dim3(kBlock), 0, stream, kin, vin, s.m,
-                     shift, s.hist, s.ntiles, kout, vout);
+                     shift, s.hist, totals, s.ntiles, kout, vout);
   return check_launch("radix pass");
 }
 
