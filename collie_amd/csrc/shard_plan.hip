@@ -147,13 +147,16 @@ __global__ __launch_bounds__(kBlock) void plan_keys_kernel(const collie_mf_batch
       *bad_flag = 1;
       id = id < 0 ? 0 : rows - 1;
     }
-    const int64_t owner = id % r.world;
+    // (ids are below 2^31 here: 32-bit division)
+    const uint32_t uid = static_cast<uint32_t>(id), uworld = static_cast<uint32_t>(r.world);
+    const int owner = static_cast<int>(uid % uworld);
+    const int64_t local = uid / uworld;
     if (e < skip) {
       if (owner != local_rank) *bad_flag = 1;
-      cu[e] = owner == local_rank ? static_cast<int32_t>(id / r.world) : 0;
+      cu[e] = owner == local_rank ? static_cast<int32_t>(local) : 0;
       continue;
     }
-    const int64_t key = r.key_base[2 * owner + kind] + id / r.world;
+    const int64_t key = r.key_base[2 * owner + kind] + local;
     if (DIRECT) {
       marks[key] = 1;   // (plain store; reading first -- "already marked?" -- measured 13 % slower,
                         // a bitmap with atomicOr 30-70 % slower)
@@ -378,8 +381,9 @@ __global__ __launch_bounds__(kBlock) void plan_direct_emit_kernel(
     int64_t id = batch_id(b, e, kind);
     const int64_t rows = kind ? r.num_items : r.num_users;
     if (id < 0 || id >= rows) id = id < 0 ? 0 : rows - 1;   // as plan_keys_kernel (reported there)
-    const int64_t owner = id % r.world;
-    const int64_t key = r.key_base[2 * owner + kind] + id / r.world;
+    const uint32_t uid = static_cast<uint32_t>(id), uworld = static_cast<uint32_t>(r.world);
+    const int owner = static_cast<int>(uid % uworld);
+    const int64_t key = r.key_base[2 * owner + kind] + uid / uworld;
     const int64_t compact = rank_of_key(words, key) + shift[owner];
     if (e < B) cu[e] = static_cast<int32_t>(compact);
     else if (e < 2 * B) cp[e - B] = static_cast<int32_t>(compact);

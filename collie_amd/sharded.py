@@ -14,9 +14,11 @@ gather and the owner-side optimizer step is one ``collie_shard_owner_update`` ca
 Training step on a rank (``train_step``), for its slice of the global batch:
   1. distinct user rows and item rows of the slice (positives and all K negatives), ordered by
      (owner, kind, id): that order IS the compact row numbering of the step
-     (``collie_shard_plan``: one stable radix sort of the (2 + K) B ids);
-  2. all-to-all of the per-peer counts (the step's first host read: ``plan_ahead`` hides it behind
-     the previous step), then of the requested row numbers;
+     (``collie_shard_plan``: marks + popcount ranks when the batch is dense in the tables, one
+     stable radix sort of the (2 + K) B ids otherwise);
+  2. all-to-all of the per-peer counts (the step's first host read: ``train_step(next_batch=)``
+     queues both inside the previous step, ``plan_ahead`` on a side stream after it), then of the
+     requested row numbers;
   3. owners write the requested rows as the peers' blocks of ONE lookup buffer -- embedding rows,
      then the bias values packed into rows of the same width (``collie_shard_serve_rows``, which
      also stamps the served item rows) -- and one all-to-all with row splits brings them back: the
@@ -27,8 +29,9 @@ Training step on a rank (``train_step``), for its slice of the global batch:
      one negative per sample the loss selected: at most 3 of the 2 + K rows a sample looks up) and
      writes them, scaled by ``B_local / B_global``, straight into the owners' blocks of the gradient
      buffer (rows, bias gradients, owner row numbers);
-  5. all-to-all of the per-owner gradient counts (second host read), then ONE all-to-all of the
-     gradient buffer;
+  5. all-to-all of the per-owner gradient counts (second host read; the update of local user rows
+     and the next step's plan are queued behind its copy, so the GPU works while the host waits),
+     then ONE all-to-all of the gradient buffer;
   6. owners coalesce what the requesters sent (stable sort by row: rank order, deterministic) and
      update: rows with an entry get their summed gradient, and -- SparseAdam -- every item row
      stamped in step 3 without an entry has its moments decayed (looked-up
