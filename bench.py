@@ -360,8 +360,13 @@ def main_sharded(args, world, rank, device):
     # a few more, untimed steps with an event at every phase boundary: where the sharded step spends
     # its time on this rank (plan / row exchange / compute / gradient exchange / owner update)
     model.profile_phases(True)
-    for i in range(min(args.steps, 10)):
-        model.train_step(batches[i % n_distinct], users_local=ul)
+    n_ph = min(args.steps, 10)
+    for i in range(n_ph):
+        nxt = batches[(i + 1) % n_distinct] if args.plan_ahead and i + 1 < n_ph else None
+        model.train_step(batches[i % n_distinct], users_local=ul,
+                         next_batch=None if args.plan_side_stream else nxt)
+        if nxt is not None and args.plan_side_stream:
+            model.plan_ahead(nxt, users_local=ul)
     phases = model.phase_times()
     model.profile_phases(False)
     rccl = rccl_selftest(device, world, backend)
@@ -393,6 +398,10 @@ def main_sharded(args, world, rank, device):
                 'rows_exchanged_per_rank_per_step': model.last_exchange.get('rows_requested'),
                 'gradient_rows_sent_per_rank_per_step': model.last_exchange.get('gradient_rows_sent'),
                 'phase_ms_rank0': phases,
+                'look_ahead': ('none' if not args.plan_ahead else
+                               'plan_ahead() on a side stream' if args.plan_side_stream else
+                               "train_step(next_batch=): the next step's plan is queued inside the "
+                               'step, in front of the owner update'),
             },
             'roofline': None,
             'rccl': rccl,
