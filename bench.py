@@ -571,6 +571,8 @@ def main():
                     help='N > 1: draw every rank\'s users from the whole table (user rows then take '
                          'the exchange like item rows) instead of from the users the rank owns')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--zipf-steps', type=int, default=20,
+                    help='steps of the Zipf(1.05)-ids leg of the default line (0 = skip it)')
     ap.add_argument('--eval-users', type=int, default=65536,
                     help='users in the eval leg (0 = skip it)')
     ap.add_argument('--hybrid-steps', type=int, default=10,
@@ -627,6 +629,16 @@ def main():
             result['roofline']['hbm_resident']['workload'] = c4['config']['workload']
         else:
             result['c4'] = {'skipped': f'{free / 2 ** 30:.0f} GiB of HBM free, the leg needs 190'}
+    if args.zipf_steps > 0 and args.shape == 'c2' and args.dist == 'uniform':
+        # "ids drawn uniform and Zipf(1.05) (report both)" -- the same step on skewed
+        # ids (hot rows own long segments: the piecewise segment sums of K3a / K4)
+        args.dist = 'zipf'
+        z = train_leg('c2', args, device, args.zipf_steps, 5)
+        args.dist = 'uniform'
+        result['zipf'] = {'id_distribution': 'Zipf(1.05)', 'value': z['value'], 'unit': z['unit'],
+                          'ms_per_step': z['ms_per_step'], 'steps': args.zipf_steps,
+                          'forward_avg_launch_ms': z['roofline']['avg_launch_ms'],
+                          'forward_frac_of_8TBs': z['roofline']['frac']}
     if args.small_batch_steps > 0 and args.shape == 'c2':
         result['b1024'] = small_batch_leg(device, 1024, args.small_batch_steps)
     if args.eval_users > 0:

@@ -8,7 +8,7 @@ R=$PWD
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-COMMON="--no-cpu-baseline --eval-users 0 --hybrid-steps 0 --c4-steps 0 --small-batch-steps 0"
+COMMON="--no-cpu-baseline --eval-users 0 --hybrid-steps 0 --c4-steps 0 --small-batch-steps 0 --zipf-steps 0"
 for leg in $LEGS; do
   case $leg in
     B1048576) ARGS="--batch 1048576 --steps 30 --warmup 5" ;;

@@ -9,8 +9,8 @@ OUT=$PWD/gpurun_out/prof_$TAG
 REPO=$PWD
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--no-cpu-baseline --eval-users 0 --hybrid-steps 0 --c4-steps 0 --small-batch-steps 0 --steps 30 --warmup 5"
-C4="--no-cpu-baseline --eval-users 0 --hybrid-steps 0 --c4-steps 0 --small-batch-steps 0 --steps 10 --warmup 3 --shape c4"
+ARGS="--no-cpu-baseline --eval-users 0 --hybrid-steps 0 --c4-steps 0 --small-batch-steps 0 --zipf-steps 0 --steps 30 --warmup 5"
+C4="--no-cpu-baseline --eval-users 0 --hybrid-steps 0 --c4-steps 0 --small-batch-steps 0 --zipf-steps 0 --steps 10 --warmup 3 --shape c4"
 stats() { timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$1 -o bench -- python3 $REPO/bench.py ${@:2} > $OUT/$1.log 2>&1; }
 pmc() { timeout -s KILL 300 rocprofv3 --pmc $2 --output-format csv -d $OUT/$1 -o bench -- python3 $REPO/bench.py ${@:3} > $OUT/$1.log 2>&1; }
 # second argument "eval-hybrid": only the eval leg and the hybrid head (what changed late in round 2)
@@ -21,8 +21,8 @@ stats stats_B1048576 $ARGS --batch 1048576
 stats stats_c4 $C4
 fi
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_hybrid -o bench -- python3 $REPO/tools/hybrid_bench.py --steps 10 --warmup 3 > $OUT/stats_hybrid.log 2>&1
-stats stats_eval --no-cpu-baseline --hybrid-steps 0 --c4-steps 0 --small-batch-steps 0 --steps 2 --warmup 1 --eval-users 65536
-EVAL="--no-cpu-baseline --hybrid-steps 0 --c4-steps 0 --small-batch-steps 0 --steps 1 --warmup 1 --eval-users 65536"
+stats stats_eval --no-cpu-baseline --hybrid-steps 0 --c4-steps 0 --small-batch-steps 0 --zipf-steps 0 --steps 2 --warmup 1 --eval-users 65536
+EVAL="--no-cpu-baseline --hybrid-steps 0 --c4-steps 0 --small-batch-steps 0 --zipf-steps 0 --steps 1 --warmup 1 --eval-users 65536"
 pmc pmc_sq_eval "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_LDS" $EVAL
 if [ "$ONLY" != all ]; then ls $OUT; exit 0; fi
 pmc pmc_fetch_B1048576 FETCH_SIZE $ARGS --batch 1048576
