@@ -116,17 +116,29 @@ struct UpdParams {
   int step;
   const StepDyn* dyn;  // non-NULL: step and the step-dependent Hyper fields are read from here
   int dyn_base;        // 2 * is_bias: index of d[0]'s table in StepDyn
+  bool stream_rows;    // host side only: pick the STREAM row kernels (beyond_caches())
 };
+
+// 16-byte accesses that leave no copy in the caches: a swept row is read and written once per step
+typedef float nt_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 nt_load4(const float* p) {
+  const nt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void nt_store4(float* p, const float4& v) {
+  nt_f4 x = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(x, reinterpret_cast<nt_f4*>(p));
+}
 
 template <int VEC>
 struct RVec {
   float v[VEC];
 };
-template <int VEC>
+template <int VEC, bool STREAM = false>
 __device__ __forceinline__ RVec<VEC> rload(const float* p) {
   RVec<VEC> r;
   if (VEC == 4) {
-    const float4 x = *reinterpret_cast<const float4*>(p);
+    const float4 x = STREAM ? nt_load4(p) : *reinterpret_cast<const float4*>(p);
     r.v[0] = x.x; r.v[1 % VEC] = x.y; r.v[2 % VEC] = x.z; r.v[3 % VEC] = x.w;
   } else if (VEC == 2) {
     const float2 x = *reinterpret_cast<const float2*>(p);
@@ -136,10 +148,12 @@ __device__ __forceinline__ RVec<VEC> rload(const float* p) {
   }
   return r;
 }
-template <int VEC>
+template <int VEC, bool STREAM = false>
 __device__ __forceinline__ void rstore(float* p, const RVec<VEC>& r) {
   if (VEC == 4) {
-    *reinterpret_cast<float4*>(p) = make_float4(r.v[0], r.v[1 % VEC], r.v[2 % VEC], r.v[3 % VEC]);
+    const float4 x = make_float4(r.v[0], r.v[1 % VEC], r.v[2 % VEC], r.v[3 % VEC]);
+    if (STREAM) nt_store4(p, x);
+    else *reinterpret_cast<float4*>(p) = x;
   } else if (VEC == 2) {
     *reinterpret_cast<float2*>(p) = make_float2(r.v[0], r.v[1 % VEC]);
   } else {
@@ -227,7 +241,9 @@ __global__ __launch_bounds__(kBlock) void piece_bias_kernel(const UpdParams p) {
 // LPR lanes own one segment (VEC floats per lane per chunk), so 64 / LPR segments are reduced and
 // updated concurrently by a wave: independent rows keep 64 / LPR times more loads in flight than
 // one-wave-per-row.  The sum over a segment is still formed entry by entry in batch order.
-template <bool EXPORT, int VEC, int LPR>
+// STREAM: the rows of the table and of its optimizer state are read and written non-temporally
+// (tables far beyond the caches, beyond_caches()).
+template <bool EXPORT, int VEC, int LPR, bool STREAM = false>
 __global__ __launch_bounds__(kBlock) void emb_rows_kernel(const UpdParams p) {
   constexpr int GPW = kWave / LPR;  // segments per wave
   const int lane = lane_id();
@@ -277,9 +293,9 @@ __global__ __launch_bounds__(kBlock) void emb_rows_kernel(const UpdParams p) {
 #pragma unroll
       for (int i = 0; i < VEC; ++i) pv.v[i] = s1.v[i] = s2.v[i] = acc.v[i] = 0.0f;
       if (!EXPORT && on) {
-        pv = rload<VEC>(t.table + off);
-        if (t.s1) s1 = rload<VEC>(t.s1 + off);
-        if (t.s2) s2 = rload<VEC>(t.s2 + off);
+        pv = rload<VEC, STREAM>(t.table + off);
+        if (t.s1) s1 = rload<VEC, STREAM>(t.s1 + off);
+        if (t.s2) s2 = rload<VEC, STREAM>(t.s2 + off);
       }
       uint32_t e0 = start;
       while (__any(e0 < end)) {
@@ -339,9 +355,9 @@ __global__ __launch_bounds__(kBlock) void emb_rows_kernel(const UpdParams p) {
           for (int i = 0; i < VEC; ++i)
             np.v[i] = apply_update2(t.h, side ? nl1 : nl0, side ? bc1 : bc0, pv.v[i], g.v[i], s1.v[i],
                                     s2.v[i]);
-          rstore<VEC>(t.table + off, np);
-          if (t.s1) rstore<VEC>(t.s1 + off, s1);
-          if (t.s2) rstore<VEC>(t.s2 + off, s2);
+          rstore<VEC, STREAM>(t.table + off, np);
+          if (t.s1) rstore<VEC, STREAM>(t.s1 + off, s1);
+          if (t.s2) rstore<VEC, STREAM>(t.s2 + off, s2);
         }
       }
     }
@@ -787,7 +803,7 @@ __global__ __launch_bounds__(kBlock) void touched_sweep_kernel(float* __restrict
 // with one coalesced load, compacts the rows that need the zero-gradient update into a wave-private
 // LDS list, and then LPR lanes own one such row (64 / LPR rows in flight per wave, every lane with
 // up to 4 chunks x (p, m, v) 16-byte loads outstanding before the first use).
-template <int LPR>
+template <int LPR, bool STREAM>
 __global__ __launch_bounds__(kBlock) void touched_rows_kernel(float* __restrict__ table,
                                                               float* __restrict__ s1p,
                                                               float* __restrict__ s2p,
@@ -829,9 +845,9 @@ __global__ __launch_bounds__(kBlock) void touched_rows_kernel(float* __restrict_
           const int c = c0 + q * LPR + lig;
           if (on_row && c < nchunks) {
             const int64_t off = row * D + c * 4;
-            pv[q] = *reinterpret_cast<const float4*>(table + off);
-            m[q] = *reinterpret_cast<const float4*>(s1p + off);
-            v[q] = *reinterpret_cast<const float4*>(s2p + off);
+            pv[q] = STREAM ? nt_load4(table + off) : *reinterpret_cast<const float4*>(table + off);
+            m[q] = STREAM ? nt_load4(s1p + off) : *reinterpret_cast<const float4*>(s1p + off);
+            v[q] = STREAM ? nt_load4(s2p + off) : *reinterpret_cast<const float4*>(s2p + off);
           }
         }
 #pragma unroll
@@ -844,9 +860,15 @@ __global__ __launch_bounds__(kBlock) void touched_rows_kernel(float* __restrict_
             np.y = apply_update(h, pv[q].y, 0.0f, m[q].y, v[q].y);
             np.z = apply_update(h, pv[q].z, 0.0f, m[q].z, v[q].z);
             np.w = apply_update(h, pv[q].w, 0.0f, m[q].w, v[q].w);
-            *reinterpret_cast<float4*>(table + off) = np;
-            *reinterpret_cast<float4*>(s1p + off) = m[q];
-            *reinterpret_cast<float4*>(s2p + off) = v[q];
+            if (STREAM) {
+              nt_store4(table + off, np);
+              nt_store4(s1p + off, m[q]);
+              nt_store4(s2p + off, v[q]);
+            } else {
+              *reinterpret_cast<float4*>(table + off) = np;
+              *reinterpret_cast<float4*>(s1p + off) = m[q];
+              *reinterpret_cast<float4*>(s2p + off) = v[q];
+            }
           }
         }
       }
@@ -1269,8 +1291,20 @@ void launch_piece_lpr(int lpr, unsigned grid, hipStream_t stream, const UpdParam
   }
 }
 
+// parameter + optimizer state of `rows` rows far beyond the 256 MB Infinity Cache: the update streams
+// them (non-temporal loads / stores), a cached copy would only evict what the next kernel reads
+bool beyond_caches(int64_t rows, int dim) {
+  return rows * dim * int64_t{12} > (int64_t{1} << 30);
+}
+
 template <bool EXPORT, int VEC>
 void launch_emb_lpr(int lpr, unsigned grid, hipStream_t stream, const UpdParams& p) {
+  if (!EXPORT && VEC == 4 && p.stream_rows && (lpr == 8 || lpr == 16 || lpr == 32)) {
+    if (lpr == 8) hipLaunchKernelGGL((emb_rows_kernel<false, 4, 8, true>), dim3(grid), dim3(kBlock), 0, stream, p);
+    else if (lpr == 16) hipLaunchKernelGGL((emb_rows_kernel<false, 4, 16, true>), dim3(grid), dim3(kBlock), 0, stream, p);
+    else hipLaunchKernelGGL((emb_rows_kernel<false, 4, 32, true>), dim3(grid), dim3(kBlock), 0, stream, p);
+    return;
+  }
   switch (lpr) {
     case 1: hipLaunchKernelGGL((emb_rows_kernel<EXPORT, VEC, 1>), dim3(grid), dim3(kBlock), 0, stream, p); break;
     case 2: hipLaunchKernelGGL((emb_rows_kernel<EXPORT, VEC, 2>), dim3(grid), dim3(kBlock), 0, stream, p); break;
@@ -1406,6 +1440,34 @@ int plan_kind(KindPlan& k, const collie_mf_tables* t, const TrainWs& ws, int tab
   return 0;
 }
 
+// rows of 16-byte chunks: 4, 8 or 16 lanes per row (at most 4 chunks per lane and pass)
+template <bool STREAM>
+void launch_touched_rows_t(int nchunks, unsigned grid, hipStream_t stream, float* table, float* s1,
+                           float* s2, const uint8_t* touch, const int32_t* seg, int64_t rows, int D,
+                           int step, const Hyper& h, const StepDyn* dyn, int dyn_idx, int span) {
+  if (nchunks <= 16)
+    hipLaunchKernelGGL((touched_rows_kernel<4, STREAM>), dim3(grid), dim3(kBlock), 0, stream, table,
+                       s1, s2, touch, seg, rows, D, step, h, dyn, dyn_idx, span);
+  else if (nchunks <= 32)
+    hipLaunchKernelGGL((touched_rows_kernel<8, STREAM>), dim3(grid), dim3(kBlock), 0, stream, table,
+                       s1, s2, touch, seg, rows, D, step, h, dyn, dyn_idx, span);
+  else
+    hipLaunchKernelGGL((touched_rows_kernel<16, STREAM>), dim3(grid), dim3(kBlock), 0, stream, table,
+                       s1, s2, touch, seg, rows, D, step, h, dyn, dyn_idx, span);
+}
+
+void launch_touched_rows(int nchunks, bool stream_rows, unsigned grid, hipStream_t stream,
+                         float* table, float* s1, float* s2, const uint8_t* touch,
+                         const int32_t* seg, int64_t rows, int D, int step, const Hyper& h,
+                         const StepDyn* dyn, int dyn_idx, int span) {
+  if (stream_rows)
+    launch_touched_rows_t<true>(nchunks, grid, stream, table, s1, s2, touch, seg, rows, D, step, h,
+                                dyn, dyn_idx, span);
+  else
+    launch_touched_rows_t<false>(nchunks, grid, stream, table, s1, s2, touch, seg, rows, D, step, h,
+                                 dyn, dyn_idx, span);
+}
+
 // rows without a gradient entry (K5 / K5b) of one kind, after its row kernel
 int sweep_kind(const KindPlan& k, const collie_mf_tables* t, const TrainWs& ws, int step,
                const StepDyn* dyn, int dyn_base, hipStream_t stream) {
@@ -1425,18 +1487,9 @@ int sweep_kind(const KindPlan& k, const collie_mf_tables* t, const TrainWs& ws, 
         const int nchunks = k.D / 4;
         const unsigned grid = sweep_grid(rows * 4);
         const int span = rows * 4 <= 4096 * static_cast<int64_t>(kBlock) ? 16 : kWave;
-        if (nchunks <= 16)
-          hipLaunchKernelGGL(touched_rows_kernel<4>, dim3(grid), dim3(kBlock), 0, stream, d.table,
-                             d.s1, d.s2, ws.touch_item, ws.seg_item, rows, k.D, step, d.h, dyn,
-                             dyn_base + side, span);
-        else if (nchunks <= 32)
-          hipLaunchKernelGGL(touched_rows_kernel<8>, dim3(grid), dim3(kBlock), 0, stream, d.table,
-                             d.s1, d.s2, ws.touch_item, ws.seg_item, rows, k.D, step, d.h, dyn,
-                             dyn_base + side, span);
-        else
-          hipLaunchKernelGGL(touched_rows_kernel<16>, dim3(grid), dim3(kBlock), 0, stream, d.table,
-                             d.s1, d.s2, ws.touch_item, ws.seg_item, rows, k.D, step, d.h, dyn,
-                             dyn_base + side, span);
+        launch_touched_rows(nchunks, beyond_caches(rows, k.D), grid, stream, d.table, d.s1, d.s2,
+                            ws.touch_item, ws.seg_item, rows, k.D, step, d.h, dyn, dyn_base + side,
+                            span);
       } else {
         hipLaunchKernelGGL(touched_sweep_kernel, dim3(sweep_grid(rows * k.D)), dim3(kBlock), 0,
                            stream, d.table, d.s1, d.s2, ws.touch_item, ws.seg_item, rows, k.D,
@@ -1561,6 +1614,7 @@ extern "C" int collie_mf_train_update(const collie_mf_tables* t, const collie_mf
   p.D = k.D;
   p.d[0] = k.d[0];
   p.d[1] = k.d[1];
+  p.stream_rows = !is_bias && beyond_caches(t->num_users + t->num_items, t->dim);
   if (is_bias) {
     if (!small_coalesce(3 * b->batch))
       hipLaunchKernelGGL(piece_bias_kernel<false>, dim3(piece_bias_grid(3 * b->batch)), dim3(kBlock),
@@ -1991,6 +2045,7 @@ extern "C" int collie_shard_owner_update(float* emb, float* bias, int64_t num_ro
   memset(&p, 0, sizeof(p));
   p.D = dim;
   p.step = step;
+  p.stream_rows = beyond_caches(num_rows, dim);
   p.d[0].table = emb;
   p.d[0].stage = wire;
   p.d[0].s1 = cfg->algo == COLLIE_OPT_SGD ? nullptr : state1;
@@ -2033,15 +2088,8 @@ extern "C" int collie_shard_owner_update(float* emb, float* bias, int64_t num_ro
       const int nchunks = dim / 4;
       const unsigned grid = sweep_grid(items * 4);
       const int span = items * 4 <= 4096 * static_cast<int64_t>(kBlock) ? 16 : kWave;
-      if (nchunks <= 16)
-        hipLaunchKernelGGL(touched_rows_kernel<4>, dim3(grid), dim3(kBlock), 0, stream, tb, s1, s2,
-                           item_touch, seg, items, dim, step, p.d[0].h, nullptr, 0, span);
-      else if (nchunks <= 32)
-        hipLaunchKernelGGL(touched_rows_kernel<8>, dim3(grid), dim3(kBlock), 0, stream, tb, s1, s2,
-                           item_touch, seg, items, dim, step, p.d[0].h, nullptr, 0, span);
-      else
-        hipLaunchKernelGGL(touched_rows_kernel<16>, dim3(grid), dim3(kBlock), 0, stream, tb, s1, s2,
-                           item_touch, seg, items, dim, step, p.d[0].h, nullptr, 0, span);
+      launch_touched_rows(nchunks, beyond_caches(num_rows, dim), grid, stream, tb, s1, s2, item_touch,
+                          seg, items, dim, step, p.d[0].h, nullptr, 0, span);
     } else {
       hipLaunchKernelGGL(touched_sweep_kernel, dim3(sweep_grid(items * dim)), dim3(kBlock), 0, stream,
                          tb, s1, s2, item_touch, seg, items, dim, step, p.d[0].h, nullptr, 0);
@@ -2128,6 +2176,7 @@ extern "C" int collie_dense_rows_update(float* table, int64_t num_rows, int32_t 
   fill_sorted(p, s, num_rows, 0xffffffffu);
   p.D = dim;
   p.step = cfg->step;
+  p.stream_rows = beyond_caches(num_rows, dim);
   TableDesc& d = p.d[0];
   d.table = table;
   d.stage = vals;

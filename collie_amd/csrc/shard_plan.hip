@@ -35,6 +35,18 @@ namespace {
 
 constexpr int kBlock = 256;
 
+// 16-byte accesses that leave no copy in the caches (tables far beyond them: every row the owners
+// serve is read once here and its copy is read once by the forward kernel)
+typedef float nt_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 nt_load4(const float4* p) {
+  const nt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void nt_store4(float4* p, const float4& v) {
+  nt_f4 x = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(x, reinterpret_cast<nt_f4*>(p));
+}
+
 struct Routes {
   int world;
   int64_t num_users, num_items;
@@ -396,7 +408,7 @@ __global__ __launch_bounds__(kBlock) void plan_direct_emit_kernel(
 // pieces when the rows allow it).  Item rows (rows at or behind item_base) are stamped "looked up in
 // this step": the owner-side update finds the looked-up rows that received no gradient through these
 // stamps (SparseAdam moves them too).
-template <int VEC>
+template <int VEC, bool STREAM>
 __global__ __launch_bounds__(kBlock) void serve_rows_kernel(
     const float* __restrict__ emb, const float* __restrict__ bias, int64_t num_rows, int dim,
     const int64_t* __restrict__ rows, const WireBlocks w, float* __restrict__ out,
@@ -425,7 +437,8 @@ __global__ __launch_bounds__(kBlock) void serve_rows_kernel(
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           v[q][h] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (ok[q] && lig + h * LPR < dim / 4) v[q][h] = src[lig + h * LPR];
+          if (ok[q] && lig + h * LPR < dim / 4)
+            v[q][h] = STREAM ? nt_load4(src + lig + h * LPR) : src[lig + h * LPR];
         }
         bv[q] = ok[q] && lig == 0 ? bias[r[q]] : 0.0f;
       }
@@ -438,7 +451,10 @@ __global__ __launch_bounds__(kBlock) void serve_rows_kernel(
         float4* dst = reinterpret_cast<float4*>(out + (w.row0[p] + jj) * dim);
 #pragma unroll
         for (int h = 0; h < 2; ++h)
-          if (lig + h * LPR < dim / 4) dst[lig + h * LPR] = v[q][h];
+          if (lig + h * LPR < dim / 4) {
+            if (STREAM) nt_store4(dst + lig + h * LPR, v[q][h]);
+            else dst[lig + h * LPR] = v[q][h];
+          }
         if (lig == 0) out[(w.row0[p] + (w.first[p + 1] - w.first[p])) * dim + jj] = bv[q];
       }
     } else {
@@ -523,13 +539,18 @@ extern "C" int collie_shard_serve_rows(const float* emb, const float* bias, int6
   int64_t blocks = (m + 4 * (kBlock / 16) - 1) / (4 * (kBlock / 16));   // four rows per 16-lane group
   if (blocks > 65536) blocks = 65536;
   auto al16 = [](const void* q) { return reinterpret_cast<uintptr_t>(q) % 16 == 0; };
-  if (dim % 4 == 0 && al16(emb) && al16(out))
-    hipLaunchKernelGGL(serve_rows_kernel<4>, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0,
-                       stream, emb, bias, num_rows, dim, rows, w, out, item_touch, item_base, tag,
+  const bool stream_rows = num_rows * dim * int64_t{12} > (int64_t{1} << 30);   // (as mf_update.hip)
+  if (dim % 4 == 0 && al16(emb) && al16(out) && stream_rows)
+    hipLaunchKernelGGL((serve_rows_kernel<4, true>), dim3(static_cast<unsigned>(blocks)), dim3(kBlock),
+                       0, stream, emb, bias, num_rows, dim, rows, w, out, item_touch, item_base, tag,
+                       status);
+  else if (dim % 4 == 0 && al16(emb) && al16(out))
+    hipLaunchKernelGGL((serve_rows_kernel<4, false>), dim3(static_cast<unsigned>(blocks)), dim3(kBlock),
+                       0, stream, emb, bias, num_rows, dim, rows, w, out, item_touch, item_base, tag,
                        status);
   else
-    hipLaunchKernelGGL(serve_rows_kernel<1>, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0,
-                       stream, emb, bias, num_rows, dim, rows, w, out, item_touch, item_base, tag,
+    hipLaunchKernelGGL((serve_rows_kernel<1, false>), dim3(static_cast<unsigned>(blocks)), dim3(kBlock),
+                       0, stream, emb, bias, num_rows, dim, rows, w, out, item_touch, item_base, tag,
                        status);
   return check_launch("serve_rows_kernel");
 }
