@@ -241,8 +241,9 @@ __global__ __launch_bounds__(kBlock) void piece_bias_kernel(const UpdParams p) {
 // LPR lanes own one segment (VEC floats per lane per chunk), so 64 / LPR segments are reduced and
 // updated concurrently by a wave: independent rows keep 64 / LPR times more loads in flight than
 // one-wave-per-row.  The sum over a segment is still formed entry by entry in batch order.
-// STREAM: the rows of the table and of its optimizer state are read and written non-temporally
-// (tables far beyond the caches, beyond_caches()).
+// STREAM: the rows of the table and of its optimizer state, and the staged gradient rows, are read
+// and written non-temporally (tables far beyond the caches, beyond_caches()).  Compare variants
+// inside ONE GPU job only: the same binary differs by up to 5 % between two boxes of the pool.
 template <bool EXPORT, int VEC, int LPR, bool STREAM = false>
 __global__ __launch_bounds__(kBlock) void emb_rows_kernel(const UpdParams p) {
   constexpr int GPW = kWave / LPR;  // segments per wave
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(kBlock) void emb_rows_kernel(const UpdParams p) {
 #pragma unroll
             for (int i = 0; i < VEC; ++i) x[q].v[i] = 0.0f;
             if (live && on && stage)
-              x[q] = rload<VEC>(stage + static_cast<int64_t>(c & kCodeMask) * D + chunk * VEC);
+              x[q] = rload<VEC, STREAM>(stage + static_cast<int64_t>(c & kCodeMask) * D + chunk * VEC);
           }
 #pragma unroll
           for (int q = 0; q < 4; ++q)
