@@ -550,6 +550,32 @@ def test_hybrid_forward_and_trajectory_vs_torch_path(dev, case):
                 assert np.median(diff) <= 2e-4 * max(np.abs(want).max(), 1e-30), name
 
 
+@pytest.mark.parametrize('kind', ['adaptive_bpr', 'adaptive_hinge', 'warp'])
+def test_one_negative_losses_give_at_most_one_negative_a_gradient(dev, kind):
+    """The invariant ``_compact_rows`` rests on (it keeps the positive and ONE negative row of a
+    sample): with tied negative scores, a negative equal to the positive, and partial credit from
+    metadata, the library's one-negative losses still hand a non-zero score gradient to at most one
+    of a sample's K negatives."""
+    from collie_amd import loss as L
+    B, K, N = 257, 7, 40
+    rng = np.random.default_rng(11)
+    pos_items = torch.tensor(rng.integers(0, N, B), device=dev)
+    neg_items = torch.tensor(rng.integers(0, N, (K, B)), device=dev)
+    neg_items[3, ::2] = neg_items[1, ::2]                    # the same item twice
+    neg_items[5, ::5] = pos_items[::5]                       # the positive among the negatives
+    item_score = torch.tensor(rng.normal(size=N).astype(np.float32), device=dev)
+    pos = (item_score[pos_items] + 0.5).clone().requires_grad_(True)
+    neg = item_score[neg_items].clone()                      # equal items -> exactly tied scores
+    neg[:, 7::16] = neg[0, 7::16]                            # all K tied
+    neg.requires_grad_(True)
+    genre = torch.tensor(rng.integers(0, 3, N), device=dev)
+    L.LOSS_FUNCTIONS[kind](pos, neg, num_items=N, positive_items=pos_items, negative_items=neg_items,
+                           metadata={'genre': genre}, metadata_weights={'genre': 0.3}).backward()
+    per_sample = (neg.grad != 0).sum(0)
+    assert int(per_sample.max()) <= 1
+    assert int(per_sample.sum()) > B // 4                    # (the case is not vacuous)
+
+
 @pytest.mark.parametrize('loss', ['adaptive_bpr', 'adaptive', 'warp'])
 @pytest.mark.parametrize('frozen', [True, False])
 def test_hybrid_backward_on_active_rows_equals_full_backward(dev, loss, frozen, monkeypatch):
@@ -563,11 +589,15 @@ def test_hybrid_backward_on_active_rows_equals_full_backward(dev, loss, frozen, 
     item_md = torch.tensor(rng.normal(size=(N, 256)).astype(np.float32))
     model = HybridPretrainedModel(train=inter, trained_model=mf, item_metadata=item_md,
                                   item_metadata_layers_dims=[128], freeze_embeddings=frozen,
-                                  loss=loss, lr_scheduler_func=None).to(dev)
+                                  loss=loss, lr_scheduler_func=None,
+                                  metadata_for_loss={'genre': torch.tensor(rng.integers(0, 4, N))},
+                                  metadata_for_loss_weights={'genre': 0.25}).to(dev)
     model.train()
+    neg = rng.integers(0, N, (B, K))
+    neg[::3, 4] = neg[::3, 2]                                # tied negatives (the same item twice)
     batch = ((torch.tensor(rng.integers(0, U, B), dtype=torch.int32, device=dev),
               torch.tensor(rng.integers(0, N, B), dtype=torch.int32, device=dev)),
-             torch.tensor(rng.integers(0, N, (B, K)), device=dev))
+             torch.tensor(neg, device=dev))
 
     def grads():
         model._staged_rows.clear()
