@@ -22,9 +22,14 @@ m = ShardedMatrixFactorizationModel(bench.NUM_USERS, bench.NUM_ITEMS, bench.NUM_
                                     embedding_dim=bench.DIM, loss='bpr', device=dev, seed=0)
 batches = bench.synthetic_batches(4, 65536, dev, 'uniform', 1)
 for i in range(6):
-    loss = m.train_step(batches[i % 4])
-    if i % 2 == 0:
+    # the three ways a step gets its plan: made by the step itself, on a side stream after the
+    # previous step (plan_ahead), queued inside the previous step (next_batch=)
+    loss = m.train_step(batches[i % 4], next_batch=batches[(i + 1) % 4] if i % 3 == 1 else None)
+    if i % 3 == 0:
         m.plan_ahead(batches[(i + 1) % 4])
+for i in range(3):      # users of this rank only (world 1: all of them): the users_local route
+    loss = m.train_step(batches[i % 4], users_local=True,
+                        next_batch=batches[(i + 1) % 4] if i < 2 else None)
 torch.cuda.synchronize()
 print('train ok, loss', float(loss))
 host = m.state_dict_to_rank0(chunk_rows=50000)
