@@ -606,12 +606,27 @@ class HybridPretrainedModel(MatrixFactorizationModel):
         down to those 2 B rows (fixed size: no host read) and every backward kernel runs on them.
         """
         B, K = hint
-        ar = torch.arange(B, device=g.device)
-        ksel = g[B:].view(K, B).abs().argmax(dim=0)         # all zero: row k = 0, a zero row
-        # positive and negative of a sample side by side: sums that cancel analytically (user
-        # biases, the last Linear bias: +g and -g per sample) then cancel pair by pair
-        act = torch.stack([ar, B + ksel * B + ar], dim=1).reshape(-1)
-        cache = {}
+        # which rows (all-zero negatives: k = 0, a zero row), and g / users / items at them: one
+        # launch.  Positive and negative of a sample sit side by side: sums that cancel analytically
+        # (user biases, the last Linear bias: +g and -g per sample) then cancel pair by pair
+        act, g_c, users_c, items_c = ops.active_rows(g.contiguous(), B, K, users, items)
+        # the saved activations, gathered down to those rows four tensors per launch
+        floats = []
+        for kind in ('user', 'item'):
+            for in_seg, o in saved.get(kind, ()):
+                floats += [in_seg[0] if in_seg[1] is None else None, o]
+        for x_segs, o in saved['combined']:
+            floats += [sg[0] if sg[1] is None else None for sg in x_segs] + [o]
+        distinct = {}
+        for t in floats:
+            if t is not None and t.dim() == 2 and t.dtype == torch.float32 and t.stride(1) == 1 \
+                    and t.shape[0] == g.shape[0]:
+                distinct.setdefault(id(t), t)
+        cache = {id(users): users_c, id(items): items_c, id(g): g_c}
+        if distinct:
+            for t, c in zip(distinct.values(),
+                            ops.gather_rows(list(distinct.values()), act, self._status_flag())):
+                cache[id(t)] = c
 
         def take(t):
             if id(t) not in cache:

@@ -420,6 +420,49 @@ def dense_forward(x_op, m, weight, bias, leaky, transposed=False, out=None, row_
     return out
 
 
+def active_rows(g, batch, num_neg, users, items):
+    """``collie_active_rows``: (act [2B] int64, g [2B], users [2B], items [2B]) -- the positive and
+    the one negative per sample whose score gradient can differ from zero."""
+    require_hip(g, 'score gradient')
+    assert g.dtype == torch.float32 and g.is_contiguous() and g.numel() == (1 + num_neg) * batch
+    assert users.dtype == torch.int64 and items.dtype == torch.int64
+    assert users.is_contiguous() and items.is_contiguous() and users.numel() == items.numel() == g.numel()
+    dev = g.device
+    act = torch.empty(2 * batch, dtype=torch.int64, device=dev)
+    g_out = torch.empty(2 * batch, dtype=torch.float32, device=dev)
+    u_out = torch.empty(2 * batch, dtype=torch.int64, device=dev)
+    i_out = torch.empty(2 * batch, dtype=torch.int64, device=dev)
+    check(load().collie_active_rows(ptr(g), batch, num_neg, ptr(users), ptr(items), ptr(act),
+                                    ptr(g_out), ptr(u_out), ptr(i_out), stream_ptr()),
+          'collie_active_rows')
+    return act, g_out, u_out, i_out
+
+
+def gather_rows(tensors, idx, status=None):
+    """``[t.index_select(0, idx) for t in tensors]`` for 2-d float32 tensors with the same number of
+    rows, four per launch (``collie_gather_rows``)."""
+    assert idx.dtype == torch.int64 and idx.is_contiguous()
+    outs = []
+    m_out = idx.shape[0]
+    for i0 in range(0, len(tensors), 4):
+        group = tensors[i0:i0 + 4]
+        n = len(group)
+        m_src = group[0].shape[0]
+        res = []
+        for t in group:
+            require_hip(t, 'gather source')
+            assert t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1 and t.shape[0] == m_src
+            res.append(torch.empty(m_out, t.shape[1], dtype=torch.float32, device=t.device))
+        srcs = (c_void_p * n)(*[t.data_ptr() for t in group])
+        lds = (ctypes.c_int64 * n)(*[t.stride(0) if t.shape[0] > 1 else t.shape[1] for t in group])
+        widths = (ctypes.c_int32 * n)(*[t.shape[1] for t in group])
+        outp = (c_void_p * n)(*[o.data_ptr() for o in res])
+        check(load().collie_gather_rows(n, srcs, lds, widths, outp, ptr(idx), m_out, m_src,
+                                        ptr(status), stream_ptr()), 'collie_gather_rows')
+        outs.extend(res)
+    return outs
+
+
 def dense_outer_sum(outer, inner, bias, leaky, out=None):
     """``act((outer[j // period] + bias) + inner[j % period])`` for ``j < len(outer) * period``,
     ``period = len(inner)`` (the first combined layer on the users x catalogue grid)."""

@@ -706,6 +706,28 @@ int collie_dense_forward_add(const collie_dense_operand* x, int64_t m, const flo
                              int64_t add_period, float* y, int64_t y_ld, int32_t* status,
                              collie_stream_t stream);
 
+/* The rows of a training batch whose score gradient can differ from zero, for the backward of the
+ * head.  torch.autograd pushes all (1 + K) B rows of `preds` through every backward GEMM of
+ * hybrid_pretrained_matrix_factorization.py:401-464; under adaptive BPR / hinge and WARP
+ * (loss/bpr.py:153-167, hinge.py:157-171, warp.py:73-154) only the positive and ONE negative of a
+ * sample have a non-zero d loss / d score.  g [(1 + K) B]: the score gradient in calculate_loss's
+ * order (base_pipeline.py:616-622: B positives, then negative k of sample b at B + k B + b);
+ * sample b keeps row b and row B + k* B + b, k* = the first k with the largest |g| (k = 0 if all
+ * are zero).  Outputs, 2 B long, positive and negative of a sample side by side: act (the row
+ * numbers), g_out, users_out, items_out (g, users, items at those rows; ids int64). */
+int collie_active_rows(const float* g, int64_t batch, int32_t num_neg, const int64_t* users,
+                       const int64_t* items, int64_t* act, float* g_out, int64_t* users_out,
+                       int64_t* items_out, collie_stream_t stream);
+
+/* outs[t][j, :] = srcs[t][idx[j], :] for up to 4 row-major float tensors at once (the saved
+ * activations of the head gathered down to the rows above: torch.index_select, one launch instead
+ * of one per tensor).  srcs[t] is [m_src, lds[t]] with widths[t] used columns, outs[t] is
+ * [m_out, widths[t]] contiguous; the arrays srcs / lds / widths / outs are HOST arrays of n
+ * entries.  idx outside [0, m_src) reads as zeros and sets bit 0 of *status (may be NULL). */
+int collie_gather_rows(int32_t n, const float* const* srcs, const int64_t* lds, const int32_t* widths,
+                       float* const* outs, const int64_t* idx, int64_t m_out, int64_t m_src,
+                       int32_t* status, collie_stream_t stream);
+
 /* The first combined layer on get_preds' users x catalogue grid (metrics.py:77-107: row j of the
  * expanded pairs is user j / period, item j mod period) once the layer's two shares are known:
  * y[j, :] = act((outer[j / period, :] + bias) + inner[j mod period, :]), j < n_outer * period;
