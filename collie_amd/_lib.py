@@ -207,6 +207,7 @@ SIGNATURES = {
                                                 c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
     'collie_active_rows': (ctypes.c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_void_p, c_void_p, c_void_p]),
+    'collie_pair_ids': (ctypes.c_int, [POINTER(Batch), c_void_p, c_void_p, c_void_p]),
     'collie_gather_rows': (ctypes.c_int, [c_int32, POINTER(c_void_p), POINTER(c_int64),
                                           POINTER(c_int32), POINTER(c_void_p), c_void_p, c_int64,
                                           c_int64, c_void_p, c_void_p]),

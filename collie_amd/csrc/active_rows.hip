@@ -39,6 +39,22 @@ __global__ __launch_bounds__(kBlock) void active_rows_kernel(
   items_out[2 * b + 1] = items[neg_row];
 }
 
+// calculate_loss's expansion of a batch into (1 + K) B (user, item) pairs (base_pipeline.py:603-622:
+// users.repeat(K + 1), cat(pos, neg.T.flatten())): pair e = k B + b is (users[b], k == 0 ? pos[b] :
+// neg[b, k - 1]), ids widened to int64.
+__global__ __launch_bounds__(kBlock) void pair_ids_kernel(const collie_mf_batch b,
+                                                          int64_t* __restrict__ all_users,
+                                                          int64_t* __restrict__ all_items) {
+  const int64_t B = b.batch;
+  const int64_t m = B * (1 + b.num_neg);
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (e >= m) return;
+  const int64_t k = e / B, s = e - k * B;
+  all_users[e] = load_idx(b.users, b.users_dtype, s);
+  all_items[e] = k == 0 ? load_idx(b.pos_items, b.pos_dtype, s)
+                        : load_idx(b.neg_items, b.neg_dtype, s * b.neg_stride_b + (k - 1) * b.neg_stride_k);
+}
+
 struct GatherSet {
   int n;
   const float* src[4];
@@ -133,4 +149,19 @@ extern "C" int collie_gather_rows(int32_t n, const float* const* srcs, const int
     hipLaunchKernelGGL(gather_rows_kernel<false>, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0,
                        stream, s, idx, m_out, m_src, status);
   return check_launch("gather_rows_kernel");
+}
+
+namespace collie {
+int validate_batch(const collie_mf_batch* b);
+}
+
+extern "C" int collie_pair_ids(const collie_mf_batch* b, int64_t* all_users, int64_t* all_items,
+                               collie_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (validate_batch(b)) return -1;
+  COLLIE_REQUIRE(all_users && all_items, "pair_ids: NULL output");
+  const int64_t m = b->batch * (1 + static_cast<int64_t>(b->num_neg));
+  hipLaunchKernelGGL(pair_ids_kernel, dim3(static_cast<unsigned>((m + kBlock - 1) / kBlock)),
+                     dim3(kBlock), 0, stream, *b, all_users, all_items);
+  return check_launch("pair_ids_kernel");
 }

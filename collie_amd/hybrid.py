@@ -55,6 +55,25 @@ class _HeadScore(torch.autograd.Function):
         return (None, None, None) + tuple(grads)
 
 
+class _SplitScores(torch.autograd.Function):
+    """``preds[:B], preds[B:].view(K, B)`` whose backward is ONE concatenation (autograd's slice
+    backward is two zero fills, two copies and an add per step)."""
+
+    @staticmethod
+    def forward(ctx, preds, B, K):
+        ctx.shape = (B, K)
+        return preds[:B], preds[B:].view(K, B)
+
+    @staticmethod
+    def backward(ctx, g_pos, g_neg):
+        B, K = ctx.shape
+        if g_pos is None:
+            g_pos = g_neg.new_zeros(B)
+        if g_neg is None:
+            g_neg = g_pos.new_zeros(K, B)
+        return torch.cat([g_pos.reshape(-1), g_neg.reshape(-1)]), None, None
+
+
 class _HeadMixin:
     """``step()`` for the optimizers of the hybrid model: dense parameters with ``.grad`` go
     through ``collie_dense_optim_step``; tables whose gradient the backward staged as an
@@ -389,12 +408,19 @@ class HybridPretrainedModel(MatrixFactorizationModel):
             ((users, pos_items), neg_items) = batch
             if neg_items.dim() == 1:
                 neg_items = neg_items.reshape(-1, 1)
-            users = users.long()
-            pos_items = pos_items.long()
-            neg_items = torch.transpose(neg_items, 0, 1).long()
-            K, B = neg_items.shape
-            all_users = users.repeat(K + 1)
-            all_items = torch.cat([pos_items, neg_items.flatten()])
+            B, K = neg_items.shape
+            if (users.is_cuda and 1 <= K <= _lib.MAX_NEG and B >= 1
+                    and B * (1 + K) < (1 << 30)):
+                # the (1 + K) B pairs in one launch (int64 ids, positives first)
+                all_users, all_items = ops.pair_ids(users, pos_items, neg_items)
+                pos_items = all_items[:B]
+                neg_items = all_items[B:].view(K, B)
+            else:
+                users = users.long()
+                pos_items = pos_items.long()
+                neg_items = torch.transpose(neg_items, 0, 1).long()
+                all_users = users.repeat(K + 1)
+                all_items = torch.cat([pos_items, neg_items.flatten()])
             from collie_amd import loss as loss_mod
             kind = getattr(self, '_loss_kind', None)
             if (K > 1 and kind in self._ONE_NEGATIVE_LOSSES
@@ -407,8 +433,7 @@ class HybridPretrainedModel(MatrixFactorizationModel):
                 preds = self(all_users, all_items)
             finally:        # the hints describe THIS call only, whatever happens inside it
                 self._active_rows_hint = self._user_period_hint = None
-            pos_preds = preds[:B]
-            neg_preds = preds[B:].view(K, B)
+            pos_preds, neg_preds = _SplitScores.apply(preds, B, K)
             return self.loss_function(
                 pos_preds, neg_preds, num_items=self.hparams.num_items, positive_items=pos_items,
                 negative_items=neg_items, metadata=self.hparams.get('metadata_for_loss'),

@@ -438,6 +438,18 @@ def active_rows(g, batch, num_neg, users, items):
     return act, g_out, u_out, i_out
 
 
+def pair_ids(users, pos_items, neg_items):
+    """``collie_pair_ids``: (all_users, all_items), each [(1 + K) B] int64, in ``calculate_loss``'s
+    order (the B positives, then negative k of every sample)."""
+    batch = make_batch(users, pos_items, neg_items)
+    B, K = neg_items.shape
+    all_users = torch.empty((1 + K) * B, dtype=torch.int64, device=users.device)
+    all_items = torch.empty((1 + K) * B, dtype=torch.int64, device=users.device)
+    check(load().collie_pair_ids(byref(batch), ptr(all_users), ptr(all_items), stream_ptr()),
+          'collie_pair_ids')
+    return all_users, all_items
+
+
 def gather_rows(tensors, idx, status=None):
     """``[t.index_select(0, idx) for t in tensors]`` for 2-d float32 tensors with the same number of
     rows, four per launch (``collie_gather_rows``)."""

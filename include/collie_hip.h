@@ -719,6 +719,13 @@ int collie_active_rows(const float* g, int64_t batch, int32_t num_neg, const int
                        const int64_t* items, int64_t* act, float* g_out, int64_t* users_out,
                        int64_t* items_out, collie_stream_t stream);
 
+/* calculate_loss's expansion of a batch into its (1 + K) B (user, item) pairs
+ * (base_pipeline.py:603-622: users.repeat(K + 1); cat(pos_items, neg_items.T.flatten())), ids
+ * widened to int64: pair k B + b is (users[b], k == 0 ? pos[b] : neg[b, k - 1]).  One launch
+ * instead of the five torch ops; all_users / all_items are [(1 + K) B] int64. */
+int collie_pair_ids(const collie_mf_batch* b, int64_t* all_users, int64_t* all_items,
+                    collie_stream_t stream);
+
 /* outs[t][j, :] = srcs[t][idx[j], :] for up to 4 row-major float tensors at once (the saved
  * activations of the head gathered down to the rows above: torch.index_select, one launch instead
  * of one per tensor).  srcs[t] is [m_src, lds[t]] with widths[t] used columns, outs[t] is
