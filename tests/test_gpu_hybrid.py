@@ -910,3 +910,62 @@ def test_hybrid_forward_backward_vs_numpy_oracle(dev):
         got = np.zeros(table.shape, np.float64)
         np.add.at(got, ids.cpu().numpy(), vals.cpu().numpy().reshape(len(ids), -1))
         close(got, want[name])
+
+
+@pytest.mark.parametrize('B,K', [(1, 1), (257, 7), (4096, 10)])
+def test_active_rows_equals_torch_selection(dev, B, K):
+    """collie_active_rows = arange / |g|.argmax / stack / index_select of _compact_rows' first
+    version: first maximum on ties, k = 0 when every negative gradient is zero."""
+    from collie_amd import ops
+    rng = np.random.default_rng(B + K)
+    m = (1 + K) * B
+    g = rng.normal(size=m).astype(np.float32)
+    gn = g[B:].reshape(K, B)
+    gn[:, ::3] = 0.0                                          # no negative carries a gradient
+    if K > 2:
+        gn[2, 1::3] = gn[0, 1::3] = 9.0                       # tie: the first maximum wins
+        gn[1, 1::3] = -9.0 if K > 1 else gn[1, 1::3]
+    g = torch.tensor(g, device=dev)
+    users = torch.tensor(rng.integers(0, 1000, m), device=dev)
+    items = torch.tensor(rng.integers(0, 1000, m), device=dev)
+    act, g2, u2, i2 = ops.active_rows(g, B, K, users, items)
+    ar = torch.arange(B, device=dev)
+    ksel = g[B:].view(K, B).abs().argmax(dim=0)
+    want = torch.stack([ar, B + ksel * B + ar], dim=1).reshape(-1)
+    assert torch.equal(act, want)
+    assert torch.equal(g2, g[want]) and torch.equal(u2, users[want]) and torch.equal(i2, items[want])
+
+
+@pytest.mark.parametrize('widths', [(128, 128, 64, 32), (5,), (12, 7, 64, 3, 256, 8)])
+def test_gather_rows_equals_index_select(dev, widths):
+    from collie_amd import ops
+    rng = np.random.default_rng(len(widths))
+    m_src, m_out = 1000, 777
+    base = [torch.tensor(rng.normal(size=(m_src, w + 4)).astype(np.float32), device=dev)
+            for w in widths]
+    tensors = [b[:, :w] for b, w in zip(base, widths)]        # row stride larger than the width
+    idx = torch.tensor(rng.integers(0, m_src, m_out), device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    got = ops.gather_rows(tensors, idx, status)
+    for t, o in zip(tensors, got):
+        assert o.is_contiguous() and torch.equal(o, t.index_select(0, idx))
+    assert int(status) == 0
+    bad = idx.clone()
+    bad[5] = m_src
+    got = ops.gather_rows(tensors[:1], bad, status)
+    assert int(status) == 1 and float(got[0][5].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize('dtypes', [(torch.int32, torch.int32, torch.int64),
+                                    (torch.int64, torch.int32, torch.int32)])
+def test_pair_ids_equals_repeat_and_cat(dev, dtypes):
+    from collie_amd import ops
+    rng = np.random.default_rng(4)
+    B, K = 333, 6
+    users = torch.tensor(rng.integers(0, 10**6, B), device=dev).to(dtypes[0])
+    pos = torch.tensor(rng.integers(0, 10**6, B), device=dev).to(dtypes[1])
+    neg = torch.tensor(rng.integers(0, 10**6, (B, K)), device=dev).to(dtypes[2])
+    for n in (neg, neg.t().contiguous().t()):                 # row-major and strided negatives
+        au, ai = ops.pair_ids(users, pos, n)
+        assert torch.equal(au, users.long().repeat(K + 1))
+        assert torch.equal(ai, torch.cat([pos.long(), n.t().long().flatten()]))
