@@ -2155,12 +2155,26 @@ extern "C" int collie_dense_rows_update(float* table, int64_t num_rows, int32_t 
                                         size_t workspace_bytes, int32_t* status,
                                         collie_stream_t stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  COLLIE_REQUIRE(table && rows && vals && cfg, "dense_rows_update: NULL pointer");
+  COLLIE_REQUIRE(table && cfg && (m == 0 || (rows && vals)), "dense_rows_update: NULL pointer");
   COLLIE_REQUIRE(num_rows >= 1 && num_rows < (int64_t{1} << 31) && dim >= 1,
                  "dense_rows_update: bad table shape");
-  COLLIE_REQUIRE(m >= 1 && m < (int64_t{1} << 30), "dense_rows_update: bad entry count");
+  COLLIE_REQUIRE(m >= 0 && m < (int64_t{1} << 30), "dense_rows_update: bad entry count");
   COLLIE_REQUIRE(cfg->algo != COLLIE_OPT_SPARSE_ADAM,
                  "SparseAdam does not support dense gradients, please consider Adam instead");
+  if (m == 0) {
+    // an all-zero gradient: no row has an entry, every row takes the zero-gradient update (Adam's
+    // moment decay, weight decay) -- the sweep alone, with stamps that match no row
+    if (cfg->algo != COLLIE_OPT_ADAM && cfg->weight_decay == 0.0f) return 0;
+    COLLIE_REQUIRE(row_stamp != nullptr,
+                   "dense Adam / weight decay need row_stamp = int32[rows] scratch");
+    float* z1 = cfg->algo == COLLIE_OPT_SGD ? nullptr : state1;
+    float* z2 = cfg->algo == COLLIE_OPT_ADAM ? state2 : nullptr;
+    Hyper h;
+    if (make_hyper(h, cfg, 1, true, z1, z2)) return -1;
+    hipLaunchKernelGGL(dense_sweep_kernel, dim3(sweep_grid(num_rows * dim)), dim3(kBlock), 0, stream,
+                       table, z1, z2, row_stamp, num_rows, dim, cfg->step, h, nullptr, 0);
+    return check_launch("dense_sweep_kernel");
+  }
   Carver c(workspace);
   SortWs s;
   carve_sort_ws(c, s, m, dim);

@@ -672,7 +672,8 @@ class HybridPretrainedModel(MatrixFactorizationModel):
         return take(users), take(items), out, take(g)
 
     def _head_backward(self, users, items, saved, g, active_hint=None):
-        if active_hint is not None and g.shape[0] == (active_hint[1] + 1) * active_hint[0]:
+        compact = active_hint is not None and g.shape[0] == (active_hint[1] + 1) * active_hint[0]
+        if compact:
             users, items, saved, g = self._compact_rows(users, items, saved, g, active_hint)
         m = users.shape[0]
         grads = {}
@@ -681,6 +682,12 @@ class HybridPretrainedModel(MatrixFactorizationModel):
         for table, ids in ((self.biases[0].weight, users), (self.biases[1].weight, items)):
             if table.requires_grad:
                 self._staged_rows[id(table)] = (ids, g)
+        if compact and self.biases[0].weight.requires_grad:
+            # The one-negative losses give a sample's negative exactly minus its positive's score
+            # gradient, and both rows share the user: in the compact batch they are neighbours, so
+            # every user-bias row's sum is (+g) + (-g) = an exact 0, pair by pair.  An empty entry
+            # list says the same thing without the sort: every row takes the zero-gradient update.
+            self._staged_rows[id(self.biases[0].weight)] = (users[:0], g[:0])
         combined = saved['combined']
         for li in range(len(combined) - 1, 0, -1):
             x_segs, out = combined[li]

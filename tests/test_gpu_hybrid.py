@@ -191,7 +191,8 @@ def test_hybrid_user_share_of_first_layer_once_per_sample(dev, monkeypatch):
                  if p.grad is not None}
         rows = {n: torch.zeros_like(p).index_add_(0, model._staged_rows[id(p)][0].long(),
                                                   model._staged_rows[id(p)][1].reshape(
-                                                      model._staged_rows[id(p)][0].shape[0], -1))
+                                                      model._staged_rows[id(p)][0].shape[0],
+                                                      p.shape[1]))
                 .cpu().numpy() for n, p in model.named_parameters() if id(p) in model._staged_rows}
         return float(loss), grads, rows
 
@@ -519,7 +520,8 @@ def test_hybrid_forward_and_trajectory_vs_torch_path(dev, case):
                 if staged is not None:
                     ids, vals = staged
                     got = np.zeros(p.shape, np.float64)
-                    np.add.at(got, ids.cpu().numpy(), vals.cpu().numpy().reshape(len(ids), -1))
+                    if len(ids):     # (an empty list: an all-zero gradient)
+                        np.add.at(got, ids.cpu().numpy(), vals.cpu().numpy().reshape(len(ids), -1))
                 else:
                     got = p.grad.cpu().numpy()
                 want = rparams[name].grad.numpy()
@@ -573,6 +575,9 @@ def test_one_negative_losses_give_at_most_one_negative_a_gradient(dev, kind):
                            metadata={'genre': genre}, metadata_weights={'genre': 0.3}).backward()
     per_sample = (neg.grad != 0).sum(0)
     assert int(per_sample.max()) <= 1
+    # ... and that negative gets exactly minus the positive's gradient (the compact backward drops
+    # the user-bias entries on this ground: (+g) + (-g) = 0 pair by pair)
+    assert torch.equal(neg.grad.sum(0), -pos.grad)
     assert int(per_sample.sum()) > B // 4                    # (the case is not vacuous)
 
 
@@ -612,13 +617,15 @@ def test_hybrid_backward_on_active_rows_equals_full_backward(dev, loss, frozen, 
             if staged is not None:
                 ids, vals = staged
                 dense = np.zeros(p.shape, np.float64)
-                np.add.at(dense, ids.cpu().numpy(), vals.cpu().numpy().reshape(len(ids), -1))
+                if len(ids):     # (an empty list: an all-zero gradient)
+                    np.add.at(dense, ids.cpu().numpy(), vals.cpu().numpy().reshape(len(ids), -1))
                 out[name] = (dense, len(ids))
             else:
                 out[name] = (p.grad.cpu().numpy().astype(np.float64), None)
         return out
 
     got = grads()
+    user_bias_name = next(n for n, p in model.named_parameters() if p is model.biases[0].weight)
     monkeypatch.setattr(HybridPretrainedModel, '_ONE_NEGATIVE_LOSSES', ())
     want = grads()
     assert got.keys() == want.keys()
@@ -626,7 +633,8 @@ def test_hybrid_backward_on_active_rows_equals_full_backward(dev, loss, frozen, 
         g, n_rows = got[name]
         w, n_rows_full = want[name]
         if n_rows is not None:       # staged (row, value) lists: 2 B entries instead of (1 + K) B
-            assert (n_rows, n_rows_full) == (2 * B, (1 + K) * B)
+            # (the user biases: none at all -- their compact sums are exact zeros pair by pair)
+            assert (n_rows, n_rows_full) == (0 if name == user_bias_name else 2 * B, (1 + K) * B)
         # entries that cancel analytically (+g and -g of every sample: user biases, the last
         # Linear bias) are rounding residue of 2 B terms of size ~|g| in the full backward and
         # cancel pair by pair in the compact one: the floor of the scale covers that residue
@@ -677,7 +685,8 @@ def test_hybrid_vs_the_reference_hybrid_model(dev, golden_dir, tag, loss):
         if staged is not None:
             ids, vals = staged
             got = np.zeros(p.shape, np.float64)
-            np.add.at(got, ids.cpu().numpy(), vals.cpu().numpy().reshape(len(ids), -1))
+            if len(ids):     # (an empty list: an all-zero gradient)
+                np.add.at(got, ids.cpu().numpy(), vals.cpu().numpy().reshape(len(ids), -1))
         else:
             got = p.grad.cpu().numpy()
         want = c[key]
@@ -908,7 +917,8 @@ def test_hybrid_forward_backward_vs_numpy_oracle(dev):
                         ('user_biases', model.biases[0].weight), ('item_biases', model.biases[1].weight)):
         ids, vals = model._staged_rows[id(table)]
         got = np.zeros(table.shape, np.float64)
-        np.add.at(got, ids.cpu().numpy(), vals.cpu().numpy().reshape(len(ids), -1))
+        if len(ids):     # (an empty list: an all-zero gradient)
+            np.add.at(got, ids.cpu().numpy(), vals.cpu().numpy().reshape(len(ids), -1))
         close(got, want[name])
 
 
