@@ -598,7 +598,10 @@ def main():
     local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
-    if world > 1:
+    if world > 1 or os.environ.get('COLLIE_BENCH_SHARDED_WORLD1') == '1':
+        # (COLLIE_BENCH_SHARDED_WORLD1=1 under torch.distributed.run --nproc-per-node 1: the whole
+        # N > 1 code path on one rank, every collective issued to RCCL -- a rehearsal of the line the
+        # driver's multi-GPU run prints, for boxes with one GPU)
         return main_sharded(args, world, rank, device)
 
     leg = train_leg(args.shape, args, device, args.steps, args.warmup)
