@@ -784,7 +784,9 @@ int collie_dense_optim_step(float* param, const float* grad, int64_t n,
  * embedding tables of the hybrid model.  Rows with entries get the summed gradient (input order,
  * deterministic); every other row gets the zero-gradient update where that is not the identity
  * (Adam's moment decay, weight decay), which needs row_stamp = int32 [num_rows] scratch owned by the
- * optimizer (zero-filled at creation).  workspace: collie_sparse_rows_workspace_bytes(m, dim). */
+ * optimizer (zero-filled at creation).  workspace: collie_sparse_rows_workspace_bytes(m, dim).
+ * m = 0 (rows / vals / workspace may be NULL): an all-zero gradient, every row takes the
+ * zero-gradient update. */
 int collie_dense_rows_update(float* table, int64_t num_rows, int32_t dim, const void* rows,
                              int32_t rows_dtype, const float* vals, int64_t m,
                              const collie_optim_cfg* cfg, float* state1, float* state2,

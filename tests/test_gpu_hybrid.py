@@ -398,16 +398,17 @@ def test_dense_optimizers_vs_torch(dev, algo, kw):
     stamp = torch.zeros(90, dtype=torch.int32, device=dev)
     for step in range(1, 4):
         g = rng.normal(size=p0.shape).astype(np.float32)
-        rows = rng.integers(0, 30, 200)          # rows 30.. never get an entry
-        vals = rng.normal(size=(200, 8)).astype(np.float32)
+        n = 0 if step == 2 else 200              # step 2: an empty list = an all-zero gradient
+        rows = rng.integers(0, 30, n)            # rows 30.. never get an entry
+        vals = rng.normal(size=(n, 8)).astype(np.float32)
         pc.grad = torch.tensor(g)
         tc.grad = torch.zeros_like(tc).index_add_(0, torch.tensor(rows), torch.tensor(vals))
         opt.step()
         cfg = ops.optim_cfg(algo, step, kw['lr'], weight_decay=kw.get('weight_decay', 0.0),
                             eps=1e-10 if algo == 'adagrad' else 1e-8)
         ops.dense_optim_step(pg, torch.tensor(g, device=dev), cfg, s['p1'], s['p2'])
-        ops.dense_rows_update(tg, torch.tensor(rows, device=dev), torch.tensor(vals, device=dev),
-                              cfg, s['t1'], s['t2'], stamp)
+        ops.dense_rows_update(tg, torch.tensor(rows, dtype=torch.int64, device=dev),
+                              torch.tensor(vals, device=dev), cfg, s['t1'], s['t2'], stamp)
     close(pg.cpu().numpy(), pc.detach().numpy(), 2e-5)
     close(tg.cpu().numpy(), tc.detach().numpy(), 2e-5)
 
