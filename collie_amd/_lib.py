@@ -211,6 +211,9 @@ SIGNATURES = {
     'collie_gather_rows': (ctypes.c_int, [c_int32, POINTER(c_void_p), POINTER(c_int64),
                                           POINTER(c_int32), POINTER(c_void_p), c_void_p, c_int64,
                                           c_int64, c_void_p, c_void_p]),
+    'collie_dense_optim_step_multi': (ctypes.c_int, [c_int32, POINTER(c_void_p), POINTER(c_void_p),
+                                                     POINTER(c_int64), POINTER(OptimCfg),
+                                                     POINTER(c_void_p), POINTER(c_void_p), c_void_p]),
     'collie_dense_outer_sum': (ctypes.c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
                                               c_void_p, c_int32, c_int32, c_float, c_void_p, c_int64,
                                               c_void_p]),

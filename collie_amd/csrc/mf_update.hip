@@ -2129,8 +2129,79 @@ __global__ __launch_bounds__(kBlock) void flat_update_kernel(float* __restrict__
   }
 }
 
+// the same for up to kMultiMax parameters of one optimizer group in ONE launch (the head has ten
+// small tensors: ten launches of 2-5 us each otherwise); block b works on tensor t with
+// first_block[t] <= b < first_block[t + 1]
+constexpr int kMultiMax = 16;
+struct MultiFlat {
+  int n;
+  float* param[kMultiMax];
+  const float* grad[kMultiMax];
+  float* s1[kMultiMax];
+  float* s2[kMultiMax];
+  int64_t numel[kMultiMax];
+  int first_block[kMultiMax + 1];
+};
+
+__global__ __launch_bounds__(kBlock) void flat_update_multi_kernel(const MultiFlat m, const Hyper h) {
+  int t = 0;
+  while (t + 1 < m.n && static_cast<int>(blockIdx.x) >= m.first_block[t + 1]) ++t;
+  const int64_t nblk = m.first_block[t + 1] - m.first_block[t];
+  const int64_t stride = nblk * kBlock;
+  float* param = m.param[t];
+  const float* grad = m.grad[t];
+  float* s1p = m.s1[t];
+  float* s2p = m.s2[t];
+  for (int64_t i = (static_cast<int64_t>(blockIdx.x) - m.first_block[t]) * kBlock + threadIdx.x;
+       i < m.numel[t]; i += stride) {
+    float s1 = s1p ? s1p[i] : 0.0f;
+    float s2 = s2p ? s2p[i] : 0.0f;
+    param[i] = apply_update(h, param[i], grad[i], s1, s2);
+    if (s1p) s1p[i] = s1;
+    if (s2p) s2p[i] = s2;
+  }
+}
+
 }  // namespace
 }  // namespace collie
+
+extern "C" int collie_dense_optim_step_multi(int32_t n, float* const* params,
+                                             const float* const* grads, const int64_t* numels,
+                                             const collie_optim_cfg* cfg, float* const* state1,
+                                             float* const* state2, collie_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  COLLIE_REQUIRE(n >= 1 && n <= kMultiMax, "dense_optim_step_multi: 1..%d tensors per call", kMultiMax);
+  COLLIE_REQUIRE(params && grads && numels && cfg, "dense_optim_step_multi: NULL pointer");
+  COLLIE_REQUIRE(cfg->algo != COLLIE_OPT_SPARSE_ADAM,
+                 "SparseAdam does not support dense gradients, please consider Adam instead");
+  const bool want1 = cfg->algo != COLLIE_OPT_SGD, want2 = cfg->algo == COLLIE_OPT_ADAM;
+  COLLIE_REQUIRE((!want1 || state1) && (!want2 || state2), "dense_optim_step_multi: missing state");
+  MultiFlat m;
+  memset(&m, 0, sizeof(m));
+  m.n = n;
+  int blocks = 0;
+  for (int t = 0; t < n; ++t) {
+    COLLIE_REQUIRE(params[t] && grads[t] && numels[t] >= 1,
+                   "dense_optim_step_multi: tensor %d: NULL pointer / empty", t);
+    m.param[t] = params[t];
+    m.grad[t] = grads[t];
+    m.s1[t] = want1 ? state1[t] : nullptr;
+    m.s2[t] = want2 ? state2[t] : nullptr;
+    COLLIE_REQUIRE((!want1 || m.s1[t]) && (!want2 || m.s2[t]),
+                   "dense_optim_step_multi: tensor %d: missing state", t);
+    m.numel[t] = numels[t];
+    m.first_block[t] = blocks;
+    int64_t b = (numels[t] + 4 * kBlock - 1) / (4 * kBlock);     // four elements per thread
+    if (b > 1024) b = 1024;
+    blocks += static_cast<int>(b);
+  }
+  m.first_block[n] = blocks;
+  Hyper h;
+  if (make_hyper(h, cfg, 1, true, m.s1[0], m.s2[0])) return -1;
+  hipLaunchKernelGGL(flat_update_multi_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0,
+                     stream, m, h);
+  return check_launch("flat_update_multi_kernel");
+}
 
 extern "C" int collie_dense_optim_step(float* param, const float* grad, int64_t n,
                                        const collie_optim_cfg* cfg, float* state1, float* state2,

@@ -92,6 +92,7 @@ class _HeadMixin:
                 loss = closure()
         model = self._collie_model
         for group in self.param_groups:
+            dense = {}      # step count -> the group's dense parameters at that count: one launch
             for p in group['params']:
                 staged = model._staged_rows.pop(id(p), None)
                 if staged is None and p.grad is None:
@@ -104,7 +105,19 @@ class _HeadMixin:
                         model._rows_ws)
                 else:
                     grad = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                    ops.dense_optim_step(p.data, grad, cfg, s1, s2)
+                    if grad.dtype != torch.float32 or not p.data.is_contiguous():
+                        ops.dense_optim_step(p.data, grad, cfg, s1, s2)
+                        continue
+                    bucket = dense.setdefault(int(cfg.step), (cfg, [], [], [], []))
+                    for lst, t in zip(bucket[1:], (p.data, grad, s1, s2)):
+                        lst.append(t)
+            for cfg, ps, gs, s1s, s2s in dense.values():
+                if len(ps) == 1:
+                    ops.dense_optim_step(ps[0], gs[0], cfg, s1s[0], s2s[0])
+                else:
+                    ops.dense_optim_step_multi(ps, gs, cfg,
+                                               s1s if s1s[0] is not None else None,
+                                               s2s if s2s[0] is not None else None)
         return loss
 
 

@@ -541,6 +541,25 @@ def dense_optim_step(param, grad, cfg, state1=None, state2=None, grad_scale=None
         stream_ptr()), 'collie_dense_optim_step')
 
 
+def dense_optim_step_multi(params, grads, cfg, state1=None, state2=None):
+    """``dense_optim_step`` for several parameters of one optimizer group, 16 per launch."""
+    for i0 in range(0, len(params), 16):
+        ps, gs = params[i0:i0 + 16], grads[i0:i0 + 16]
+        n = len(ps)
+        for p_, g_ in zip(ps, gs):
+            require_hip(p_, 'parameter')
+            assert p_.is_contiguous() and g_.is_contiguous() and g_.dtype == torch.float32 \
+                and g_.numel() == p_.numel()
+
+        def arr(ts):
+            if ts is None:
+                return None
+            return (c_void_p * n)(*[t.data_ptr() if t is not None else None for t in ts[i0:i0 + 16]])
+        check(load().collie_dense_optim_step_multi(
+            n, arr(params), arr(grads), (ctypes.c_int64 * n)(*[p_.numel() for p_ in ps]),
+            byref(cfg), arr(state1), arr(state2), stream_ptr()), 'collie_dense_optim_step_multi')
+
+
 def dense_rows_update(table, rows, vals, cfg, state1=None, state2=None, row_stamp=None,
                       status=None, workspace=None):
     """Dense-gradient optimizers on a table whose gradient is an uncoalesced COO list."""

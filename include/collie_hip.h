@@ -779,6 +779,14 @@ int collie_dense_optim_step(float* param, const float* grad, int64_t n,
                             const collie_optim_cfg* cfg, float* state1, float* state2,
                             const float* grad_scale, collie_stream_t stream);
 
+/* The same step for up to 16 parameters of ONE optimizer group (same cfg) in one launch: the head's
+ * ten small Linear weights and biases.  params / grads / numels / state1 / state2 are HOST arrays of
+ * n entries (state arrays may be NULL where the algorithm keeps no such state). */
+int collie_dense_optim_step_multi(int32_t n, float* const* params, const float* const* grads,
+                                  const int64_t* numels, const collie_optim_cfg* cfg,
+                                  float* const* state1, float* const* state2,
+                                  collie_stream_t stream);
+
 /* The same optimizers on a table whose dense gradient is given as an UNCOALESCED COO list (rows [m],
  * vals [m, dim]): what nn.Embedding(sparse=False).backward + a dense optimizer do to the bias /
  * embedding tables of the hybrid model.  Rows with entries get the summed gradient (input order,

@@ -980,3 +980,28 @@ def test_pair_ids_equals_repeat_and_cat(dev, dtypes):
         au, ai = ops.pair_ids(users, pos, n)
         assert torch.equal(au, users.long().repeat(K + 1))
         assert torch.equal(ai, torch.cat([pos.long(), n.t().long().flatten()]))
+
+
+@pytest.mark.parametrize('algo', ['adam', 'sgd', 'adagrad'])
+def test_dense_optim_step_multi_equals_single_steps(dev, algo):
+    """One launch over several parameters of a group = one launch per parameter, bit for bit."""
+    from collie_amd import ops
+    rng = np.random.default_rng(2)
+    shapes = [(128, 384), (128,), (64, 128), (64,), (1, 32), (1,), (3, 5)] + [(7,)] * 12
+    ps = [torch.tensor(rng.normal(size=s).astype(np.float32), device=dev) for s in shapes]
+    gs = [torch.tensor(rng.normal(size=s).astype(np.float32), device=dev) for s in shapes]
+    single = [p.clone() for p in ps]
+    st = {k: [torch.zeros_like(p) for p in ps] for k in ('a1', 'a2', 'b1', 'b2')}
+    for step in (1, 2):
+        cfg = ops.optim_cfg(algo, step, 1e-2, weight_decay=1e-3 if algo != 'adagrad' else 0.0,
+                            eps=1e-10 if algo == 'adagrad' else 1e-8)
+        s1 = st['a1'] if algo != 'sgd' else None
+        s2 = st['a2'] if algo == 'adam' else None
+        ops.dense_optim_step_multi(ps, gs, cfg, s1, s2)           # 19 tensors: two launches
+        for i, p in enumerate(single):
+            ops.dense_optim_step(p, gs[i], cfg, st['b1'][i] if algo != 'sgd' else None,
+                                 st['b2'][i] if algo == 'adam' else None)
+    for a, b in zip(ps, single):
+        assert torch.equal(a, b)
+    for a, b in zip(st['a1'] + st['a2'], st['b1'] + st['b2']):
+        assert torch.equal(a, b)
