@@ -575,7 +575,7 @@ def main():
                     help='steps of the Zipf(1.05)-ids leg of the default line (0 = skip it)')
     ap.add_argument('--eval-users', type=int, default=65536,
                     help='users in the eval leg (0 = skip it)')
-    ap.add_argument('--hybrid-steps', type=int, default=10,
+    ap.add_argument('--hybrid-steps', type=int, default=20,
                     help="steps of the configs[4] leg (hybrid MLP head, reported under 'hybrid'; "
                          '0 = skip it; single-GPU runs only)')
     ap.add_argument('--small-batch-steps', type=int, default=3000,
@@ -648,7 +648,7 @@ def main():
         result['eval'] = eval_leg(device, args.eval_users)
     if args.hybrid_steps > 0 and args.shape == 'c2':
         torch.cuda.empty_cache()
-        leg = hybrid_leg(args.hybrid_steps, 3)
+        leg = hybrid_leg(args.hybrid_steps, 8)  # (3 warm-up steps left the first timed ones 5 % slow)
         result['hybrid'] = {k: leg[k] for k in ('metric', 'value', 'unit', 'ms_per_step',
                                                 'config', 'roofline')}
         del leg
