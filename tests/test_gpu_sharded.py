@@ -121,6 +121,34 @@ def test_world_2_on_one_gpu_matches_unsharded_oracle():
     assert 'rank 0: sharded checks ok' in out.stdout and 'rank 1: sharded checks ok' in out.stdout
 
 
+@pytest.mark.parametrize('shape', [(1, 1, 5, 2), (3, 63, 40, 1), (64, 64, 300, 4), (65, 129, 7, 63),
+                                   (16385, 16383, 2000, 3)])
+@pytest.mark.parametrize('G', [1, 5, 16])
+def test_hip_shard_plan_edge_sizes(shape, G):
+    """Key spaces that end inside / at / just behind a 64-key word or a 16,384-key workgroup range,
+    one-row tables, the largest world: the marks-and-ranks route against plan_torch."""
+    from collie_amd import ops
+    from collie_amd.sharded import plan_torch
+    dev = torch.device('cuda:0')
+    U, N, B, K = shape
+    D = 8
+    rng = np.random.default_rng(U + N + G)
+    planner = ops.ShardPlanner(U, N, G, D, dev)
+    for local_rank in (-1, 0):
+        users = rng.integers(0, U, B)
+        if local_rank >= 0:
+            users = users // G * G                             # users owned by rank 0
+        users = torch.tensor(users, dtype=torch.int64, device=dev)
+        pos = torch.tensor(rng.integers(0, N, B), dtype=torch.int32, device=dev)
+        neg = torch.tensor(rng.integers(0, N, (B, K)), device=dev)
+        cu, cp, cn, rows, counts = planner.plan(users, pos, neg, local_rank)
+        tu, tp, tn, trows, tcounts = plan_torch(users, pos, neg, U, N, G, D, local_rank)
+        assert torch.equal(counts, tcounts)
+        n = int(counts[2 * G])
+        assert torch.equal(rows[:n], trows)
+        assert torch.equal(cu, tu) and torch.equal(cp, tp) and torch.equal(cn, tn)
+
+
 @pytest.mark.parametrize('local_rank', [-1, 0, 2])
 @pytest.mark.parametrize('G', [1, 2, 3, 8])
 @pytest.mark.parametrize('neg_dtype', [torch.int64, torch.int32])
