@@ -395,6 +395,7 @@ def main_sharded(args, world, rank, device):
                                             for k in ('bytes_in', 'bytes_out')},
                 'single_gpu_same_workload': "the 'c4' object of the N=1 line (python bench.py): "
                                             'same tables and global batch on one GPU, fused route',
+                'single_gpu_same_workload_recorded': recorded_c4(),
                 'final_loss': float(loss.item()),
                 'rows_exchanged_per_rank_per_step': model.last_exchange.get('rows_requested'),
                 'gradient_rows_sent_per_rank_per_step': model.last_exchange.get('gradient_rows_sent'),
@@ -518,6 +519,23 @@ def launch_ranks(n):
         print(lines[-1])
     sys.stdout.flush()
     raise SystemExit(child.returncode if child.returncode or lines else 1)
+
+
+def recorded_c4():
+    """The single-GPU number of the N > 1 workload as the last committed N = 1 line has it
+    (profiles/rNN_bench_default.json, 'c4' object): what `value` of an N > 1 line is to be compared
+    with -- the N = 1 line's own `value` is a different workload (configs[1])."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_bench_default.json')), reverse=True):
+        try:
+            with open(path) as f:
+                c4 = json.loads(f.read().strip().splitlines()[-1]).get('c4') or {}
+            if 'value' in c4:
+                return {'value': c4['value'], 'unit': c4.get('unit'), 'ms_per_step': c4.get('ms_per_step'),
+                        'source': os.path.relpath(path, ROOT)}
+        except (OSError, ValueError):
+            continue
+    return None
 
 
 def rccl_selftest(device, world, backend):
