@@ -395,7 +395,8 @@ def main_sharded(args, world, rank, device):
                                             for k in ('bytes_in', 'bytes_out')},
                 'single_gpu_same_workload': "the 'c4' object of the N=1 line (python bench.py): "
                                             'same tables and global batch on one GPU, fused route',
-                'single_gpu_same_workload_recorded': recorded_c4(),
+                'single_gpu_same_workload_recorded': (recorded_c4() if args.sharded_shape == 'c4'
+                                                      else None),
                 'final_loss': float(loss.item()),
                 'rows_exchanged_per_rank_per_step': model.last_exchange.get('rows_requested'),
                 'gradient_rows_sent_per_rank_per_step': model.last_exchange.get('gradient_rows_sent'),
